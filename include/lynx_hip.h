@@ -1,0 +1,179 @@
+/*
+ * liblynxhip -- C ABI of the MI355X (gfx950) beam-tracking hot path.
+ *
+ * This is the drop-in boundary for jank324/lynx's `Segment.track()` path.  The reference
+ * has no FFI of its own (it is pure Python on jax.numpy); the functions below are what a
+ * binding for that path replaces, and each one cites the reference interface it stands
+ * for (paths relative to the reference repository).  Plain pointers and sizes only; every
+ * `d_*` pointer is device memory obtained from lynx_buf_alloc.
+ *
+ * Status convention: every function returns 0 on success and a negative lynx_status on
+ * failure; lynx_last_error() returns the message of the last failure on that context.
+ */
+#ifndef LYNX_HIP_H
+#define LYNX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lynx_ctx lynx_ctx;
+typedef struct lynx_lattice lynx_lattice;
+
+enum lynx_status {
+  LYNX_OK = 0,
+  LYNX_ERR_INVALID = -1, /* bad argument / shape mismatch */
+  LYNX_ERR_HIP = -2,     /* HIP runtime error            */
+  LYNX_ERR_RCCL = -3,    /* RCCL error                   */
+  LYNX_ERR_NOMEM = -4
+};
+
+enum lynx_dtype { LYNX_F32 = 0, LYNX_F64 = 1 };
+
+/* Element kinds on the path (reference: the element modules under lynx/accelerator/). */
+enum lynx_kind {
+  LYNX_KIND_IDENTITY = 0,   /* Marker (marker.py:32-35), inactive BPM (bpm.py:43-46)   */
+  LYNX_KIND_DRIFT = 1,      /* drift.py:44-62               params [L]                 */
+  LYNX_KIND_QUADRUPOLE = 2, /* quadrupole.py:66-80          params [L,k1,tilt,mx,my]   */
+  LYNX_KIND_DIPOLE = 3,     /* dipole.py:112-181, rbend.py  params [L,angle,e1,e2,tilt,fint,fintx,gap] */
+  LYNX_KIND_HCOR = 4,       /* horizontal_corrector.py:52-67 params [L,angle]          */
+  LYNX_KIND_VCOR = 5,       /* vertical_corrector.py:52-66  params [L,angle]           */
+  LYNX_KIND_CAVITY = 6,     /* cavity.py:97-325             params [L,V,phase_deg,f]   */
+  LYNX_KIND_CUSTOM = 7      /* custom_transfer_map.py:87-88 params [49 map entries]    */
+};
+
+/*
+ * Whole-batch predicates.  The reference evaluates these as Python `if any(...)` over the
+ * whole batch (so they are host decisions there too); the host evaluates them once per
+ * lattice and hands them to the kernels as flags.
+ */
+#define LYNX_FLAG_TILT 1        /* quadrupole: any(tilt != 0)          track_methods.py:101 */
+#define LYNX_FLAG_MISALIGNED 2  /* quadrupole: !all(misalignment == 0) quadrupole.py:75    */
+#define LYNX_FLAG_THICK 4       /* dipole: any(length != 0)            dipole.py:119        */
+#define LYNX_FLAG_CAV_BETA 8    /* cavity: any(V != 0 & E != 0)        cavity.py:290        */
+#define LYNX_FLAG_CAV_GAIN 16   /* cavity: any(E + dE > 0)             cavity.py:128        */
+#define LYNX_FLAG_CAV_T5XX 32   /* cavity: any(dE > 0)                 cavity.py:164        */
+
+/* One lattice element.  Sample b reads its parameters at
+ * pool[param_offset + b * batch_stride + j]; batch_stride == 0 means "same for all samples". */
+typedef struct lynx_elem {
+  int32_t kind;
+  int32_t flags;
+  int32_t param_offset;
+  int32_t batch_stride;
+} lynx_elem;
+
+/* A step of the tracking program = what `Segment.track` calls a "todo"
+ * (segment.py:344-354): a maximal run of skippable elements whose maps are composed
+ * first (segment.py:329-336), or one active cavity (cavity.py:81-246). */
+enum lynx_step_kind { LYNX_STEP_RUN = 0, LYNX_STEP_CAVITY = 1 };
+typedef struct lynx_step {
+  int32_t kind;  /* lynx_step_kind */
+  int32_t first; /* first element index */
+  int32_t last;  /* one past the last element index (first+1 for a cavity) */
+  int32_t flags; /* cavity steps: copy of the element's LYNX_FLAG_CAV_* */
+} lynx_step;
+
+/* flags of lynx_track_particles */
+#define LYNX_TRACK_MOMENTS 1     /* also accumulate the output-beam moments (fused epilogue) */
+#define LYNX_TRACK_TWO_KERNEL 2  /* build+compose in its own launch instead of the fused prologue */
+
+/* Layout of one sample's moment record (float64 regardless of the particle dtype):
+ * [0..6] mean of the 7 coordinates, [7..27] upper triangle (row-major, i<=j<6) of the
+ * BIASED 6x6 covariance, [28..34] reserved (0), [35] number of particles. */
+#define LYNX_MOMENT_STRIDE 36
+
+typedef struct lynx_device_info_t {
+  char name[64];
+  char arch[32];
+  int32_t compute_units;
+  int32_t lds_bytes_per_cu;
+  int64_t hbm_bytes;
+} lynx_device_info_t;
+
+/* ---- diagnostics ---------------------------------------------------------------- */
+const char* lynx_version(void);
+int lynx_device_count(int* count);
+int lynx_ctx_create(int device, lynx_ctx** out);
+int lynx_ctx_destroy(lynx_ctx* ctx);
+const char* lynx_last_error(lynx_ctx* ctx);
+int lynx_device_info(lynx_ctx* ctx, lynx_device_info_t* out);
+int lynx_sync(lynx_ctx* ctx);
+/* HIP-event timer on the context's stream (the stream every kernel below runs on). */
+int lynx_timer_start(lynx_ctx* ctx);
+int lynx_timer_stop(lynx_ctx* ctx, float* elapsed_ms);
+
+/* ---- device buffers (reference: jax.Array storage behind `ParticleBeam.particles`,
+ *      particle_beam.py:24-45; the Python side owns the handles) ----------------------- */
+int lynx_buf_alloc(lynx_ctx* ctx, size_t bytes, void** d_out);
+int lynx_buf_free(lynx_ctx* ctx, void* d_ptr);
+int lynx_buf_h2d(lynx_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
+int lynx_buf_d2h(lynx_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
+int lynx_buf_d2d(lynx_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
+int lynx_buf_memset(lynx_ctx* ctx, void* d_dst, int value, size_t bytes);
+int lynx_pool_trim(lynx_ctx* ctx); /* return cached blocks to the driver */
+
+/* ---- lattice program (reference: the `Segment.elements` list and every element's
+ *      parameter arrays, segment.py:40-54; partition into steps, segment.py:344-351) --- */
+int lynx_lattice_create(lynx_ctx* ctx, int dtype, int64_t batch, int32_t n_elems,
+                        const lynx_elem* elems, int32_t n_steps, const lynx_step* steps,
+                        const void* pool, int64_t pool_count, lynx_lattice** out);
+/* overwrite pool[offset : offset+count] (element parameters changed, e.g. `quad.k1 = ...`) */
+int lynx_lattice_update_params(lynx_lattice* lat, int64_t offset, int64_t count, const void* host);
+/* overwrite element / step flags (whole-batch predicates that depend on the beam energy) */
+int lynx_lattice_set_flags(lynx_lattice* lat, const int32_t* elem_flags, const int32_t* step_flags);
+int lynx_lattice_destroy(lynx_lattice* lat);
+
+/* ---- the hot path ----------------------------------------------------------------- */
+
+/* Build every element's 7x7 map from the batched parameters and compose each step's map
+ * (reference: Element.transfer_map of every kind, track_methods.py:14-122,
+ * Segment.transfer_map segment.py:329-338, Cavity._cavity_rmatrix cavity.py:248-325).
+ *   d_energy_in  [B]                      beam energy entering the lattice
+ *   d_steps_out  [B][n_steps][64]         per step: 49 map entries + 8 cavity coefficients
+ *   d_energy_out [B] or NULL              beam energy leaving the lattice                  */
+int lynx_build_compose(lynx_ctx* ctx, lynx_lattice* lat, const void* d_energy_in,
+                       void* d_steps_out, void* d_energy_out);
+
+/* Segment.track on a ParticleBeam (reference: segment.py:340-356 -> element.py:83-92
+ * `particles @ tm^T`, cavity.py:141-161,219-226).
+ *   d_p_in / d_p_out [B][N][7]  (may alias)
+ *   d_moments_out    [B][36] float64 or NULL (needs LYNX_TRACK_MOMENTS)                    */
+int lynx_track_particles(lynx_ctx* ctx, lynx_lattice* lat, int64_t n_particles,
+                         const void* d_energy_in, const void* d_p_in, void* d_p_out,
+                         void* d_energy_out, double* d_moments_out, int flags);
+
+/* Segment.track on a ParameterBeam (reference: element.py:71-82 mu'=T mu, cov'=T cov T^T;
+ * cavity.py:134-140,202-218).  d_mu [B][7], d_cov [B][7][7] (in/out may alias).            */
+int lynx_track_moments(lynx_ctx* ctx, lynx_lattice* lat, const void* d_energy_in,
+                       const void* d_mu_in, const void* d_cov_in, void* d_mu_out,
+                       void* d_cov_out, void* d_energy_out);
+
+/* Moment read-out of an existing ParticleBeam (reference: particle_beam.py:736-836,
+ * one fused pass instead of 14 separate reductions).  d_moments_out [B][36] float64.       */
+int lynx_moments(lynx_ctx* ctx, int dtype, int64_t batch, int64_t n_particles, const void* d_p,
+                 double* d_moments_out);
+
+/* Seeded synthetic beam, generated in HBM: uncorrelated 6-D Gaussian per sample, 7th
+ * coordinate 1 (shape of ParticleBeam.from_parameters, particle_beam.py:144-170; not the
+ * same random stream).  mu[6], sigma[6] are host arrays.                                   */
+int lynx_fill_gaussian(lynx_ctx* ctx, int dtype, int64_t batch, int64_t n_particles,
+                       const double* mu, const double* sigma, uint64_t seed, void* d_p);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI (no reference counterpart: the
+ *      reference is single-process; batch samples are independent, so only the
+ *      per-sample moment records are exchanged) --------------------------------------- */
+#define LYNX_UNIQUE_ID_BYTES 128
+int lynx_comm_unique_id(char* id_out /* LYNX_UNIQUE_ID_BYTES */);
+int lynx_comm_init(lynx_ctx* ctx, int n_ranks, int rank, const char* id);
+int lynx_comm_destroy(lynx_ctx* ctx);
+/* all-gather `count` float64 per rank: d_recv [n_ranks][count] */
+int lynx_gather_moments(lynx_ctx* ctx, const double* d_send, double* d_recv, int64_t count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LYNX_HIP_H */

@@ -1,0 +1,14 @@
+"""Run-time switches of the package (plain module attributes)."""
+
+import os
+
+# Accumulate the outgoing beam's moments in the epilogue of the tracking kernel (no extra
+# HBM traffic).  If False, the first moment property read costs one more pass over the beam.
+fused_moments = os.environ.get("LYNX_FUSED_MOMENTS", "1") != "0"
+
+# Build+compose in its own launch instead of the fused prologue (A/B switch).
+two_kernel = os.environ.get("LYNX_TWO_KERNEL", "0") == "1"
+
+# Delta degrees of freedom of ParticleBeam.sigma_*.  The reference spells it
+# `xs.std(dim=-1)` (lynx/particles/particle_beam.py:742), i.e. the torch default: unbiased.
+std_ddof = int(os.environ.get("LYNX_STD_DDOF", "1"))

@@ -1,0 +1,556 @@
+// gfx950 kernels of the beam-tracking hot path.  Included only by lynx_hip.hip.
+//
+// Data layout in HBM
+//   particles   [B][N][7]  array-of-structs, exactly the reference's `(…, N, 7)` array
+//               (lynx/particles/particle_beam.py:24-45); scalar type T = float | double.
+//   lattice     elems[E], steps[S], elem_step[E] (int32) + parameter pool (T), see
+//               include/lynx_hip.h.
+//   step table  [B][S][64] T: per sample and step the composed 7x7 map (49) and the
+//               cavity coefficients (8).  In the fused kernel it only ever lives in LDS.
+//   partials    [B][chunks][36] double: per-workgroup moment sums (deterministic
+//               two-stage reduction; no float atomics).
+//
+// Wavefront = 64 everywhere; workgroups are 256 threads (4 waves) for the streaming
+// kernel and 64 threads (1 wave) for the per-sample kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "lynx_maps.hpp"
+
+namespace lynx {
+
+struct LatticeDev {
+  const lynx_elem* elems;
+  const lynx_step* steps;
+  const int32_t* elem_step;
+  const void* pool;
+  int64_t batch;
+  int32_t n_elems;
+  int32_t n_steps;
+};
+
+constexpr int kBuildChunk = 64;   // elements built in parallel per compose round
+constexpr int kTrackThreads = 256;
+constexpr int kPartialStride = 36;
+
+template <typename T> __device__ __forceinline__ T shfl_t(T v, int src) { return __shfl(v, src, 64); }
+
+// ---------------------------------------------------------------------------------------
+// Build + compose for ONE batch sample, executed by a whole workgroup (blockDim.x threads,
+// a multiple of 64).  Result: s_steps[S][64] in LDS, s_energy[S+1] in LDS.
+//
+//   phase 0  thread 0 walks the steps and accumulates the beam energy across active
+//            cavities (cavity.py:130: E_out = E + V cos(phi)).
+//   phase 1  up to kBuildChunk elements are built in parallel, one element per thread,
+//            straight into LDS (transcendentals run element-parallel).
+//   phase 2  wave 0 left-multiplies them in lattice order, tm = M_e . tm
+//            (segment.py:334-335): lane (i,j) keeps tm[i][j] in a register, fetches
+//            column j of tm with 7 wave shuffles and row i of M_e from LDS.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__device__ void build_compose_sample(const LatticeDev& lat, int64_t b, T energy_in, T* s_steps,
+                                     T* s_energy, T* s_scratch /* kBuildChunk*49 */) {
+  const int tid = threadIdx.x;
+  const int E = lat.n_elems, S = lat.n_steps;
+  const T* pool = static_cast<const T*>(lat.pool);
+
+  if (tid == 0) {
+    T e = energy_in;
+    for (int s = 0; s < S; ++s) {
+      s_energy[s] = e;
+      lynx_step st = lat.steps[s];
+      if (st.kind == LYNX_STEP_CAVITY && (st.flags & LYNX_FLAG_CAV_GAIN)) {
+        lynx_elem el = lat.elems[st.first];
+        const T* p = pool + el.param_offset + b * (int64_t)el.batch_stride;
+        T phi = p[2] * T(LYNX_PI / 180.0);
+        T de = p[1] * t_cos(phi);
+        e = e + de;
+      }
+    }
+    s_energy[S] = e;
+  }
+  __syncthreads();
+
+  const int lane = tid & 63;
+  const int cl = lane < 49 ? lane : 48;
+  const int ci = cl / 7, cj = cl % 7;
+  T tval = T(0);
+
+  for (int e0 = 0; e0 < E; e0 += kBuildChunk) {
+    const int ne = (E - e0) < kBuildChunk ? (E - e0) : kBuildChunk;
+    // phase 1
+    for (int t = tid; t < ne; t += blockDim.x) {
+      const int e = e0 + t;
+      lynx_elem el = lat.elems[e];
+      const int s = lat.elem_step[e];
+      const T* p = pool + el.param_offset + b * (int64_t)el.batch_stride;
+      const bool cav_step = lat.steps[s].kind == LYNX_STEP_CAVITY;
+      build_element<T>(el.kind, el.flags, p, s_energy[s], s_scratch + t * 49,
+                       cav_step ? s_steps + s * LYNX_STEP_STRIDE + LYNX_COEF_OFFSET : nullptr);
+    }
+    __syncthreads();
+    // phase 2 (wave 0)
+    if (tid < 64) {
+      int info = 0;  // lane t: (step << 2) | is_last << 1 | is_first, for element e0 + t
+      if (lane < ne) {
+        const int e = e0 + lane;
+        const int s = lat.elem_step[e];
+        lynx_step st = lat.steps[s];
+        info = (s << 2) | ((e == st.last - 1) ? 2 : 0) | ((e == st.first) ? 1 : 0);
+      }
+      for (int t = 0; t < ne; ++t) {
+        const int inf = __shfl(info, t, 64);
+        if (inf & 1) tval = (ci == cj) ? T(1) : T(0);
+        const T* M = s_scratch + t * 49 + ci * 7;
+        T acc = M[0] * shfl_t(tval, 0 * 7 + cj);
+#pragma unroll
+        for (int k = 1; k < 7; ++k) acc = t_fma(M[k], shfl_t(tval, k * 7 + cj), acc);
+        tval = acc;
+        if ((inf & 2) && lane < 49) s_steps[(inf >> 2) * LYNX_STEP_STRIDE + lane] = tval;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// Copy a precomputed step table of one sample from HBM into LDS (two-kernel mode).
+template <typename T>
+__device__ void load_steps_sample(const T* g_steps, int S, T* s_steps) {
+  for (int i = threadIdx.x; i < S * LYNX_STEP_STRIDE; i += blockDim.x) s_steps[i] = g_steps[i];
+  __syncthreads();
+}
+
+// Apply one step of the program to one particle held in registers.
+//   run:    z <- T z                                  (element.py:85, `particles @ tm^T`)
+//   cavity: z <- T z, then the non-linear delta / s update from the INCOMING s, delta
+//           (cavity.py:141-161, 219-226)
+template <typename T>
+__device__ __forceinline__ void apply_step(const T* M /*49 + coef*/, int step_kind, int step_flags,
+                                           T (&z)[7]) {
+  T o[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    T acc = z[0] * M[i * 7 + 0];
+#pragma unroll
+    for (int j = 1; j < 7; ++j) acc = t_fma(z[j], M[i * 7 + j], acc);
+    o[i] = acc;
+  }
+  if (step_kind == LYNX_STEP_CAVITY && (step_flags & LYNX_FLAG_CAV_GAIN)) {
+    cavity_kick<T>(M + LYNX_COEF_OFFSET, z[4], z[5], o[4], o[5]);
+  }
+#pragma unroll
+  for (int i = 0; i < 7; ++i) z[i] = o[i];
+}
+
+// Whole program on one particle, step data read from LDS.
+template <typename T>
+__device__ __forceinline__ void apply_program(const LatticeDev& lat, const T* s_steps, T (&z)[7]) {
+  for (int s = 0; s < lat.n_steps; ++s) {
+    lynx_step st = lat.steps[s];
+    apply_step<T>(s_steps + s * LYNX_STEP_STRIDE, st.kind, st.flags, z);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_build: standalone build+compose, one 64-thread workgroup per sample.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(64) void k_build(LatticeDev lat, const T* __restrict__ energy_in,
+                                               T* __restrict__ steps_out,
+                                               T* __restrict__ energy_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* s_scratch = reinterpret_cast<T*>(smem_raw);
+  T* s_steps = s_scratch + kBuildChunk * 49;
+  T* s_energy = s_steps + (size_t)lat.n_steps * LYNX_STEP_STRIDE;
+  const int64_t b = blockIdx.x;
+  // zero the coefficient slots so that run steps have defined padding
+  for (int i = threadIdx.x; i < lat.n_steps * LYNX_STEP_STRIDE; i += blockDim.x) s_steps[i] = T(0);
+  __syncthreads();
+  build_compose_sample<T>(lat, b, energy_in[b], s_steps, s_energy, s_scratch);
+  T* dst = steps_out + b * (int64_t)lat.n_steps * LYNX_STEP_STRIDE;
+  for (int i = threadIdx.x; i < lat.n_steps * LYNX_STEP_STRIDE; i += blockDim.x) dst[i] = s_steps[i];
+  if (energy_out && threadIdx.x == 0) energy_out[b] = s_energy[lat.n_steps];
+}
+
+// ---------------------------------------------------------------------------------------
+// k_track: the streaming kernel.  grid.x = B * chunks; each 256-thread workgroup owns
+// `tiles_per_wg` consecutive tiles of TILE = 256*PPT particles of ONE sample.
+//
+// Per tile: the AoS tile travels HBM -> registers -> LDS as a flat array with 16-byte
+// accesses (perfectly coalesced; stride 7 never shows up on the HBM side).  Each lane then
+// picks its particles out of LDS with stride 7 words (7 is coprime with the 32/64 LDS
+// banks -> conflict-free), runs the program in registers, writes the result back into the
+// same LDS slots, and the tile leaves LDS again as a flat 16-byte stream.  The loads of
+// tile t+1 are issued before tile t is processed (register prefetch), so every workgroup
+// keeps a tile of HBM reads in flight while it computes and stores.
+//
+// Single-run programs (every all-skippable lattice: one composed 7x7 per sample) keep the
+// map in SGPRs for fp32 (it is wave-uniform), so the inner loop is 49 v_fma with a scalar
+// operand each and the map costs no VGPRs.
+// ---------------------------------------------------------------------------------------
+template <typename T, bool VEC> struct VecOf { using type = T; static constexpr int width = 1; };
+// clang native vectors (HIP's float4/double2 structs defeat SROA and land in scratch)
+typedef float lynx_f32x4 __attribute__((ext_vector_type(4)));
+typedef double lynx_f64x2 __attribute__((ext_vector_type(2)));
+template <> struct VecOf<float, true> { using type = lynx_f32x4; static constexpr int width = 4; };
+template <> struct VecOf<double, true> { using type = lynx_f64x2; static constexpr int width = 2; };
+
+struct TrackArgs {
+  int64_t n_particles;
+  int32_t chunks;        // workgroups per sample
+  int32_t tiles_per_wg;
+  int32_t fused_build;   // 1: build+compose in the prologue, 0: read steps_in
+  int32_t store;         // 1: write p_out
+  int32_t lds_tile_scalars;  // size of the tile/scratch region in scalars
+};
+
+__device__ __forceinline__ float uniform_value(float v) {
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+__device__ __forceinline__ double uniform_value(double v) { return v; }  // stays in VGPRs / LDS
+
+template <typename T> struct MomentAcc {
+  double d[6], dd[21], one, cnt;
+  __device__ __forceinline__ void clear() {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) d[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 21; ++i) dd[i] = 0.0;
+    one = 0.0;
+    cnt = 0.0;
+  }
+  __device__ __forceinline__ void add(const T (&z)[7], const T (&shift)[7]) {
+    double e[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      e[i] = (double)z[i] - (double)shift[i];
+      d[i] += e[i];
+    }
+    one += (double)z[6];
+    cnt += 1.0;
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = i; j < 6; ++j) {
+        dd[k] = fma(e[i], e[j], dd[k]);
+        ++k;
+      }
+  }
+};
+
+template <typename T, int PPT, bool VEC, bool MOMENTS>
+__global__ __launch_bounds__(kTrackThreads) void k_track(
+    LatticeDev lat, TrackArgs a, const T* __restrict__ energy_in, const T* p_in, T* p_out,
+    T* __restrict__ energy_out, const T* __restrict__ steps_in, double* __restrict__ partials) {
+  constexpr int TILE = kTrackThreads * PPT;
+  using V = typename VecOf<T, VEC>::type;
+  constexpr int VW = VecOf<T, VEC>::width;
+  constexpr int NV = (TILE * 7 / VW + kTrackThreads - 1) / kTrackThreads;  // vectors per thread and tile
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* s_tile = reinterpret_cast<T*>(smem_raw);                      // tile, aliases build scratch
+  T* s_steps = s_tile + a.lds_tile_scalars;                        // [S][64]
+  T* s_energy = s_steps + (size_t)lat.n_steps * LYNX_STEP_STRIDE;  // [S+1]
+
+  const int tid = threadIdx.x;
+  const int64_t b = blockIdx.x / a.chunks;
+  const int chunk = blockIdx.x % a.chunks;
+  const int64_t N = a.n_particles;
+  const int S = lat.n_steps;
+  const int64_t first_tile = (int64_t)chunk * a.tiles_per_wg;
+
+  // Issue the first tile's loads before the build prologue: they fly while the map is built.
+  V pre[NV];
+  {
+    const int64_t tile_start = first_tile * TILE;
+    const int cnt = (int)((N - tile_start) < TILE ? (N - tile_start) : TILE);
+    const V* src = reinterpret_cast<const V*>(p_in + (b * N + tile_start) * 7);
+    const int nvec = cnt * 7 / VW;
+    // clamped index instead of a guarded load: keeps `pre` in registers (a guarded
+    // element-wise assignment sends the array to scratch and serialises the prefetch)
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {
+      const int v = r * kTrackThreads + tid;
+      pre[r] = src[v < nvec ? v : nvec - 1];
+    }
+  }
+
+  if (a.fused_build) {
+    build_compose_sample<T>(lat, b, energy_in[b], s_steps, s_energy, s_tile);
+    if (energy_out && chunk == 0 && tid == 0) energy_out[b] = s_energy[S];
+  } else if (S > 0) {
+    load_steps_sample<T>(steps_in + b * (int64_t)S * LYNX_STEP_STRIDE, S, s_steps);
+  }
+
+  const bool one_run = (S == 1) && (lat.steps[0].kind == LYNX_STEP_RUN);
+  T m0[49];  // the single composed map, wave-uniform
+  if (one_run) {
+#pragma unroll
+    for (int i = 0; i < 49; ++i) m0[i] = uniform_value(s_steps[i]);
+  }
+
+  // Moment accumulation (float64): d = z - c with c = the transformed first particle of
+  // the sample (same value in every workgroup of the sample) to avoid cancellation.
+  MomentAcc<T> acc;
+  T shift[7];
+  if (MOMENTS) {
+    acc.clear();
+    const T* p0 = p_in + b * N * 7;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) shift[i] = p0[i];
+    apply_program<T>(lat, s_steps, shift);
+  }
+
+  for (int t = 0; t < a.tiles_per_wg; ++t) {
+    const int64_t tile_start = (first_tile + t) * TILE;
+    if (tile_start >= N) break;
+    const int cnt = (int)((N - tile_start) < TILE ? (N - tile_start) : TILE);
+    const int nvec = cnt * 7 / VW;
+    const int64_t goff = (b * N + tile_start) * 7;
+
+    // registers -> LDS (flat)
+    {
+      V* dst = reinterpret_cast<V*>(s_tile);
+#pragma unroll
+      for (int r = 0; r < NV; ++r) {
+        const int v = r * kTrackThreads + tid;
+        if (v < nvec) dst[v] = pre[r];
+      }
+    }
+    __syncthreads();
+
+    // prefetch the next tile of this workgroup
+    {
+      const int64_t next_start = tile_start + TILE;
+      if (t + 1 < a.tiles_per_wg && next_start < N) {
+        const int ncnt = (int)((N - next_start) < TILE ? (N - next_start) : TILE);
+        const V* src = reinterpret_cast<const V*>(p_in + (b * N + next_start) * 7);
+        const int nnvec = ncnt * 7 / VW;
+#pragma unroll
+        for (int r = 0; r < NV; ++r) {
+          const int v = r * kTrackThreads + tid;
+          pre[r] = src[v < nnvec ? v : nnvec - 1];
+        }
+      }
+    }
+
+#pragma unroll 1
+    for (int q = 0; q < PPT; ++q) {
+      const int pi = q * kTrackThreads + tid;
+      if (pi < cnt) {
+        T z[7];
+#pragma unroll
+        for (int c = 0; c < 7; ++c) z[c] = s_tile[pi * 7 + c];
+        if (one_run) {
+          apply_step<T>(m0, LYNX_STEP_RUN, 0, z);
+        } else {
+          apply_program<T>(lat, s_steps, z);
+        }
+        if (a.store) {
+#pragma unroll
+          for (int c = 0; c < 7; ++c) s_tile[pi * 7 + c] = z[c];
+        }
+        if (MOMENTS) acc.add(z, shift);
+      }
+    }
+
+    if (a.store) {
+      __syncthreads();
+      V* dstg = reinterpret_cast<V*>(p_out + goff);
+      const V* srcl = reinterpret_cast<const V*>(s_tile);
+#pragma unroll
+      for (int r = 0; r < NV; ++r) {
+        const int v = r * kTrackThreads + tid;
+        if (v < nvec) dstg[v] = srcl[v];
+      }
+    }
+    __syncthreads();  // the tile buffer is rewritten by the next iteration
+  }
+
+  if (MOMENTS) {
+    // wave reduction (xor butterfly over 64 lanes), then across the 4 waves through LDS
+    double* s_red = reinterpret_cast<double*>(s_tile);  // 4 waves x 29
+    const int wave = tid >> 6, lane = tid & 63;
+#define LYNX_WAVE_SUM(dst_idx, value)                                        \
+    {                                                                          \
+      double v_ = (value);                                                     \
+      for (int off = 32; off >= 1; off >>= 1) v_ += __shfl_xor(v_, off, 64);   \
+      if (lane == 0) s_red[wave * 29 + (dst_idx)] = v_;                        \
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) LYNX_WAVE_SUM(i, acc.d[i]);
+    LYNX_WAVE_SUM(6, acc.one);
+#pragma unroll
+    for (int i = 0; i < 21; ++i) LYNX_WAVE_SUM(7 + i, acc.dd[i]);
+    LYNX_WAVE_SUM(28, acc.cnt);
+#undef LYNX_WAVE_SUM
+    __syncthreads();
+    double* dst = partials + ((int64_t)b * a.chunks + chunk) * kPartialStride;
+    if (tid < 29) {
+      double v = s_red[tid] + s_red[29 + tid] + s_red[58 + tid] + s_red[87 + tid];
+      dst[tid == 28 ? 35 : tid] = v;
+    } else if (tid >= 32 && tid < 39) {
+      dst[28 + (tid - 32)] = (double)shift[tid - 32];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_finalize_moments: partials [B][chunks][36] -> moment records [B][36].
+// One 64-thread workgroup per sample; chunk sums run in a fixed order (deterministic).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_finalize_moments(const double* __restrict__ partials,
+                                                          int chunks, double* __restrict__ out) {
+  __shared__ double s[kPartialStride];
+  const int64_t b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const double* src = partials + b * (int64_t)chunks * kPartialStride;
+  if (tid < kPartialStride) {
+    double v;
+    if (tid >= 28 && tid < 35) {
+      v = src[tid];  // shift: identical in every chunk
+    } else {
+      v = 0.0;
+      for (int c = 0; c < chunks; ++c) v += src[(int64_t)c * kPartialStride + tid];
+    }
+    s[tid] = v;
+  }
+  __syncthreads();
+  double* dst = out + b * LYNX_MOMENT_STRIDE;
+  const double n = s[35];
+  if (tid < 6) {
+    dst[tid] = s[28 + tid] + s[tid] / n;
+  } else if (tid == 6) {
+    dst[6] = s[6] / n;
+  } else if (tid < 28) {
+    // upper-triangle index -> (i, j)
+    int k = tid - 7, i = 0, row = 6;
+    while (k >= row) { k -= row; --row; ++i; }
+    const int j = i + k;
+    dst[tid] = (s[tid] - s[i] * s[j] / n) / n;
+  } else if (tid < 35) {
+    dst[tid] = 0.0;
+  } else if (tid == 35) {
+    dst[35] = n;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_track_moments: ParameterBeam path, one wave per sample (element.py:71-82,
+// cavity.py:134-140, 202-218).
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(64) void k_track_moments(LatticeDev lat, const T* __restrict__ energy_in,
+                                                       const T* mu_in, const T* cov_in, T* mu_out,
+                                                       T* cov_out, T* __restrict__ energy_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* s_scratch = reinterpret_cast<T*>(smem_raw);
+  T* s_steps = s_scratch + kBuildChunk * 49;
+  T* s_energy = s_steps + (size_t)lat.n_steps * LYNX_STEP_STRIDE;
+  T* s_mu = s_energy + lat.n_steps + 1;  // 8
+  T* s_cov = s_mu + 8;                   // 49
+  T* s_x = s_cov + 49;                   // 49
+  T* s_in = s_x + 49;                    // mu_in(7) + cov_in 44,45,55 for the cavity branch
+
+  const int64_t b = blockIdx.x;
+  const int lane = threadIdx.x;
+  build_compose_sample<T>(lat, b, energy_in[b], s_steps, s_energy, s_scratch);
+
+  if (lane < 7) s_mu[lane] = mu_in[b * 7 + lane];
+  if (lane < 49) s_cov[lane] = cov_in[b * 49 + lane];
+  __syncthreads();
+  const int cl = lane < 49 ? lane : 48;
+  const int i = cl / 7, j = cl % 7;
+
+  for (int s = 0; s < lat.n_steps; ++s) {
+    lynx_step st = lat.steps[s];
+    const T* M = s_steps + s * LYNX_STEP_STRIDE;
+    // keep what the cavity branch needs from the incoming beam
+    if (lane < 7) s_in[lane] = s_mu[lane];
+    if (lane == 7) s_in[7] = s_cov[4 * 7 + 4];
+    if (lane == 8) s_in[8] = s_cov[4 * 7 + 5];
+    if (lane == 9) s_in[9] = s_cov[5 * 7 + 5];
+    // mu' = T mu
+    T mu_new = T(0);
+    if (lane < 7) {
+      mu_new = M[lane * 7 + 0] * s_mu[0];
+#pragma unroll
+      for (int k = 1; k < 7; ++k) mu_new = t_fma(M[lane * 7 + k], s_mu[k], mu_new);
+    }
+    // X = cov . T^T
+    T x = s_cov[i * 7 + 0] * M[j * 7 + 0];
+#pragma unroll
+    for (int k = 1; k < 7; ++k) x = t_fma(s_cov[i * 7 + k], M[j * 7 + k], x);
+    __syncthreads();
+    if (lane < 49) s_x[lane] = x;
+    if (lane < 7) s_mu[lane] = mu_new;
+    __syncthreads();
+    // cov' = T . X
+    T c = M[i * 7 + 0] * s_x[0 * 7 + j];
+#pragma unroll
+    for (int k = 1; k < 7; ++k) c = t_fma(M[i * 7 + k], s_x[k * 7 + j], c);
+    __syncthreads();
+    if (lane < 49) s_cov[lane] = c;
+    __syncthreads();
+    if (st.kind == LYNX_STEP_CAVITY && (st.flags & LYNX_FLAG_CAV_GAIN) && lane == 0) {
+      const T* coef = M + LYNX_COEF_OFFSET;
+      T s_o = s_mu[4], d_o;
+      cavity_kick<T>(coef, s_in[4], s_in[5], s_o, d_o);  // cavity.py:134-140, 202-206
+      s_mu[4] = s_o;
+      s_mu[5] = d_o;
+      const T c44 = s_in[7], c45 = s_in[8], c55 = s_in[9];
+      s_cov[5 * 7 + 5] = c55;  // cavity.py:140
+      const T v = coef[LYNX_C_T566] * (c55 * c55) + coef[LYNX_C_T556] * c45 * c55 +
+                  coef[LYNX_C_T555] * (c44 * c44);  // cavity.py:207-218
+      s_cov[4 * 7 + 4] = v;
+      s_cov[4 * 7 + 5] = v;
+      s_cov[5 * 7 + 4] = v;
+    }
+    __syncthreads();
+  }
+  if (lane < 7) mu_out[b * 7 + lane] = s_mu[lane];
+  if (lane < 49) cov_out[b * 49 + lane] = s_cov[lane];
+  if (energy_out && lane == 0) energy_out[b] = s_energy[lat.n_steps];
+}
+
+// ---------------------------------------------------------------------------------------
+// k_fill_gaussian: counter-based synthetic beam (splitmix64 -> Box-Muller), one scalar of
+// the flat [B][N][7] array per thread, fully coalesced stores.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+struct GaussArgs {
+  double mu[6];
+  double sigma[6];
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_fill_gaussian(T* __restrict__ p, int64_t total, uint64_t seed,
+                                                        GaussArgs g) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+    const int c = (int)(idx % 7);
+    T v;
+    if (c == 6) {
+      v = T(1);
+    } else {
+      const uint64_t h1 = splitmix64(seed ^ splitmix64((uint64_t)idx * 2 + 0));
+      const uint64_t h2 = splitmix64(seed ^ splitmix64((uint64_t)idx * 2 + 1));
+      const double u1 = ((double)(h1 >> 11) + 1.0) * (1.0 / 9007199254740993.0);  // (0,1)
+      const double u2 = (double)(h2 >> 11) * (1.0 / 9007199254740992.0);          // [0,1)
+      const double r = sqrt(-2.0 * log(u1));
+      const double zn = r * cos(6.283185307179586 * u2);
+      v = (T)(g.mu[c] + g.sigma[c] * zn);
+    }
+    p[idx] = v;
+  }
+}
+
+}  // namespace lynx

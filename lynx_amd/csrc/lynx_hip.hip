@@ -1,0 +1,629 @@
+// liblynxhip: C-ABI entry points (include/lynx_hip.h) over the gfx950 kernels in
+// lynx_device.hpp.  One lynx_ctx per GPU and per process: one HIP stream, a caching
+// device allocator (so that `track()` never pays hipMalloc on the hot path), the
+// moment-reduction scratch and, optionally, an RCCL communicator.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "lynx_device.hpp"
+
+using namespace lynx;
+
+struct lynx_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  std::string err;
+  hipDeviceProp_t prop;
+  // caching allocator: size class -> free blocks; live pointer -> size class
+  std::multimap<size_t, void*> free_blocks;
+  std::unordered_map<void*, size_t> live;
+  // internal scratch (grown on demand, stream-ordered reuse)
+  void* scratch_partials = nullptr;
+  size_t scratch_partials_bytes = 0;
+  void* scratch_steps = nullptr;
+  size_t scratch_steps_bytes = 0;
+  ncclComm_t comm = nullptr;
+  int comm_ranks = 0;
+};
+
+struct lynx_lattice {
+  lynx_ctx* ctx = nullptr;
+  int dtype = LYNX_F32;
+  int64_t batch = 0;
+  int32_t n_elems = 0, n_steps = 0;
+  int64_t pool_count = 0;
+  std::vector<lynx_elem> h_elems;
+  std::vector<lynx_step> h_steps;
+  lynx_elem* d_elems = nullptr;
+  lynx_step* d_steps = nullptr;
+  int32_t* d_elem_step = nullptr;
+  void* d_pool = nullptr;
+};
+
+static thread_local std::string g_err;
+
+static int fail(lynx_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->err = msg;
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                  \
+  do {                                                                                      \
+    hipError_t _e = (expr);                                                                 \
+    if (_e != hipSuccess)                                                                   \
+      return fail((ctx), LYNX_ERR_HIP,                                                      \
+                  std::string(#expr) + ": " + hipGetErrorString(_e) + " (" __FILE__ ":" +   \
+                      std::to_string(__LINE__) + ")");                                      \
+  } while (0)
+
+#define NCCL_TRY(ctx, expr)                                                                 \
+  do {                                                                                      \
+    ncclResult_t _e = (expr);                                                               \
+    if (_e != ncclSuccess)                                                                  \
+      return fail((ctx), LYNX_ERR_RCCL, std::string(#expr) + ": " + ncclGetErrorString(_e)); \
+  } while (0)
+
+static size_t dtype_size(int dtype) { return dtype == LYNX_F64 ? 8 : 4; }
+
+static size_t size_class(size_t bytes) {
+  if (bytes == 0) bytes = 1;
+  const size_t g = bytes >= (1u << 20) ? (1u << 20) : 256;
+  return (bytes + g - 1) / g * g;
+}
+
+static int ctx_alloc(lynx_ctx* ctx, size_t bytes, void** out) {
+  const size_t sc = size_class(bytes);
+  auto it = ctx->free_blocks.find(sc);
+  if (it != ctx->free_blocks.end()) {
+    *out = it->second;
+    ctx->free_blocks.erase(it);
+    ctx->live[*out] = sc;
+    return LYNX_OK;
+  }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, sc);
+  if (e != hipSuccess) {
+    // give cached blocks back and retry once
+    for (auto& kv : ctx->free_blocks) (void)hipFree(kv.second);
+    ctx->free_blocks.clear();
+    e = hipMalloc(&p, sc);
+    if (e != hipSuccess)
+      return fail(ctx, LYNX_ERR_NOMEM, "hipMalloc(" + std::to_string(sc) + "): " + hipGetErrorString(e));
+  }
+  ctx->live[p] = sc;
+  *out = p;
+  return LYNX_OK;
+}
+
+static int ctx_free(lynx_ctx* ctx, void* p) {
+  if (!p) return LYNX_OK;
+  auto it = ctx->live.find(p);
+  if (it == ctx->live.end()) return fail(ctx, LYNX_ERR_INVALID, "lynx_buf_free: unknown pointer");
+  ctx->free_blocks.emplace(it->second, p);
+  ctx->live.erase(it);
+  return LYNX_OK;
+}
+
+static int ensure_scratch(lynx_ctx* ctx, void** buf, size_t* have, size_t need) {
+  if (*have >= need) return LYNX_OK;
+  if (*buf) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipFree(*buf));
+    *buf = nullptr;
+    *have = 0;
+  }
+  const size_t sz = size_class(need);
+  HIP_TRY(ctx, hipMalloc(buf, sz));
+  *have = sz;
+  return LYNX_OK;
+}
+
+// The API functions below get C linkage from their declarations in include/lynx_hip.h.
+
+const char* lynx_version(void) { return "lynxhip 0.1.0 (gfx950)"; }
+
+int lynx_device_count(int* count) {
+  hipError_t e = hipGetDeviceCount(count);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(nullptr, LYNX_ERR_HIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+  }
+  return LYNX_OK;
+}
+
+int lynx_ctx_create(int device, lynx_ctx** out) {
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(nullptr, LYNX_ERR_HIP,
+                std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "count = 0"));
+  if (device < 0 || device >= n) return fail(nullptr, LYNX_ERR_INVALID, "device ordinal out of range");
+  lynx_ctx* ctx = new lynx_ctx();
+  ctx->device = device;
+  HIP_TRY(nullptr, hipSetDevice(device));
+  HIP_TRY(nullptr, hipGetDeviceProperties(&ctx->prop, device));
+  HIP_TRY(nullptr, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  HIP_TRY(nullptr, hipEventCreate(&ctx->ev_start));
+  HIP_TRY(nullptr, hipEventCreate(&ctx->ev_stop));
+  *out = ctx;
+  return LYNX_OK;
+}
+
+int lynx_ctx_destroy(lynx_ctx* ctx) {
+  if (!ctx) return LYNX_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
+  for (auto& kv : ctx->free_blocks) (void)hipFree(kv.second);
+  for (auto& kv : ctx->live) (void)hipFree(kv.first);
+  if (ctx->scratch_partials) (void)hipFree(ctx->scratch_partials);
+  if (ctx->scratch_steps) (void)hipFree(ctx->scratch_steps);
+  (void)hipEventDestroy(ctx->ev_start);
+  (void)hipEventDestroy(ctx->ev_stop);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return LYNX_OK;
+}
+
+const char* lynx_last_error(lynx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+int lynx_device_info(lynx_ctx* ctx, lynx_device_info_t* out) {
+  memset(out, 0, sizeof(*out));
+  snprintf(out->name, sizeof(out->name), "%s", ctx->prop.name);
+  snprintf(out->arch, sizeof(out->arch), "%s", ctx->prop.gcnArchName);
+  out->compute_units = ctx->prop.multiProcessorCount;
+  out->lds_bytes_per_cu = (int32_t)ctx->prop.maxSharedMemoryPerMultiProcessor;
+  out->hbm_bytes = (int64_t)ctx->prop.totalGlobalMem;
+  return LYNX_OK;
+}
+
+int lynx_sync(lynx_ctx* ctx) {
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return LYNX_OK;
+}
+
+int lynx_timer_start(lynx_ctx* ctx) {
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+  return LYNX_OK;
+}
+
+int lynx_timer_stop(lynx_ctx* ctx, float* elapsed_ms) {
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+  HIP_TRY(ctx, hipEventSynchronize(ctx->ev_stop));
+  HIP_TRY(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev_start, ctx->ev_stop));
+  return LYNX_OK;
+}
+
+int lynx_buf_alloc(lynx_ctx* ctx, size_t bytes, void** d_out) {
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  return ctx_alloc(ctx, bytes, d_out);
+}
+
+int lynx_buf_free(lynx_ctx* ctx, void* d_ptr) { return ctx_free(ctx, d_ptr); }
+
+int lynx_buf_h2d(lynx_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+  if (bytes == 0) return LYNX_OK;
+  HIP_TRY(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // h_src is pageable and may be freed
+  return LYNX_OK;
+}
+
+int lynx_buf_d2h(lynx_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
+  if (bytes == 0) return LYNX_OK;
+  HIP_TRY(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return LYNX_OK;
+}
+
+int lynx_buf_d2d(lynx_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) {
+  if (bytes == 0) return LYNX_OK;
+  HIP_TRY(ctx, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return LYNX_OK;
+}
+
+int lynx_buf_memset(lynx_ctx* ctx, void* d_dst, int value, size_t bytes) {
+  if (bytes == 0) return LYNX_OK;
+  HIP_TRY(ctx, hipMemsetAsync(d_dst, value, bytes, ctx->stream));
+  return LYNX_OK;
+}
+
+int lynx_pool_trim(lynx_ctx* ctx) {
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (auto& kv : ctx->free_blocks) (void)hipFree(kv.second);
+  ctx->free_blocks.clear();
+  return LYNX_OK;
+}
+
+// ---- lattice ---------------------------------------------------------------------------
+
+static int params_of_kind(int kind) {
+  switch (kind) {
+    case LYNX_KIND_IDENTITY: return 0;
+    case LYNX_KIND_DRIFT: return 1;
+    case LYNX_KIND_QUADRUPOLE: return 5;
+    case LYNX_KIND_DIPOLE: return 8;
+    case LYNX_KIND_HCOR:
+    case LYNX_KIND_VCOR: return 2;
+    case LYNX_KIND_CAVITY: return 4;
+    case LYNX_KIND_CUSTOM: return 49;
+    default: return -1;
+  }
+}
+
+int lynx_lattice_create(lynx_ctx* ctx, int dtype, int64_t batch, int32_t n_elems,
+                        const lynx_elem* elems, int32_t n_steps, const lynx_step* steps,
+                        const void* pool, int64_t pool_count, lynx_lattice** out) {
+  *out = nullptr;
+  if (dtype != LYNX_F32 && dtype != LYNX_F64) return fail(ctx, LYNX_ERR_INVALID, "bad dtype");
+  if (batch <= 0 || n_elems < 0 || n_steps < 0 || pool_count < 0)
+    return fail(ctx, LYNX_ERR_INVALID, "bad lattice sizes");
+  // Validate every index the kernels will dereference: a bad table must never reach the GPU.
+  std::vector<int32_t> elem_step(n_elems, -1);
+  for (int32_t e = 0; e < n_elems; ++e) {
+    const int np = params_of_kind(elems[e].kind);
+    if (np < 0) return fail(ctx, LYNX_ERR_INVALID, "element " + std::to_string(e) + ": unknown kind");
+    const int64_t bs = elems[e].batch_stride;
+    if (bs != 0 && bs < np) return fail(ctx, LYNX_ERR_INVALID, "element batch_stride smaller than its row");
+    const int64_t lo = elems[e].param_offset;
+    const int64_t hi = lo + (batch - 1) * bs + np;
+    if (lo < 0 || hi > pool_count)
+      return fail(ctx, LYNX_ERR_INVALID, "element " + std::to_string(e) + ": parameters outside the pool");
+  }
+  int32_t next = 0;
+  for (int32_t s = 0; s < n_steps; ++s) {
+    const lynx_step& st = steps[s];
+    if (st.first != next || st.last <= st.first || st.last > n_elems)
+      return fail(ctx, LYNX_ERR_INVALID, "steps must tile the element list in order");
+    if (st.kind == LYNX_STEP_CAVITY) {
+      if (st.last != st.first + 1 || elems[st.first].kind != LYNX_KIND_CAVITY)
+        return fail(ctx, LYNX_ERR_INVALID, "cavity step must hold exactly one cavity element");
+    } else if (st.kind != LYNX_STEP_RUN) {
+      return fail(ctx, LYNX_ERR_INVALID, "unknown step kind");
+    }
+    for (int32_t e = st.first; e < st.last; ++e) elem_step[e] = s;
+    next = st.last;
+  }
+  if (next != n_elems) return fail(ctx, LYNX_ERR_INVALID, "steps do not cover every element");
+
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  lynx_lattice* lat = new lynx_lattice();
+  lat->ctx = ctx;
+  lat->dtype = dtype;
+  lat->batch = batch;
+  lat->n_elems = n_elems;
+  lat->n_steps = n_steps;
+  lat->pool_count = pool_count;
+  lat->h_elems.assign(elems, elems + n_elems);
+  lat->h_steps.assign(steps, steps + n_steps);
+  const size_t es = dtype_size(dtype);
+  int rc;
+  if ((rc = ctx_alloc(ctx, std::max<size_t>(1, n_elems) * sizeof(lynx_elem), (void**)&lat->d_elems)) ||
+      (rc = ctx_alloc(ctx, std::max<size_t>(1, n_steps) * sizeof(lynx_step), (void**)&lat->d_steps)) ||
+      (rc = ctx_alloc(ctx, std::max<size_t>(1, n_elems) * sizeof(int32_t), (void**)&lat->d_elem_step)) ||
+      (rc = ctx_alloc(ctx, std::max<size_t>(1, pool_count) * es, &lat->d_pool))) {
+    delete lat;
+    return rc;
+  }
+  HIP_TRY(ctx, hipMemcpyAsync(lat->d_elems, elems, n_elems * sizeof(lynx_elem), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(lat->d_steps, steps, n_steps * sizeof(lynx_step), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(lat->d_elem_step, elem_step.data(), n_elems * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(lat->d_pool, pool, pool_count * es, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  *out = lat;
+  return LYNX_OK;
+}
+
+int lynx_lattice_update_params(lynx_lattice* lat, int64_t offset, int64_t count, const void* host) {
+  lynx_ctx* ctx = lat->ctx;
+  if (offset < 0 || count < 0 || offset + count > lat->pool_count)
+    return fail(ctx, LYNX_ERR_INVALID, "lynx_lattice_update_params: range outside the pool");
+  const size_t es = dtype_size(lat->dtype);
+  HIP_TRY(ctx, hipMemcpyAsync((char*)lat->d_pool + offset * es, host, count * es, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return LYNX_OK;
+}
+
+int lynx_lattice_set_flags(lynx_lattice* lat, const int32_t* elem_flags, const int32_t* step_flags) {
+  lynx_ctx* ctx = lat->ctx;
+  for (int32_t e = 0; e < lat->n_elems; ++e) lat->h_elems[e].flags = elem_flags[e];
+  for (int32_t s = 0; s < lat->n_steps; ++s) lat->h_steps[s].flags = step_flags[s];
+  HIP_TRY(ctx, hipMemcpyAsync(lat->d_elems, lat->h_elems.data(), lat->n_elems * sizeof(lynx_elem), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(lat->d_steps, lat->h_steps.data(), lat->n_steps * sizeof(lynx_step), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return LYNX_OK;
+}
+
+int lynx_lattice_destroy(lynx_lattice* lat) {
+  if (!lat) return LYNX_OK;
+  lynx_ctx* ctx = lat->ctx;
+  ctx_free(ctx, lat->d_elems);
+  ctx_free(ctx, lat->d_steps);
+  ctx_free(ctx, lat->d_elem_step);
+  ctx_free(ctx, lat->d_pool);
+  delete lat;
+  return LYNX_OK;
+}
+
+static LatticeDev dev_view(const lynx_lattice* lat) {
+  LatticeDev d;
+  d.elems = lat->d_elems;
+  d.steps = lat->d_steps;
+  d.elem_step = lat->d_elem_step;
+  d.pool = lat->d_pool;
+  d.batch = lat->batch;
+  d.n_elems = lat->n_elems;
+  d.n_steps = lat->n_steps;
+  return d;
+}
+
+template <typename K>
+static int allow_lds(lynx_ctx* ctx, K kernel, size_t bytes) {
+  if (bytes > 160 * 1024)
+    return fail(ctx, LYNX_ERR_INVALID,
+                "program needs " + std::to_string(bytes) + " B of LDS (> 160 KiB): split the lattice");
+  if (bytes > 48 * 1024)
+    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return LYNX_OK;
+}
+
+// ---- build + compose -------------------------------------------------------------------
+
+template <typename T>
+static int launch_build(lynx_ctx* ctx, lynx_lattice* lat, const void* d_energy_in, void* d_steps_out,
+                        void* d_energy_out) {
+  const size_t lds = ((size_t)kBuildChunk * 49 + (size_t)lat->n_steps * LYNX_STEP_STRIDE + lat->n_steps + 1) * sizeof(T);
+  int rc = allow_lds(ctx, k_build<T>, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_build<T>, dim3((unsigned)lat->batch), dim3(64), lds, ctx->stream, dev_view(lat),
+                     (const T*)d_energy_in, (T*)d_steps_out, (T*)d_energy_out);
+  HIP_TRY(ctx, hipGetLastError());
+  return LYNX_OK;
+}
+
+int lynx_build_compose(lynx_ctx* ctx, lynx_lattice* lat, const void* d_energy_in, void* d_steps_out,
+                       void* d_energy_out) {
+  if (!ctx || !lat || !d_energy_in || !d_steps_out) return fail(ctx, LYNX_ERR_INVALID, "null argument");
+  if (lat->batch > 0x7fffffffLL) return fail(ctx, LYNX_ERR_INVALID, "batch too large");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  return lat->dtype == LYNX_F64 ? launch_build<double>(ctx, lat, d_energy_in, d_steps_out, d_energy_out)
+                                : launch_build<float>(ctx, lat, d_energy_in, d_steps_out, d_energy_out);
+}
+
+// ---- particle tracking -----------------------------------------------------------------
+
+struct TrackPlan {
+  int ppt;
+  bool vec;
+  TrackArgs a;
+  size_t lds;
+  unsigned grid;
+};
+
+template <typename T>
+static TrackPlan plan_track(lynx_ctx* ctx, int64_t B, int64_t N, int32_t S, bool fused, const void* p_in,
+                            const void* p_out) {
+  TrackPlan p;
+  const int ppt_big = sizeof(T) == 4 ? 4 : 2;
+  const int64_t cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+  const int64_t tiles_big = B * ((N + 256 * ppt_big - 1) / (256 * ppt_big));
+  p.ppt = tiles_big >= 4 * cus ? ppt_big : 1;  // small jobs: smaller tiles, more workgroups
+  const int64_t tile = 256 * p.ppt;
+  const int64_t ntiles = (N + tile - 1) / tile;
+  // aim for ~16 workgroups per CU over the whole launch
+  const int64_t target = 16 * cus;
+  int64_t chunks = std::max<int64_t>(1, std::min<int64_t>(ntiles, (target + B - 1) / B));
+  int64_t tpw = (ntiles + chunks - 1) / chunks;
+  chunks = (ntiles + tpw - 1) / tpw;
+  p.a.n_particles = N;
+  p.a.chunks = (int32_t)chunks;
+  p.a.tiles_per_wg = (int32_t)tpw;
+  p.a.fused_build = fused ? 1 : 0;
+  p.a.store = p_out ? 1 : 0;
+  int64_t tile_scalars = tile * 7;
+  if (fused) tile_scalars = std::max<int64_t>(tile_scalars, kBuildChunk * 49);
+  tile_scalars = std::max<int64_t>(tile_scalars, (4 * 29 * 8 + sizeof(T) - 1) / sizeof(T));
+  tile_scalars = (tile_scalars + 3) / 4 * 4;
+  p.a.lds_tile_scalars = (int32_t)tile_scalars;
+  p.lds = ((size_t)tile_scalars + (size_t)S * LYNX_STEP_STRIDE + S + 1) * sizeof(T);
+  p.grid = (unsigned)(B * chunks);
+  const bool aligned = ((uintptr_t)p_in % 16 == 0) && (!p_out || (uintptr_t)p_out % 16 == 0) &&
+                       ((N * 7 * (int64_t)sizeof(T)) % 16 == 0);
+  p.vec = aligned;
+  return p;
+}
+
+template <typename T, int PPT, bool VEC, bool MOMENTS>
+static int launch_track_inst(lynx_ctx* ctx, const TrackPlan& p, const LatticeDev& lv, const void* d_energy_in,
+                             const void* d_p_in, void* d_p_out, void* d_energy_out, const void* d_steps,
+                             double* d_partials) {
+  int rc = allow_lds(ctx, k_track<T, PPT, VEC, MOMENTS>, p.lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL((k_track<T, PPT, VEC, MOMENTS>), dim3(p.grid), dim3(kTrackThreads), p.lds, ctx->stream, lv,
+                     p.a, (const T*)d_energy_in, (const T*)d_p_in, (T*)d_p_out, (T*)d_energy_out,
+                     (const T*)d_steps, d_partials);
+  HIP_TRY(ctx, hipGetLastError());
+  return LYNX_OK;
+}
+
+template <typename T, int PPT_BIG>
+static int launch_track(lynx_ctx* ctx, const TrackPlan& p, const LatticeDev& lv, const void* d_energy_in,
+                        const void* d_p_in, void* d_p_out, void* d_energy_out, const void* d_steps,
+                        double* d_partials, bool moments) {
+#define LYNX_DISPATCH(PPT, VEC, MOM) \
+  return launch_track_inst<T, PPT, VEC, MOM>(ctx, p, lv, d_energy_in, d_p_in, d_p_out, d_energy_out, d_steps, d_partials)
+  if (p.ppt == 1) {
+    if (p.vec) { if (moments) LYNX_DISPATCH(1, true, true); else LYNX_DISPATCH(1, true, false); }
+    else       { if (moments) LYNX_DISPATCH(1, false, true); else LYNX_DISPATCH(1, false, false); }
+  } else {
+    if (p.vec) { if (moments) LYNX_DISPATCH(PPT_BIG, true, true); else LYNX_DISPATCH(PPT_BIG, true, false); }
+    else       { if (moments) LYNX_DISPATCH(PPT_BIG, false, true); else LYNX_DISPATCH(PPT_BIG, false, false); }
+  }
+#undef LYNX_DISPATCH
+}
+
+template <typename T>
+static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev& lv, int64_t B, int64_t N,
+                             const void* d_energy_in, const void* d_p_in, void* d_p_out, void* d_energy_out,
+                             double* d_moments_out, int flags) {
+  const int32_t S = lv.n_steps;
+  const bool moments = (flags & LYNX_TRACK_MOMENTS) != 0;
+  const bool fused = S > 0 && !(flags & LYNX_TRACK_TWO_KERNEL);
+  const void* d_steps = nullptr;
+  int rc;
+  if (S > 0 && !fused) {
+    const size_t need = (size_t)B * S * LYNX_STEP_STRIDE * sizeof(T);
+    if ((rc = ensure_scratch(ctx, &ctx->scratch_steps, &ctx->scratch_steps_bytes, need))) return rc;
+    if ((rc = launch_build<T>(ctx, lat, d_energy_in, ctx->scratch_steps, d_energy_out))) return rc;
+    d_steps = ctx->scratch_steps;
+  }
+  TrackPlan p = plan_track<T>(ctx, B, N, S, fused, d_p_in, d_p_out);
+  if ((int64_t)B * p.a.chunks > 0x7fffffffLL) return fail(ctx, LYNX_ERR_INVALID, "grid too large");
+  double* d_partials = nullptr;
+  if (moments) {
+    const size_t need = (size_t)B * p.a.chunks * kPartialStride * sizeof(double);
+    if ((rc = ensure_scratch(ctx, &ctx->scratch_partials, &ctx->scratch_partials_bytes, need))) return rc;
+    d_partials = (double*)ctx->scratch_partials;
+  }
+  rc = launch_track<T, (sizeof(T) == 4 ? 4 : 2)>(ctx, p, lv, d_energy_in, d_p_in, d_p_out,
+                                                 fused ? d_energy_out : nullptr, d_steps, d_partials, moments);
+  if (rc) return rc;
+  if (moments) {
+    hipLaunchKernelGGL(k_finalize_moments, dim3((unsigned)B), dim3(64), 0, ctx->stream, d_partials, p.a.chunks,
+                       d_moments_out);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  return LYNX_OK;
+}
+
+int lynx_track_particles(lynx_ctx* ctx, lynx_lattice* lat, int64_t n_particles, const void* d_energy_in,
+                         const void* d_p_in, void* d_p_out, void* d_energy_out, double* d_moments_out,
+                         int flags) {
+  if (!ctx || !lat || !d_p_in) return fail(ctx, LYNX_ERR_INVALID, "null argument");
+  if (n_particles <= 0) return fail(ctx, LYNX_ERR_INVALID, "n_particles must be > 0");
+  if (lat->n_steps > 0 && !d_energy_in) return fail(ctx, LYNX_ERR_INVALID, "energy_in required");
+  if ((flags & LYNX_TRACK_MOMENTS) && !d_moments_out)
+    return fail(ctx, LYNX_ERR_INVALID, "LYNX_TRACK_MOMENTS needs d_moments_out");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  LatticeDev lv = dev_view(lat);
+  return lat->dtype == LYNX_F64
+             ? track_particles_t<double>(ctx, lat, lv, lat->batch, n_particles, d_energy_in, d_p_in, d_p_out,
+                                         d_energy_out, d_moments_out, flags)
+             : track_particles_t<float>(ctx, lat, lv, lat->batch, n_particles, d_energy_in, d_p_in, d_p_out,
+                                        d_energy_out, d_moments_out, flags);
+}
+
+int lynx_moments(lynx_ctx* ctx, int dtype, int64_t batch, int64_t n_particles, const void* d_p,
+                 double* d_moments_out) {
+  if (!ctx || !d_p || !d_moments_out) return fail(ctx, LYNX_ERR_INVALID, "null argument");
+  if (batch <= 0 || n_particles <= 0) return fail(ctx, LYNX_ERR_INVALID, "bad shape");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  LatticeDev lv;
+  memset(&lv, 0, sizeof(lv));
+  lv.batch = batch;
+  return dtype == LYNX_F64
+             ? track_particles_t<double>(ctx, nullptr, lv, batch, n_particles, nullptr, d_p, nullptr, nullptr,
+                                         d_moments_out, LYNX_TRACK_MOMENTS)
+             : track_particles_t<float>(ctx, nullptr, lv, batch, n_particles, nullptr, d_p, nullptr, nullptr,
+                                        d_moments_out, LYNX_TRACK_MOMENTS);
+}
+
+// ---- ParameterBeam ---------------------------------------------------------------------
+
+template <typename T>
+static int launch_track_moments(lynx_ctx* ctx, lynx_lattice* lat, const void* d_energy_in, const void* d_mu_in,
+                                const void* d_cov_in, void* d_mu_out, void* d_cov_out, void* d_energy_out) {
+  const size_t lds =
+      ((size_t)kBuildChunk * 49 + (size_t)lat->n_steps * LYNX_STEP_STRIDE + lat->n_steps + 1 + 8 + 49 + 49 + 16) * sizeof(T);
+  int rc = allow_lds(ctx, k_track_moments<T>, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_track_moments<T>, dim3((unsigned)lat->batch), dim3(64), lds, ctx->stream, dev_view(lat),
+                     (const T*)d_energy_in, (const T*)d_mu_in, (const T*)d_cov_in, (T*)d_mu_out, (T*)d_cov_out,
+                     (T*)d_energy_out);
+  HIP_TRY(ctx, hipGetLastError());
+  return LYNX_OK;
+}
+
+int lynx_track_moments(lynx_ctx* ctx, lynx_lattice* lat, const void* d_energy_in, const void* d_mu_in,
+                       const void* d_cov_in, void* d_mu_out, void* d_cov_out, void* d_energy_out) {
+  if (!ctx || !lat || !d_energy_in || !d_mu_in || !d_cov_in || !d_mu_out || !d_cov_out)
+    return fail(ctx, LYNX_ERR_INVALID, "null argument");
+  if (lat->batch > 0x7fffffffLL) return fail(ctx, LYNX_ERR_INVALID, "batch too large");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  return lat->dtype == LYNX_F64
+             ? launch_track_moments<double>(ctx, lat, d_energy_in, d_mu_in, d_cov_in, d_mu_out, d_cov_out, d_energy_out)
+             : launch_track_moments<float>(ctx, lat, d_energy_in, d_mu_in, d_cov_in, d_mu_out, d_cov_out, d_energy_out);
+}
+
+// ---- synthetic beams -------------------------------------------------------------------
+
+int lynx_fill_gaussian(lynx_ctx* ctx, int dtype, int64_t batch, int64_t n_particles, const double* mu,
+                       const double* sigma, uint64_t seed, void* d_p) {
+  if (!ctx || !d_p || !mu || !sigma || batch <= 0 || n_particles <= 0)
+    return fail(ctx, LYNX_ERR_INVALID, "bad argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  GaussArgs g;
+  for (int i = 0; i < 6; ++i) {
+    g.mu[i] = mu[i];
+    g.sigma[i] = sigma[i];
+  }
+  const int64_t total = batch * n_particles * 7;
+  const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 32);
+  if (dtype == LYNX_F64)
+    hipLaunchKernelGGL(k_fill_gaussian<double>, dim3(grid), dim3(256), 0, ctx->stream, (double*)d_p, total, seed, g);
+  else
+    hipLaunchKernelGGL(k_fill_gaussian<float>, dim3(grid), dim3(256), 0, ctx->stream, (float*)d_p, total, seed, g);
+  HIP_TRY(ctx, hipGetLastError());
+  return LYNX_OK;
+}
+
+// ---- RCCL ------------------------------------------------------------------------------
+
+int lynx_comm_unique_id(char* id_out) {
+  static_assert(sizeof(ncclUniqueId) <= LYNX_UNIQUE_ID_BYTES, "unique id does not fit");
+  ncclUniqueId id;
+  NCCL_TRY(nullptr, ncclGetUniqueId(&id));
+  memset(id_out, 0, LYNX_UNIQUE_ID_BYTES);
+  memcpy(id_out, &id, sizeof(id));
+  return LYNX_OK;
+}
+
+int lynx_comm_init(lynx_ctx* ctx, int n_ranks, int rank, const char* id) {
+  if (!ctx || !id || n_ranks <= 0 || rank < 0 || rank >= n_ranks) return fail(ctx, LYNX_ERR_INVALID, "bad argument");
+  if (ctx->comm) return fail(ctx, LYNX_ERR_INVALID, "communicator already initialised");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ncclUniqueId uid;
+  memcpy(&uid, id, sizeof(uid));
+  NCCL_TRY(ctx, ncclCommInitRank(&ctx->comm, n_ranks, uid, rank));
+  ctx->comm_ranks = n_ranks;
+  return LYNX_OK;
+}
+
+int lynx_comm_destroy(lynx_ctx* ctx) {
+  if (ctx && ctx->comm) {
+    NCCL_TRY(ctx, ncclCommDestroy(ctx->comm));
+    ctx->comm = nullptr;
+    ctx->comm_ranks = 0;
+  }
+  return LYNX_OK;
+}
+
+int lynx_gather_moments(lynx_ctx* ctx, const double* d_send, double* d_recv, int64_t count) {
+  if (!ctx || !ctx->comm) return fail(ctx, LYNX_ERR_INVALID, "communicator not initialised");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  NCCL_TRY(ctx, ncclAllGather(d_send, d_recv, (size_t)count, ncclDouble, ctx->comm, ctx->stream));
+  return LYNX_OK;
+}
+

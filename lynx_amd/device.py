@@ -1,0 +1,201 @@
+"""
+GPU runtime of the package: one `Runtime` (liblynxhip context = one GPU, one HIP stream)
+per process, and `DeviceArray`, the HBM-resident array the beams hold.
+
+One process drives one GPU (the multi-GPU model is one process per GPU, see
+`lynx_amd.parallel`); the device ordinal is `LYNX_DEVICE`, else `LOCAL_RANK`, else 0.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import weakref
+
+import numpy as np
+
+from . import _ffi
+
+_DTYPES = {np.dtype(np.float32): _ffi.F32, np.dtype(np.float64): _ffi.F64}
+
+
+def dtype_code(dtype) -> int:
+    try:
+        return _DTYPES[np.dtype(dtype)]
+    except KeyError:
+        raise TypeError(f"lynx_amd supports float32 and float64, not {dtype}") from None
+
+
+class Runtime:
+    """Owns the liblynxhip context of this process."""
+
+    def __init__(self, device: int | None = None):
+        self.lib = _ffi.load()
+        if device is None:
+            device = int(os.environ.get("LYNX_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+            count = C.c_int(0)
+            self.lib.lynx_device_count(C.byref(count))
+            if count.value > 0:
+                device %= count.value
+        handle = C.c_void_p()
+        _ffi.check(self.lib.lynx_ctx_create(int(device), C.byref(handle)))
+        self.ctx = handle
+        self.device = int(device)
+        self._finalizer = weakref.finalize(self, self.lib.lynx_ctx_destroy, handle)
+
+    # -- plumbing -------------------------------------------------------------------------
+    def check(self, status: int):
+        _ffi.check(status, self.ctx)
+
+    def sync(self):
+        self.check(self.lib.lynx_sync(self.ctx))
+
+    def info(self) -> dict:
+        di = _ffi.DeviceInfo()
+        self.check(self.lib.lynx_device_info(self.ctx, C.byref(di)))
+        return {"name": di.name.decode(), "arch": di.arch.decode(), "compute_units": di.compute_units,
+                "lds_bytes_per_cu": di.lds_bytes_per_cu, "hbm_bytes": di.hbm_bytes}
+
+    def timer_start(self):
+        self.check(self.lib.lynx_timer_start(self.ctx))
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        self.check(self.lib.lynx_timer_stop(self.ctx, C.byref(ms)))
+        return float(ms.value)
+
+    def alloc(self, nbytes: int) -> int:
+        ptr = C.c_void_p()
+        self.check(self.lib.lynx_buf_alloc(self.ctx, int(nbytes), C.byref(ptr)))
+        return ptr.value
+
+    def free(self, ptr: int):
+        self.lib.lynx_buf_free(self.ctx, C.c_void_p(ptr))
+
+    # -- arrays ---------------------------------------------------------------------------
+    def empty(self, shape, dtype) -> "DeviceArray":
+        return DeviceArray(self, tuple(int(s) for s in shape), np.dtype(dtype))
+
+    def to_device(self, host) -> "DeviceArray":
+        host = np.ascontiguousarray(host)
+        arr = self.empty(host.shape, host.dtype)
+        if host.nbytes:
+            self.check(self.lib.lynx_buf_h2d(self.ctx, arr.ptr, host.ctypes.data, host.nbytes))
+        return arr
+
+
+_runtime: Runtime | None = None
+
+
+def get_runtime() -> Runtime:
+    """The process-wide runtime (created on first use).  Raises without a GPU."""
+    global _runtime
+    if _runtime is None:
+        _runtime = Runtime()
+    return _runtime
+
+
+class DeviceArray:
+    """A C-contiguous array in HBM.  `np.asarray(x)` copies it to the host."""
+
+    def __init__(self, rt: Runtime, shape: tuple, dtype: np.dtype):
+        self.rt = rt
+        self.shape = shape
+        self.dtype = dtype
+        self.size = int(np.prod(shape, dtype=np.int64)) if shape else 1
+        self.nbytes = self.size * dtype.itemsize
+        self.ptr = rt.alloc(max(self.nbytes, 1))
+        self._finalizer = weakref.finalize(self, rt.free, self.ptr)
+
+    @property
+    def ndim(self) -> int:
+        return len(self.shape)
+
+    def numpy(self) -> np.ndarray:
+        out = np.empty(self.shape, dtype=self.dtype)
+        if self.nbytes:
+            self.rt.check(self.rt.lib.lynx_buf_d2h(self.rt.ctx, out.ctypes.data, self.ptr, self.nbytes))
+        return out
+
+    def __array__(self, dtype=None, copy=None):
+        out = self.numpy()
+        return out if dtype is None else out.astype(dtype)
+
+    def __getitem__(self, idx):
+        return self.numpy()[idx]
+
+    def __len__(self):
+        return self.shape[0]
+
+    def reshape(self, *shape) -> "DeviceArray":
+        """A view with another shape sharing the same HBM block."""
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list)):
+            shape = tuple(shape[0])
+        view = object.__new__(DeviceArray)
+        view.rt, view.dtype, view.ptr = self.rt, self.dtype, self.ptr
+        view.shape = tuple(int(s) for s in shape)
+        view.size = int(np.prod(view.shape, dtype=np.int64)) if view.shape else 1
+        assert view.size == self.size, "reshape must keep the number of elements"
+        view.nbytes = self.nbytes
+        view._base = self  # keeps the owner (and its finalizer) alive
+        return view
+
+    def copy(self) -> "DeviceArray":
+        out = self.rt.empty(self.shape, self.dtype)
+        self.rt.check(self.rt.lib.lynx_buf_d2d(self.rt.ctx, out.ptr, self.ptr, self.nbytes))
+        return out
+
+    def __repr__(self):
+        return f"DeviceArray(shape={self.shape}, dtype={self.dtype}, device={self.rt.device})"
+
+
+def as_host(x) -> np.ndarray:
+    """NumPy view/copy of a host array, DeviceArray or sequence."""
+    if isinstance(x, DeviceArray):
+        return x.numpy()
+    return np.asarray(x)
+
+
+class Dual:
+    """
+    A value that may live on the host, in HBM, or both.  Beams hold these so that a beam
+    built from NumPy data is uploaded once, and a beam produced by a kernel is only copied
+    back when somebody looks at it.
+    """
+
+    def __init__(self, host=None, dev: DeviceArray | None = None):
+        assert host is not None or dev is not None
+        self._host = None if host is None else np.asarray(host)
+        self._dev = dev
+        self._bcast = {}
+
+    @property
+    def shape(self):
+        return self._dev.shape if self._dev is not None else self._host.shape
+
+    @property
+    def dtype(self):
+        return self._dev.dtype if self._dev is not None else self._host.dtype
+
+    @property
+    def on_device(self) -> bool:
+        return self._dev is not None
+
+    def host(self) -> np.ndarray:
+        if self._host is None:
+            self._host = self._dev.numpy()
+        return self._host
+
+    def device(self, rt: Runtime | None = None) -> DeviceArray:
+        if self._dev is None:
+            self._dev = (rt or get_runtime()).to_device(self._host)
+        return self._dev
+
+    def broadcast_device(self, rt: Runtime, shape) -> DeviceArray:
+        """Device copy broadcast to `shape` (per-sample scalars such as the beam energy)."""
+        shape = tuple(shape)
+        if tuple(self.shape) == shape:
+            return self.device(rt)
+        if shape not in self._bcast:
+            self._bcast[shape] = rt.to_device(np.ascontiguousarray(np.broadcast_to(self.host(), shape)))
+        return self._bcast[shape]

@@ -1,0 +1,364 @@
+"""
+Host side of the hot path: turns a list of element objects into the flat lattice program
+liblynxhip consumes (include/lynx_hip.h) and dispatches the kernels.
+
+What stays on the host is exactly what the reference also decides in Python: the order of
+elements, the partition of the lattice into maximal skippable runs and non-skippable
+elements (`Segment.track`, lynx/accelerator/segment.py:340-356) and the whole-batch
+`if any(...)` predicates (track_methods.py:101, quadrupole.py:75, dipole.py:119,
+cavity.py:128,164,260,290).  All arithmetic on maps, moments and particles happens in the
+HIP kernels; there is no CPU fallback.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _ffi, config
+from .device import DeviceArray, Dual, dtype_code, get_runtime
+
+ELECTRON_MASS_EV = 510998.95069  # cavity.py:20
+
+
+# -------------------------------------------------------------------------------------------
+# program = what Segment.track iterates over
+# -------------------------------------------------------------------------------------------
+
+
+@dataclass
+class Program:
+    """A maximal stretch of the lattice one kernel launch can run: runs + active cavities."""
+
+    leaves: list = field(default_factory=list)  # leaf elements in lattice order
+    steps: list = field(default_factory=list)   # (kind, first, last) over `leaves`
+
+    def add_run_element(self, element, new_run: bool):
+        idx = len(self.leaves)
+        self.leaves.append(element)
+        if new_run or not self.steps or self.steps[-1][0] != _ffi.STEP_RUN:
+            self.steps.append([_ffi.STEP_RUN, idx, idx + 1])
+        else:
+            self.steps[-1][2] = idx + 1
+
+    def add_cavity(self, element):
+        idx = len(self.leaves)
+        self.leaves.append(element)
+        self.steps.append([_ffi.STEP_CAVITY, idx, idx + 1])
+
+
+def partition(elements) -> list:
+    """
+    Mirror of the `todos` loop in segment.py:344-351, flattened over nested segments:
+    returns a list of `Program` objects and host-side barrier elements (active BPMs), in
+    order.  A nested non-skippable Segment is tracked on its own by the reference, so it
+    starts and ends a run; a nested skippable Segment's elements join the current run (the
+    reference multiplies its pre-composed product instead: same map up to rounding).
+    """
+    from .accelerator.segment import Segment  # cycle-free at call time
+
+    out: list = []
+    state = {"new_run": True}
+
+    def current() -> Program:
+        if not out or not isinstance(out[-1], Program):
+            out.append(Program())
+            state["new_run"] = True
+        return out[-1]
+
+    def walk(items):
+        for el in items:
+            if isinstance(el, Segment):
+                if el.is_skippable:
+                    walk(el.elements)
+                else:
+                    state["new_run"] = True
+                    walk(el.elements)
+                    state["new_run"] = True
+            elif el.is_skippable:
+                current().add_run_element(el, state["new_run"])
+                state["new_run"] = False
+            elif el._kind == _ffi.KIND_CAVITY:
+                current().add_cavity(el)
+                state["new_run"] = True
+            elif getattr(el, "_host_barrier", False):
+                out.append(el)
+                state["new_run"] = True
+            else:
+                raise TypeError(f"element {el!r} cannot be tracked by lynx_amd")
+
+    walk(elements)
+    return out
+
+
+# -------------------------------------------------------------------------------------------
+# packing
+# -------------------------------------------------------------------------------------------
+
+
+def _broadcast_param(value, batch_shape, dtype, what):
+    arr = np.asarray(value, dtype=dtype)
+    try:
+        return np.broadcast_to(arr, batch_shape)
+    except ValueError:
+        raise AssertionError(
+            f"Beam shape {tuple(batch_shape)} does not match element shape {arr.shape} ({what})"
+        ) from None
+
+
+class PackedLattice:
+    """Device-resident lattice program + the host arrays it was packed from."""
+
+    def __init__(self, program: Program, batch_shape, dtype):
+        self.program = program
+        self.batch_shape = tuple(batch_shape)
+        self.dtype = np.dtype(dtype)
+        self.B = int(np.prod(self.batch_shape, dtype=np.int64))
+        leaves = program.leaves
+        E, S = len(leaves), len(program.steps)
+        self.elems = (_ffi.Elem * max(E, 1))()
+        self.steps = (_ffi.Step * max(S, 1))()
+        parts, offset = [], 0
+        for e, el in enumerate(leaves):
+            rows = el._param_rows(self.dtype)
+            n = _ffi.PARAMS_OF_KIND[el._kind]
+            assert len(rows) == n, (el, len(rows), n)
+            if n == 0:
+                stride = 0
+            elif all(np.asarray(r).size == 1 for r in rows):
+                parts.append(np.array([np.asarray(r, dtype=self.dtype).reshape(()) for r in rows],
+                                      dtype=self.dtype))
+                stride = 0
+            else:
+                mat = np.stack(
+                    [_broadcast_param(r, self.batch_shape, self.dtype, type(el).__name__).reshape(self.B)
+                     for r in rows], axis=1)
+                parts.append(np.ascontiguousarray(mat).reshape(-1))
+                stride = n
+            self.elems[e] = _ffi.Elem(el._kind, 0, offset, stride)
+            offset += parts[-1].size if n else 0
+        self.pool = (np.concatenate(parts) if parts else np.zeros(1, dtype=self.dtype)).astype(self.dtype)
+        for s, (kind, first, last) in enumerate(program.steps):
+            self.steps[s] = _ffi.Step(kind, first, last, 0)
+        self.E, self.S = E, S
+        self.elem_flags = [0] * E
+        self.step_flags = [0] * S
+        self.has_cavity_step = any(k == _ffi.STEP_CAVITY for k, _, _ in program.steps)
+        self.handle = None
+        self.rt = None
+
+    # whole-batch predicates -----------------------------------------------------------------
+    def evaluate_flags(self, energy_host):
+        """
+        Element flags, cavity step flags and the reference's assertions, from the host view
+        of the beam energy.  Returns (elem_flags, step_flags).
+        """
+        leaves = self.program.leaves
+        elem_flags = [el._static_flags() for el in leaves]
+        step_flags = [0] * self.S
+        energy = np.broadcast_to(np.asarray(energy_host, dtype=self.dtype), self.batch_shape)
+        for s, (kind, first, last) in enumerate(self.program.steps):
+            for e in range(first, last):
+                el = leaves[e]
+                if el._kind != _ffi.KIND_CAVITY:
+                    continue
+                # cavity.py:260 (also reached for switched-off cavities inside a run)
+                assert np.all(energy > 0), "Initial energy must be larger than 0"
+                voltage = np.asarray(el.voltage, dtype=self.dtype)
+                with np.errstate(all="ignore"):
+                    d_energy = voltage * np.cos(np.deg2rad(np.asarray(el.phase, dtype=self.dtype)))
+                    f = 0
+                    if np.any((voltage != 0) & (energy != 0)):  # cavity.py:290
+                        f |= _ffi.FLAG_CAV_BETA
+                    if kind == _ffi.STEP_CAVITY:
+                        if np.any(energy + d_energy > 0):  # cavity.py:128
+                            f |= _ffi.FLAG_CAV_GAIN
+                        if np.any(d_energy > 0):  # cavity.py:164
+                            f |= _ffi.FLAG_CAV_T5XX
+                        step_flags[s] = f
+                        if f & _ffi.FLAG_CAV_GAIN:
+                            energy = np.broadcast_to(energy + d_energy, self.batch_shape)
+                elem_flags[e] |= f
+        return elem_flags, step_flags
+
+    # device side ----------------------------------------------------------------------------
+    def upload(self, rt, elem_flags, step_flags):
+        for e, f in enumerate(elem_flags):
+            self.elems[e].flags = f
+        for s, f in enumerate(step_flags):
+            self.steps[s].flags = f
+        self.elem_flags, self.step_flags = list(elem_flags), list(step_flags)
+        handle = C.c_void_p()
+        rt.check(rt.lib.lynx_lattice_create(
+            rt.ctx, dtype_code(self.dtype), self.B, self.E, self.elems, self.S, self.steps,
+            self.pool.ctypes.data, self.pool.size, C.byref(handle)))
+        self.handle, self.rt = handle, rt
+
+    def set_flags(self, elem_flags, step_flags):
+        if list(elem_flags) == self.elem_flags and list(step_flags) == self.step_flags:
+            return
+        ef = (C.c_int32 * max(self.E, 1))(*elem_flags)
+        sf = (C.c_int32 * max(self.S, 1))(*step_flags)
+        self.rt.check(self.rt.lib.lynx_lattice_set_flags(self.handle, ef, sf))
+        self.elem_flags, self.step_flags = list(elem_flags), list(step_flags)
+
+    def release(self):
+        if self.handle is not None:
+            self.rt.lib.lynx_lattice_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+class LatticeCache:
+    """Packed programs of one owner (a Segment or an Element), keyed by element versions."""
+
+    def __init__(self, capacity: int = 4):
+        self.capacity = capacity
+        self.entries: dict = {}
+
+    def get(self, program: Program, batch_shape, dtype) -> PackedLattice:
+        key = (tuple((id(el), el._version) for el in program.leaves),
+               tuple(tuple(s) for s in program.steps), tuple(batch_shape), np.dtype(dtype).str)
+        hit = self.entries.get(key)
+        if hit is None:
+            if len(self.entries) >= self.capacity:
+                self.entries.pop(next(iter(self.entries))).release()
+            hit = PackedLattice(program, batch_shape, dtype)
+            self.entries[key] = hit
+        return hit
+
+
+def _ready(cache: LatticeCache, program: Program, batch_shape, dtype, energy_host) -> PackedLattice:
+    lat = cache.get(program, batch_shape, dtype)
+    elem_flags, step_flags = lat.evaluate_flags(energy_host)
+    if lat.handle is None:
+        lat.upload(get_runtime(), elem_flags, step_flags)
+    else:
+        lat.set_flags(elem_flags, step_flags)
+    return lat
+
+
+# -------------------------------------------------------------------------------------------
+# dispatch
+# -------------------------------------------------------------------------------------------
+
+
+def _ptr(x):
+    return None if x is None else C.c_void_p(x.ptr)
+
+
+def run_program_particles(cache, program: Program, beam, moments: bool | None = None):
+    """One launch of the fused kernel: ParticleBeam -> ParticleBeam."""
+    from .particles.particle_beam import ParticleBeam
+
+    rt = get_runtime()
+    dtype = beam.dtype
+    batch_shape = beam.batch_shape
+    lat = _ready(cache, program, batch_shape, dtype, beam._energy.host())
+    p_in = beam._particles.device(rt)
+    p_out = rt.empty(p_in.shape, dtype)
+    e_in = beam._energy.broadcast_device(rt, batch_shape)
+    e_out = rt.empty(batch_shape, dtype) if lat.has_cavity_step else None
+    want_moments = config.fused_moments if moments is None else moments
+    mom = rt.empty((*batch_shape, _ffi.MOMENT_STRIDE), np.float64) if want_moments else None
+    flags = (_ffi.TRACK_MOMENTS if want_moments else 0) | (_ffi.TRACK_TWO_KERNEL if config.two_kernel else 0)
+    rt.check(rt.lib.lynx_track_particles(rt.ctx, lat.handle, beam.num_particles, _ptr(e_in), _ptr(p_in),
+                                         _ptr(p_out), _ptr(e_out), _ptr(mom), flags))
+    out = ParticleBeam.__new__(ParticleBeam)
+    out._init_raw(Dual(dev=p_out), Dual(dev=e_out) if e_out is not None else beam._energy,
+                  beam._charges, dtype, moments=Dual(dev=mom) if mom is not None else None)
+    return out
+
+
+def run_program_parameters(cache, program: Program, beam):
+    """ParameterBeam -> ParameterBeam (lynx_track_moments)."""
+    from .particles.parameter_beam import ParameterBeam
+
+    rt = get_runtime()
+    dtype = beam.dtype
+    batch_shape = beam.batch_shape
+    lat = _ready(cache, program, batch_shape, dtype, beam._energy.host())
+    mu_in = beam._mu_d.device(rt)
+    cov_in = beam._cov_d.device(rt)
+    mu_out = rt.empty(mu_in.shape, dtype)
+    cov_out = rt.empty(cov_in.shape, dtype)
+    e_in = beam._energy.broadcast_device(rt, batch_shape)
+    e_out = rt.empty(batch_shape, dtype) if lat.has_cavity_step else None
+    rt.check(rt.lib.lynx_track_moments(rt.ctx, lat.handle, _ptr(e_in), _ptr(mu_in), _ptr(cov_in),
+                                       _ptr(mu_out), _ptr(cov_out), _ptr(e_out)))
+    out = ParameterBeam.__new__(ParameterBeam)
+    out._init_raw(Dual(dev=mu_out), Dual(dev=cov_out),
+                  Dual(dev=e_out) if e_out is not None else beam._energy, beam.total_charge, dtype)
+    return out
+
+
+def track(owner, elements, incoming):
+    """`Segment.track` / `Element.track` for both beam types."""
+    from .particles.beam import Beam
+    from .particles.parameter_beam import ParameterBeam
+    from .particles.particle_beam import ParticleBeam
+
+    if incoming is Beam.empty:
+        for el in elements:
+            if getattr(el, "_host_barrier", False):
+                el._observe(incoming)
+        return incoming
+    if not isinstance(incoming, (ParameterBeam, ParticleBeam)):
+        raise TypeError(f"Parameter incoming is of invalid type {type(incoming)}")
+    cache = owner.__dict__.setdefault("_lattice_cache", LatticeCache())
+    beam = incoming
+    for item in partition(elements):
+        if isinstance(item, Program):
+            if isinstance(beam, ParticleBeam):
+                beam = run_program_particles(cache, item, beam)
+            else:
+                beam = run_program_parameters(cache, item, beam)
+        else:  # active BPM: bpm.py:48-58
+            item._observe(beam)
+            beam = beam._shallow_copy()
+    return beam
+
+
+def transfer_map(owner, elements, energy, dtype) -> np.ndarray:
+    """`transfer_map(energy)` of a skippable element list -> host array (*batch, 7, 7)."""
+    rt = get_runtime()
+    dtype = np.dtype(dtype)
+    energy = np.asarray(energy, dtype=dtype)
+    batch_shape = energy.shape
+    items = partition(elements)
+    if not items:
+        out = np.zeros((*batch_shape, 7, 7), dtype=dtype)
+        out[..., range(7), range(7)] = 1
+        return out
+    assert len(items) == 1 and isinstance(items[0], Program) and len(items[0].steps) == 1, (
+        "transfer_map needs a skippable element list")
+    program = items[0]
+    cache = owner.__dict__.setdefault("_lattice_cache", LatticeCache())
+    lat = _ready(cache, program, batch_shape, dtype, energy)
+    e_in = rt.to_device(np.ascontiguousarray(energy))
+    steps = rt.empty((lat.B, 1, _ffi.STEP_STRIDE), dtype)
+    rt.check(rt.lib.lynx_build_compose(rt.ctx, lat.handle, _ptr(e_in), _ptr(steps), None))
+    table = steps.numpy()
+    return table[:, 0, :49].reshape(*batch_shape, 7, 7)
+
+
+def cavity_rmatrix(cavity, energy, dtype) -> np.ndarray:
+    """`Cavity.transfer_map` = `_cavity_rmatrix` (cavity.py:248-325) whether or not it is on."""
+    rt = get_runtime()
+    dtype = np.dtype(dtype)
+    energy = np.asarray(energy, dtype=dtype)
+    program = Program()
+    program.add_run_element(cavity, True)
+    cache = cavity.__dict__.setdefault("_lattice_cache", LatticeCache())
+    lat = _ready(cache, program, energy.shape, dtype, energy)
+    e_in = rt.to_device(np.ascontiguousarray(energy))
+    steps = rt.empty((lat.B, 1, _ffi.STEP_STRIDE), dtype)
+    rt.check(rt.lib.lynx_build_compose(rt.ctx, lat.handle, _ptr(e_in), _ptr(steps), None))
+    return steps.numpy()[:, 0, :49].reshape(*energy.shape, 7, 7)
