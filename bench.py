@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""
+Benchmark of the hot path: `Segment.track()` on a `ParticleBeam`, fused output moments
+included, on synthetic lattices/beams of the shapes BASELINE.json names.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torchrun)
+
+A "step" is one `segment.track(beam)` over the whole per-GPU batch: one fused launch that
+builds + composes every sample's element maps and streams the particles through them,
+the moment finalisation, and (N > 1) the RCCL all-gather of the per-sample moment records.
+Particles, lattice parameters and outputs are resident in HBM when the timed region starts.
+
+Workload (default `c4`): BASELINE.json config 4, the configuration the metric's target is
+quoted on ("1024-batch x 100k-particle x 128-element lattice"): 1024 lattice-parameter
+samples (k1 scan) x 128-element FODO x 100 000 particles, fp32 -- 5.73 GB of algorithmic
+traffic per step, it fits one GPU.  Scaling is weak: every GPU tracks its own 1024
+samples (global batch 1024 N), no particle ever crosses xGMI.
+
+Prints ONE JSON line on rank 0.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+
+WORKLOADS = {
+    # name: (batch per GPU, particles, FODO cells (x4 elements), dtype, description)
+    "c4": (1024, 100_000, 32, np.float32,
+           "BASELINE config 4: 1024 k1-scan samples x 128-element FODO x 100k particles fp32 per GPU"),
+    "c3": (1, 1_000_000, 32, np.float64, "BASELINE config 3: 128-element FODO x 1M particles fp64, batch 1"),
+    "c3big": (1, 8_000_000, 32, np.float64, "config 3 at 8M particles (896 MB: defeats the 256 MB Infinity Cache)"),
+    "c2": (1, 100_000, 0, np.float32, "BASELINE config 2: 11-element ARES-style segment x 100k particles fp32"),
+}
+
+
+def build_segment(lx, name, batch, cells, dtype, rank, world):
+    f = lambda v: np.full((batch,), v, dtype=dtype)  # noqa: E731
+    if name == "c2":
+        return lx.Segment([
+            lx.BPM(name="BPM1SMATCH"), lx.Drift(f(1.0), dtype=dtype), lx.BPM(name="BPM6SMATCH"),
+            lx.Drift(f(1.0), dtype=dtype), lx.VerticalCorrector(f(0.3), angle=f(3.142e-3), name="V7SMATCH", dtype=dtype),
+            lx.Drift(f(0.2), dtype=dtype), lx.HorizontalCorrector(f(0.3), angle=f(1e-4), name="H10SMATCH", dtype=dtype),
+            lx.Drift(f(7.0), dtype=dtype), lx.HorizontalCorrector(f(0.3), angle=f(-1e-4), name="H12SMATCH", dtype=dtype),
+            lx.Drift(f(0.05), dtype=dtype), lx.BPM(name="BPM13SMATCH")])
+    # k1 scan over the GLOBAL batch: sample g = rank*batch + b gets k1 = +-4.2 (0.5 + (g mod 1024)/1023)
+    g = rank * batch + np.arange(batch)
+    scale = (0.5 + (g % 1024) / 1023.0) if batch > 1 else np.ones(1)
+    k = (4.2 * scale).astype(dtype)
+    elements = []
+    for _ in range(cells):
+        elements += [lx.Quadrupole(f(0.2), k1=k, dtype=dtype), lx.Drift(f(0.5), dtype=dtype),
+                     lx.Quadrupole(f(0.2), k1=-k, dtype=dtype), lx.Drift(f(0.5), dtype=dtype)]
+    return lx.Segment(elements)
+
+
+def cpu_baseline(name, particles, cells, dtype, budget_s=12.0):
+    """The oracle (NumPy restatement of the reference algorithm) on a bounded sample, 1 thread."""
+    from oracle import lynx_oracle as o
+
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:  # pragma: no cover
+        threadpool_limits = None
+    bs = 8 if name == "c4" else 1
+    n = particles if name != "c3big" else 1_000_000
+    if name == "c2":
+        specs = o.ares_like_segment(dtype, (bs,))
+    else:
+        scale = 0.5 + np.arange(bs) / max(bs - 1, 1) if bs > 1 else None
+        specs = o.fodo_segment(cells, np.dtype(dtype).type, (bs,), scale)
+    P = o.gaussian_particles((bs,), n, seed=2, dtype=dtype, sigma=[1e-4, 1e-5, 1e-4, 1e-5, 1e-5, 1e-3])
+    beam = o.particle_beam(P, np.full((bs,), 1e8, dtype=dtype), dtype)
+    E = len(specs)
+
+    def run():
+        out = o.segment_track(specs, beam, dtype)
+        o.beam_moments(out)
+
+    ctx = threadpool_limits(limits=1) if threadpool_limits else None
+    try:
+        run()
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            run()
+            reps += 1
+            dt = time.perf_counter() - t0
+            if dt > budget_s or reps >= 200:
+                break
+    finally:
+        if ctx is not None:
+            ctx.unregister() if hasattr(ctx, "unregister") else None
+    steps = bs * n * E * reps
+    return {"value": steps / dt, "unit": "particle-element-steps/s", "cores": 1, "kind": "port",
+            "sample": f"oracle (NumPy restatement) on {bs} samples x {n} particles x {E} elements, "
+                      f"{reps} passes in {dt:.1f} s, 1 thread of {os.cpu_count()} host cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=os.environ.get("LYNX_BENCH_WORKLOAD", "c4"), choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=None, help="override the per-GPU batch")
+    ap.add_argument("--particles", type=int, default=None)
+    ap.add_argument("--no-moments", action="store_true", help="track without the fused moment epilogue")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        sys.exit(f"--gpus {args.gpus} needs torchrun with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # plumbing only: rendezvous, barrier, max over ranks
+
+        dist.init_process_group("gloo")
+
+    import lynx_amd as lx
+    from lynx_amd.device import get_runtime
+    from lynx_amd.parallel import RcclCommunicator
+
+    rt = get_runtime()
+    batch, particles, cells, dtype, descr = WORKLOADS[args.workload]
+    batch = args.batch or batch
+    particles = args.particles or particles
+    dtype = np.dtype(dtype).type
+    lx.config.fused_moments = not args.no_moments
+
+    segment = build_segment(lx, args.workload, batch, cells, dtype, rank, world)
+    n_elements = len(segment.elements)
+    beam = lx.ParticleBeam.synthetic((batch,), particles, sigma=[1e-4, 1e-5, 1e-4, 1e-5, 1e-5, 1e-3], energy=1e8,
+                                     seed=2 + rank, dtype=dtype)
+
+    comm, gather_kind = None, "none"
+    if world > 1:
+        def exchange(uid):
+            box = [uid]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+
+        comm = RcclCommunicator(world, rank, exchange, rt)
+        gather_kind = "rccl-allgather"
+
+    def step():
+        out = segment.track(beam)
+        if comm is not None and out._moments is not None:
+            return out, comm.all_gather(out._moments.device(rt).reshape(batch, 36))
+        return out, None
+
+    for _ in range(args.warmup):
+        last = step()
+    rt.sync()
+    if dist is not None:
+        dist.barrier()
+    rt.sync()
+    rt.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    rt.sync()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kern_ms, launches = rt.profile_end()
+
+    if dist is not None:
+        import torch
+
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity on the last result (outside the timed region): finite moments, right count
+    out, gathered = last
+    if out._moments is not None:
+        rec = out.moment_record()
+        assert np.all(np.isfinite(rec)) and np.all(rec[..., 35] == particles), "bench: bad moment records"
+    if gathered is not None:
+        g = np.asarray(gathered)
+        assert g.shape == (world, batch, 36) and np.allclose(g[rank], rec.reshape(batch, 36))
+
+    if rank == 0:
+        itemsize = np.dtype(dtype).itemsize
+        steps_per_pass = batch * world * particles * n_elements
+        alg_bytes = 2 * batch * particles * 7 * itemsize  # per launch of the streaming kernel, per GPU
+        kern_s = kern_ms / 1e3 / max(launches, 1)
+        achieved = alg_bytes / kern_s / 1e9 if launches else None
+        result = {
+            "metric": "particle-element-steps/sec (whole node), Segment.track ParticleBeam",
+            "value": steps_per_pass * args.steps / elapsed,
+            "unit": "particle-element-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32" if itemsize == 4 else "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {descr}", "batch_per_gpu": batch, "global_batch": batch * world,
+                       "particles": particles, "elements": n_elements, "fused_moments": not args.no_moments,
+                       "gather": gather_kind, "parallelism": f"batch-sharded x{world}"},
+            "roofline": {"bound": "hbm", "kernel": "k_track", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                         "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+                         "avg_launch_ms": kern_s * 1e3, "launches": launches},
+            "hbm_gbs_whole_step": alg_bytes * world * args.steps / elapsed / 1e9,
+            "device": rt.info(),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            result["cpu_baseline"] = cpu_baseline(args.workload, particles, cells, dtype)
+        print(json.dumps(result))
+    if comm is not None:
+        comm.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

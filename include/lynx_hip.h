@@ -74,8 +74,14 @@ typedef struct lynx_step {
   int32_t kind;  /* lynx_step_kind */
   int32_t first; /* first element index */
   int32_t last;  /* one past the last element index (first+1 for a cavity) */
-  int32_t flags; /* cavity steps: copy of the element's LYNX_FLAG_CAV_* */
+  int32_t flags; /* cavity steps: copy of the element's LYNX_FLAG_CAV_*; runs: LYNX_STEP_FLAG_RAW */
 } lynx_step;
+/* Run step: take the first element's map as it is instead of left-multiplying it onto the
+ * identity.  `Element.track` applies `transfer_map()` directly (element.py:72,84), while
+ * `Segment.transfer_map` starts from eye(7) (segment.py:331-335); the two differ only in
+ * signed zeros and in how a NaN entry spreads (NaN * 0).  Cavity steps are always raw
+ * (cavity.py:113-121). */
+#define LYNX_STEP_FLAG_RAW 64
 
 /* flags of lynx_track_particles */
 #define LYNX_TRACK_MOMENTS 1     /* also accumulate the output-beam moments (fused epilogue) */
@@ -105,6 +111,11 @@ int lynx_sync(lynx_ctx* ctx);
 /* HIP-event timer on the context's stream (the stream every kernel below runs on). */
 int lynx_timer_start(lynx_ctx* ctx);
 int lynx_timer_stop(lynx_ctx* ctx, float* elapsed_ms);
+/* Per-launch timing of the streaming kernel (k_track) with HIP events recorded on the
+ * context's stream immediately around every launch between begin and end.  This is the
+ * figure bench.py's roofline uses; it matches rocprofv3's per-kernel duration. */
+int lynx_profile_begin(lynx_ctx* ctx);
+int lynx_profile_end(lynx_ctx* ctx, double* total_ms, int64_t* launches);
 
 /* ---- device buffers (reference: jax.Array storage behind `ParticleBeam.particles`,
  *      particle_beam.py:24-45; the Python side owns the handles) ----------------------- */

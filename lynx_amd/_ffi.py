@@ -26,6 +26,7 @@ FLAG_TILT, FLAG_MISALIGNED, FLAG_THICK = 1, 2, 4
 FLAG_CAV_BETA, FLAG_CAV_GAIN, FLAG_CAV_T5XX = 8, 16, 32
 
 STEP_RUN, STEP_CAVITY = 0, 1
+STEP_FLAG_RAW = 64
 
 TRACK_MOMENTS, TRACK_TWO_KERNEL = 1, 2
 
@@ -62,6 +63,8 @@ SIGNATURES = {
     "lynx_sync": (_i, [_vp]),
     "lynx_timer_start": (_i, [_vp]),
     "lynx_timer_stop": (_i, [_vp, C.POINTER(C.c_float)]),
+    "lynx_profile_begin": (_i, [_vp]),
+    "lynx_profile_end": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "lynx_buf_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "lynx_buf_free": (_i, [_vp, _vp]),
     "lynx_buf_h2d": (_i, [_vp, _vp, _vp, _sz]),

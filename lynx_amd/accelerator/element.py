@@ -67,11 +67,11 @@ class Element:
         """
         energy = np.asarray(energy)
         dtype = energy.dtype if energy.dtype in (np.float32, np.float64) else self.dtype
-        return engine.transfer_map(self, [self], energy, dtype)
+        return engine.transfer_map(self, [self], energy, dtype, raw=True)
 
     def track(self, incoming):
         """Track a `ParameterBeam` or `ParticleBeam` through the element (element.py:61-94)."""
-        return engine.track(self, [self], incoming)
+        return engine.track(self, [self], incoming, raw=True)
 
     def forward(self, incoming):
         return self.track(incoming)

@@ -92,22 +92,27 @@ __device__ void build_compose_sample(const LatticeDev& lat, int64_t b, T energy_
     __syncthreads();
     // phase 2 (wave 0)
     if (tid < 64) {
-      int info = 0;  // lane t: (step << 2) | is_last << 1 | is_first, for element e0 + t
+      int info = 0;  // lane t: (step << 3) | raw << 2 | is_last << 1 | is_first, for element e0 + t
       if (lane < ne) {
         const int e = e0 + lane;
         const int s = lat.elem_step[e];
         lynx_step st = lat.steps[s];
-        info = (s << 2) | ((e == st.last - 1) ? 2 : 0) | ((e == st.first) ? 1 : 0);
+        const bool raw = st.kind == LYNX_STEP_CAVITY || (st.flags & LYNX_STEP_FLAG_RAW);
+        info = (s << 3) | (raw ? 4 : 0) | ((e == st.last - 1) ? 2 : 0) | ((e == st.first) ? 1 : 0);
       }
       for (int t = 0; t < ne; ++t) {
         const int inf = __shfl(info, t, 64);
-        if (inf & 1) tval = (ci == cj) ? T(1) : T(0);
         const T* M = s_scratch + t * 49 + ci * 7;
-        T acc = M[0] * shfl_t(tval, 0 * 7 + cj);
+        if ((inf & 5) == 5) {
+          tval = M[cj];  // raw first element: the map itself
+        } else {
+          if (inf & 1) tval = (ci == cj) ? T(1) : T(0);
+          T acc = M[0] * shfl_t(tval, 0 * 7 + cj);
 #pragma unroll
-        for (int k = 1; k < 7; ++k) acc = t_fma(M[k], shfl_t(tval, k * 7 + cj), acc);
-        tval = acc;
-        if ((inf & 2) && lane < 49) s_steps[(inf >> 2) * LYNX_STEP_STRIDE + lane] = tval;
+          for (int k = 1; k < 7; ++k) acc = t_fma(M[k], shfl_t(tval, k * 7 + cj), acc);
+          tval = acc;
+        }
+        if ((inf & 2) && lane < 49) s_steps[(inf >> 3) * LYNX_STEP_STRIDE + lane] = tval;
       }
     }
     __syncthreads();

@@ -33,6 +33,9 @@ struct lynx_ctx {
   size_t scratch_steps_bytes = 0;
   ncclComm_t comm = nullptr;
   int comm_ranks = 0;
+  // per-launch profiling of k_track (lynx_profile_begin / _end)
+  bool profiling = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
 };
 
 struct lynx_lattice {
@@ -203,6 +206,33 @@ int lynx_timer_stop(lynx_ctx* ctx, float* elapsed_ms) {
   HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
   HIP_TRY(ctx, hipEventSynchronize(ctx->ev_stop));
   HIP_TRY(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev_start, ctx->ev_stop));
+  return LYNX_OK;
+}
+
+int lynx_profile_begin(lynx_ctx* ctx) {
+  for (auto& pr : ctx->prof_events) {
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
+  ctx->prof_events.clear();
+  ctx->profiling = true;
+  return LYNX_OK;
+}
+
+int lynx_profile_end(lynx_ctx* ctx, double* total_ms, int64_t* launches) {
+  ctx->profiling = false;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  double total = 0.0;
+  for (auto& pr : ctx->prof_events) {
+    float ms = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, pr.first, pr.second));
+    total += ms;
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
+  *total_ms = total;
+  *launches = (int64_t)ctx->prof_events.size();
+  ctx->prof_events.clear();
   return LYNX_OK;
 }
 
@@ -451,10 +481,20 @@ static int launch_track_inst(lynx_ctx* ctx, const TrackPlan& p, const LatticeDev
                              double* d_partials) {
   int rc = allow_lds(ctx, k_track<T, PPT, VEC, MOMENTS>, p.lds);
   if (rc) return rc;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (ctx->profiling) {
+    HIP_TRY(ctx, hipEventCreate(&e0));
+    HIP_TRY(ctx, hipEventCreate(&e1));
+    HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+  }
   hipLaunchKernelGGL((k_track<T, PPT, VEC, MOMENTS>), dim3(p.grid), dim3(kTrackThreads), p.lds, ctx->stream, lv,
                      p.a, (const T*)d_energy_in, (const T*)d_p_in, (T*)d_p_out, (T*)d_energy_out,
                      (const T*)d_steps, d_partials);
   HIP_TRY(ctx, hipGetLastError());
+  if (ctx->profiling) {
+    HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+    ctx->prof_events.emplace_back(e0, e1);
+  }
   return LYNX_OK;
 }
 

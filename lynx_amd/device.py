@@ -8,6 +8,7 @@ One process drives one GPU (the multi-GPU model is one process per GPU, see
 
 from __future__ import annotations
 
+import atexit
 import ctypes as C
 import os
 import weakref
@@ -41,7 +42,14 @@ class Runtime:
         _ffi.check(self.lib.lynx_ctx_create(int(device), C.byref(handle)))
         self.ctx = handle
         self.device = int(device)
-        self._finalizer = weakref.finalize(self, self.lib.lynx_ctx_destroy, handle)
+        self.closed = False
+        atexit.register(self.close)
+
+    def close(self):
+        """Destroy the context.  Later frees of arrays/lattices that outlive it are no-ops."""
+        if not self.closed:
+            self.closed = True
+            self.lib.lynx_ctx_destroy(self.ctx)
 
     # -- plumbing -------------------------------------------------------------------------
     def check(self, status: int):
@@ -64,13 +72,23 @@ class Runtime:
         self.check(self.lib.lynx_timer_stop(self.ctx, C.byref(ms)))
         return float(ms.value)
 
+    def profile_begin(self):
+        self.check(self.lib.lynx_profile_begin(self.ctx))
+
+    def profile_end(self):
+        """(total milliseconds, launches) of the streaming kernel since profile_begin()."""
+        ms, n = C.c_double(), C.c_int64()
+        self.check(self.lib.lynx_profile_end(self.ctx, C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
+
     def alloc(self, nbytes: int) -> int:
         ptr = C.c_void_p()
         self.check(self.lib.lynx_buf_alloc(self.ctx, int(nbytes), C.byref(ptr)))
         return ptr.value
 
     def free(self, ptr: int):
-        self.lib.lynx_buf_free(self.ctx, C.c_void_p(ptr))
+        if not self.closed:
+            self.lib.lynx_buf_free(self.ctx, C.c_void_p(ptr))
 
     # -- arrays ---------------------------------------------------------------------------
     def empty(self, shape, dtype) -> "DeviceArray":

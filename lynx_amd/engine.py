@@ -34,6 +34,7 @@ class Program:
 
     leaves: list = field(default_factory=list)  # leaf elements in lattice order
     steps: list = field(default_factory=list)   # (kind, first, last) over `leaves`
+    raw: bool = False  # runs take their first map as is (Element.track), see LYNX_STEP_FLAG_RAW
 
     def add_run_element(self, element, new_run: bool):
         idx = len(self.leaves)
@@ -148,6 +149,8 @@ class PackedLattice:
         self.has_cavity_step = any(k == _ffi.STEP_CAVITY for k, _, _ in program.steps)
         self.handle = None
         self.rt = None
+        self._static = None
+        self._has_cavity = False
 
     # whole-batch predicates -----------------------------------------------------------------
     def evaluate_flags(self, energy_host):
@@ -156,8 +159,14 @@ class PackedLattice:
         of the beam energy.  Returns (elem_flags, step_flags).
         """
         leaves = self.program.leaves
-        elem_flags = [el._static_flags() for el in leaves]
-        step_flags = [0] * self.S
+        if self._static is None:  # element versions are part of the cache key: these cannot change
+            self._static = [el._static_flags() for el in leaves]
+            self._has_cavity = any(el._kind == _ffi.KIND_CAVITY for el in leaves)
+        base = _ffi.STEP_FLAG_RAW if self.program.raw else 0
+        if not self._has_cavity:
+            return self._static, [base] * self.S
+        elem_flags = list(self._static)
+        step_flags = [base] * self.S
         energy = np.broadcast_to(np.asarray(energy_host, dtype=self.dtype), self.batch_shape)
         for s, (kind, first, last) in enumerate(self.program.steps):
             for e in range(first, last):
@@ -206,7 +215,8 @@ class PackedLattice:
 
     def release(self):
         if self.handle is not None:
-            self.rt.lib.lynx_lattice_destroy(self.handle)
+            if not self.rt.closed:
+                self.rt.lib.lynx_lattice_destroy(self.handle)
             self.handle = None
 
     def __del__(self):
@@ -225,7 +235,7 @@ class LatticeCache:
 
     def get(self, program: Program, batch_shape, dtype) -> PackedLattice:
         key = (tuple((id(el), el._version) for el in program.leaves),
-               tuple(tuple(s) for s in program.steps), tuple(batch_shape), np.dtype(dtype).str)
+               tuple(tuple(s) for s in program.steps), tuple(batch_shape), np.dtype(dtype).str, program.raw)
         hit = self.entries.get(key)
         if hit is None:
             if len(self.entries) >= self.capacity:
@@ -299,8 +309,8 @@ def run_program_parameters(cache, program: Program, beam):
     return out
 
 
-def track(owner, elements, incoming):
-    """`Segment.track` / `Element.track` for both beam types."""
+def track(owner, elements, incoming, raw: bool = False):
+    """`Segment.track` (raw=False) / `Element.track` (raw=True) for both beam types."""
     from .particles.beam import Beam
     from .particles.parameter_beam import ParameterBeam
     from .particles.particle_beam import ParticleBeam
@@ -316,6 +326,7 @@ def track(owner, elements, incoming):
     beam = incoming
     for item in partition(elements):
         if isinstance(item, Program):
+            item.raw = raw
             if isinstance(beam, ParticleBeam):
                 beam = run_program_particles(cache, item, beam)
             else:
@@ -326,7 +337,7 @@ def track(owner, elements, incoming):
     return beam
 
 
-def transfer_map(owner, elements, energy, dtype) -> np.ndarray:
+def transfer_map(owner, elements, energy, dtype, raw: bool = False) -> np.ndarray:
     """`transfer_map(energy)` of a skippable element list -> host array (*batch, 7, 7)."""
     rt = get_runtime()
     dtype = np.dtype(dtype)
@@ -340,6 +351,7 @@ def transfer_map(owner, elements, energy, dtype) -> np.ndarray:
     assert len(items) == 1 and isinstance(items[0], Program) and len(items[0].steps) == 1, (
         "transfer_map needs a skippable element list")
     program = items[0]
+    program.raw = raw
     cache = owner.__dict__.setdefault("_lattice_cache", LatticeCache())
     lat = _ready(cache, program, batch_shape, dtype, energy)
     e_in = rt.to_device(np.ascontiguousarray(energy))
@@ -354,7 +366,7 @@ def cavity_rmatrix(cavity, energy, dtype) -> np.ndarray:
     rt = get_runtime()
     dtype = np.dtype(dtype)
     energy = np.asarray(energy, dtype=dtype)
-    program = Program()
+    program = Program(raw=True)
     program.add_run_element(cavity, True)
     cache = cavity.__dict__.setdefault("_lattice_cache", LatticeCache())
     lat = _ready(cache, program, energy.shape, dtype, energy)

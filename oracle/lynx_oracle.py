@@ -744,7 +744,14 @@ def segment_track(elements, beam, dtype=np.float32, bpm_readings=None):
 
 
 def element_track(spec, beam, dtype=np.float32):
-    """`element.track(beam)` for one element (element.py:61-94, cavity.py:81-95)."""
+    """
+    `element.track(beam)` for one element (element.py:61-94, cavity.py:81-95): the
+    element's own map is applied directly, without `Segment.transfer_map`'s product with
+    eye(7) (which only matters for signed zeros and NaN spreading).
+    """
+    dtype = np.dtype(dtype)
+    if is_skippable(spec):
+        return _apply_map(element_transfer_map(spec, beam["energy"], dtype), beam)
     return segment_track([spec], beam, dtype)
 
 

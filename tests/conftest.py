@@ -1,0 +1,56 @@
+import ctypes
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _gpu_count() -> int:
+    lib = ROOT / "lynx_amd" / "_lib" / "liblynxhip.so"
+    if not lib.exists():
+        return 0
+    try:
+        from lynx_amd import _ffi
+
+        n = ctypes.c_int(0)
+        _ffi.load().lynx_device_count(ctypes.byref(n))
+        return n.value
+    except Exception:
+        return 0
+
+
+@pytest.fixture(scope="session")
+def built_library():
+    """liblynxhip.so, built on demand (hipcc cross-compiles gfx950 without a GPU)."""
+    lib = ROOT / "lynx_amd" / "_lib" / "liblynxhip.so"
+    if not lib.exists():
+        subprocess.run(["bash", str(ROOT / "lynx_amd" / "csrc" / "build.sh")], check=True)
+    return lib
+
+
+@pytest.fixture(scope="session")
+def host_harness():
+    """tests/harness/libhostcheck.so: the kernels' map-builder source compiled for the host."""
+    so = ROOT / "tests" / "harness" / "libhostcheck.so"
+    src = ROOT / "tests" / "harness" / "host_check.cpp"
+    hdr = ROOT / "lynx_amd" / "csrc" / "lynx_maps.hpp"
+    if not so.exists() or so.stat().st_mtime < max(src.stat().st_mtime, hdr.stat().st_mtime):
+        subprocess.run(["bash", str(ROOT / "tests" / "harness" / "build.sh")], check=True)
+    return ctypes.CDLL(str(so))
+
+
+def pytest_collection_modifyitems(config, items):
+    """`-m gpu` on a box without a GPU must fail loudly, not pass by skipping."""
+    if any("gpu" in item.keywords for item in items) and config.getoption("-m") == "gpu":
+        if _gpu_count() == 0:
+            raise pytest.UsageError("-m gpu requested but liblynxhip sees no GPU (or is not built)")

@@ -1,0 +1,26 @@
+// TEST INFRASTRUCTURE ONLY -- not part of lynx_amd, never loaded by it.
+//
+// Compiles the kernels' map-builder source (lynx_amd/csrc/lynx_maps.hpp) for the host so
+// that the CPU-only test suite can check the arithmetic the GPU will run against the
+// oracle before any GPU time is spent.  The shipped library has no host path.
+#include "../../lynx_amd/csrc/lynx_maps.hpp"
+
+template <typename T>
+static void build(int kind, int flags, const T* p, T energy, T* M, T* coef, int want_coef) {
+  lynx::build_element<T>(kind, flags, p, energy, M, want_coef ? coef : nullptr);
+}
+
+extern "C" {
+void harness_build_f32(int kind, int flags, const float* p, float energy, float* M, float* coef, int want_coef) {
+  build<float>(kind, flags, p, energy, M, coef, want_coef);
+}
+void harness_build_f64(int kind, int flags, const double* p, double energy, double* M, double* coef, int want_coef) {
+  build<double>(kind, flags, p, energy, M, coef, want_coef);
+}
+void harness_kick_f32(const float* coef, float s_in, float d_in, float* s_io, float* d_out) {
+  lynx::cavity_kick<float>(coef, s_in, d_in, *s_io, *d_out);
+}
+void harness_kick_f64(const double* coef, double s_in, double d_in, double* s_io, double* d_out) {
+  lynx::cavity_kick<double>(coef, s_in, d_in, *s_io, *d_out);
+}
+}

@@ -1,0 +1,71 @@
+"""Shared test helpers: one lattice description -> (lynx_amd elements, oracle specs)."""
+
+import ctypes as C
+
+import numpy as np
+
+from oracle import lynx_oracle as o
+
+
+def make_lattice(desc, dtype, lx=None):
+    """
+    desc: list of (kind, kwargs) with array-valued kwargs.  Returns (elements, specs);
+    `elements` is None when the product package is not wanted (lx=None).
+    """
+    ctor_o = {"drift": o.Drift, "quadrupole": o.Quadrupole, "dipole": o.Dipole, "rbend": o.RBend,
+              "hcor": o.HorizontalCorrector, "vcor": o.VerticalCorrector, "cavity": o.Cavity,
+              "custom": o.CustomTransferMap, "bpm": o.BPM, "marker": o.Marker}
+    specs, elements = [], []
+    for kind, kw in desc:
+        kw_t = {k: (np.asarray(v, dtype=dtype) if isinstance(v, (np.ndarray, list, float)) else v)
+                for k, v in kw.items()}
+        specs.append(ctor_o[kind](**kw_t))
+        if lx is not None:
+            ctor_x = {"drift": lx.Drift, "quadrupole": lx.Quadrupole, "dipole": lx.Dipole, "rbend": lx.RBend,
+                      "hcor": lx.HorizontalCorrector, "vcor": lx.VerticalCorrector, "cavity": lx.Cavity,
+                      "custom": lx.CustomTransferMap, "bpm": lx.BPM, "marker": lx.Marker}
+            if kind in ("bpm", "marker"):
+                elements.append(ctor_x[kind](**kw_t))
+            else:
+                elements.append(ctor_x[kind](**kw_t, dtype=dtype))
+    return (elements if lx is not None else None), specs
+
+
+def rel_err(got, ref):
+    """max |got-ref| / max|ref| per trailing coordinate (robust to zeros), NaN-aware."""
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    nan_g, nan_r = np.isnan(got), np.isnan(ref)
+    assert np.array_equal(nan_g, nan_r), "NaN pattern differs"
+    g, r = np.where(nan_g, 0.0, got), np.where(nan_r, 0.0, ref)
+    scale = np.max(np.abs(r)) + 1e-300
+    return float(np.max(np.abs(g - r)) / scale)
+
+
+def map_err(got, ref):
+    """
+    Error of a 7x7 map (or a batch of them) entry-wise relative to the largest entry of its
+    2x2-block row: maps hold entries of very different magnitude (R56 ~ 1e-6 next to 1).
+    """
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape
+    nan_g, nan_r = np.isnan(got), np.isnan(ref)
+    assert np.array_equal(nan_g, nan_r), "NaN pattern differs"
+    g, r = np.where(nan_g, 0.0, got), np.where(nan_r, 0.0, ref)
+    denom = np.maximum(np.abs(r), 1e-3 * np.max(np.abs(r), axis=(-1, -2), keepdims=True)) + 1e-300
+    return float(np.max(np.abs(g - r) / denom))
+
+
+def harness_map(h, kind, flags, params, energy, dtype, want_coef=False):
+    dtype = np.dtype(dtype)
+    ct = C.c_float if dtype == np.float32 else C.c_double
+    fn = h.harness_build_f32 if dtype == np.float32 else h.harness_build_f64
+    fn.argtypes = [C.c_int, C.c_int, C.c_void_p, ct, C.c_void_p, C.c_void_p, C.c_int]
+    fn.restype = None
+    p = np.ascontiguousarray(np.asarray(params, dtype=dtype))
+    if p.size == 0:
+        p = np.zeros(1, dtype=dtype)
+    M = np.zeros(49, dtype=dtype)
+    coef = np.zeros(8, dtype=dtype)
+    fn(kind, flags, p.ctypes.data, ct(float(energy)), M.ctypes.data, coef.ctypes.data, int(want_coef))
+    return M.reshape(7, 7), coef

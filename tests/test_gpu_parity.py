@@ -1,0 +1,544 @@
+"""
+Parity of the HIP path (through the C ABI, via the lynx_amd Python layer) with the oracle.
+
+Tolerances (north_star: 1e-6 rel fp64 / 1e-4 rel fp32 on beam moments; "bit-exact for
+indexing"): maps and particles are compared relative to the scale of the quantity,
+fp32 <= 1e-4 (observed ~1e-6), fp64 <= 1e-10 (observed ~1e-14).  Index placement is checked
+exactly through maps whose every entry is distinct.
+"""
+
+import numpy as np
+import pytest
+
+from oracle import lynx_oracle as o
+
+from .helpers import make_lattice, map_err, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL_MAP = {np.float32: 5e-5, np.float64: 1e-11}
+TOL_P = {np.float32: 1e-4, np.float64: 1e-10}
+TOL_MOM = {np.float32: 1e-4, np.float64: 1e-6}
+
+
+@pytest.fixture(scope="module")
+def lx(built_library):
+    import lynx_amd
+
+    lynx_amd.device.get_runtime()  # raises loudly without a GPU
+    return lynx_amd
+
+
+def _particle_case(lx, desc, dtype, batch_shape, n, seed, energy=1e8, sigma=None, ddof=1):
+    dtype = np.dtype(dtype).type
+    elements, specs = make_lattice(desc, dtype, lx)
+    P = o.gaussian_particles(batch_shape, n, seed=seed, dtype=dtype,
+                             sigma=sigma or [1e-4, 1e-5, 1e-4, 1e-5, 1e-5, 1e-3])
+    e = np.full(batch_shape, energy, dtype=dtype)
+    out = lx.Segment(elements).track(lx.ParticleBeam(P, e, dtype=dtype))
+    ref = o.segment_track(specs, o.particle_beam(P, e, dtype), dtype)
+    return out, ref
+
+
+def _assert_particles(out, ref, dtype):
+    got = np.asarray(out.particles)
+    assert got.shape == ref["particles"].shape
+    for c in range(7):
+        err = rel_err(got[..., c], ref["particles"][..., c])
+        assert err < TOL_P[dtype], (c, err)
+    assert rel_err(out.energy, ref["energy"]) < 1e-6
+
+
+def _assert_moments(out, ref, dtype):
+    m = o.beam_moments(ref, ddof=1)
+    for key in ("mu_x", "mu_xp", "mu_y", "mu_yp", "mu_s", "mu_p"):
+        sig = m["sigma" + key[2:]]
+        assert np.all(np.abs(getattr(out, key) - m[key]) <= TOL_MOM[dtype] * (np.abs(m[key]) + sig)), key
+    for key in ("sigma_x", "sigma_xp", "sigma_y", "sigma_yp", "sigma_s", "sigma_p"):
+        assert np.allclose(getattr(out, key), m[key], rtol=TOL_MOM[dtype], atol=0), key
+    for key, a, b in (("sigma_xxp", "sigma_x", "sigma_xp"), ("sigma_yyp", "sigma_y", "sigma_yp")):
+        assert np.all(np.abs(getattr(out, key) - m[key]) <= TOL_MOM[dtype] * m[a] * m[b]), key
+
+
+# ---------------------------------------------------------------------------------------------
+# maps
+# ---------------------------------------------------------------------------------------------
+
+ELEMENT_CASES = [
+    ("drift", dict(length=[0.3, 1.0, 0.0])),
+    ("hcor", dict(length=[0.3, 0.1, 0.2], angle=[1e-4, 0.0, -2e-3])),
+    ("vcor", dict(length=[0.3, 0.1, 0.2], angle=[3.142e-3, 0.0, -2e-3])),
+    ("quadrupole", dict(length=[0.2, 0.1, 0.3], k1=[4.2, -4.2, 0.0])),
+    ("quadrupole", dict(length=[0.5, 0.5, 0.5], k1=[1.0, 1.0, 1.0], tilt=[np.pi / 4, np.pi / 2, 0.0])),
+    ("quadrupole", dict(length=[1.0, 1.0, 1.0], k1=[1.0, -2.0, 3.0],
+                        misalignment=[[0.1, 0.1], [0.0, 0.0], [-1e-3, 2e-3]], tilt=[0.0, 0.3, 0.0])),
+    ("dipole", dict(length=[0.5, 0.5, 1.0], angle=[0.1, 0.2, 0.0])),
+    ("dipole", dict(length=[0.5, 0.0, 1.0], angle=[0.1, 0.01, -0.3], e1=[0.05, 0.0, 0.1], e2=[0.02, 0.0, -0.1],
+                    tilt=[0.0, 0.2, np.pi / 2], fringe_integral=[0.3, 0.0, 0.5], gap=[0.02, 0.0, 0.03])),
+    ("dipole", dict(length=[0.0, 0.0, 0.0], angle=[0.1, 0.01, -0.3])),
+    ("rbend", dict(length=[0.5, 0.4, 1.0], angle=[0.1, 0.01, -0.3], e1=[0.0, 0.01, 0.0],
+                   fringe_integral=[0.3, 0.0, 0.5], fringe_integral_exit=[0.1, 0.2, 0.5], gap=[0.02, 0.0, 0.03])),
+    ("cavity", dict(length=[1.0377, 3.0441, 1.0], voltage=[0.01815975e9, 48198468.0, 1e6],
+                    phase=[0.0, 30.0, -10.0], frequency=[1.3e9, 2.856e9, 1.3e9])),
+    ("cavity", dict(length=[1.0, 1.0, 1.0], voltage=[0.0, 0.0, 0.0], phase=[0.0, 1.0, 2.0],
+                    frequency=[1.3e9, 1.3e9, 1.3e9])),
+    ("marker", dict()),
+    ("bpm", dict()),
+]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("case", range(len(ELEMENT_CASES)))
+def test_element_transfer_map(lx, case, dtype):
+    kind, kw = ELEMENT_CASES[case]
+    elements, specs = make_lattice([(kind, kw)], dtype, lx)
+    energy = np.array([1e8, 6e6, 1.0732e8], dtype=dtype)
+    got = elements[0].transfer_map(energy)
+    ref = o.element_transfer_map(specs[0], energy, dtype)
+    assert got.shape == (3, 7, 7)
+    tol = TOL_MAP[dtype] * (10 if kind in ("dipole", "rbend", "cavity") else 1)
+    assert map_err(got, ref) < tol, (kind, map_err(got, ref))
+
+
+def test_custom_transfer_map_index_placement_is_exact(lx):
+    """Every one of the 49 entries distinct: catches any row/column/transposition mix-up."""
+    tm = (np.arange(49, dtype=np.float64).reshape(1, 7, 7) + 1) / 64.0
+    el = lx.CustomTransferMap(tm, dtype=np.float64)
+    assert np.array_equal(el.transfer_map(np.array([1e8])), tm)
+    seg = lx.Segment([el])
+    assert np.array_equal(seg.transfer_map(np.array([1e8])), tm)  # tm @ I is exact
+    P = np.zeros((1, 7, 7))
+    P[0] = np.eye(7)  # unit vectors: row n of the output is column n of tm
+    out = seg.track(lx.ParticleBeam(P, np.array([1e8]), dtype=np.float64))
+    assert np.array_equal(np.asarray(out.particles)[0], tm[0].T)
+
+
+def test_kat3_custom_map_broadcast(lx):
+    """reference tests/test_vectorized.py:371-392"""
+    tm = np.array([[[1.0, 4.0e-02, 0, 0, 0, 0, 0], [0, 1.0, 0, 0, 0, 0, 1.0e-05], [0, 0, 1.0, 4.0e-02, 0, 0, 0],
+                    [0, 0, 0, 1.0, 0, 0, 0], [0, 0, 0, 0, 1.0, -4.6422e-07, 0], [0, 0, 0, 0, 0, 1.0, 0],
+                    [0, 0, 0, 0, 0, 0, 1.0]]], dtype=np.float32)
+    element = lx.CustomTransferMap(length=np.array([0.4]), transfer_map=tm)
+    b = element.broadcast((3, 10))
+    assert b.length.shape == (3, 10) and b._transfer_map.shape == (3, 10, 7, 7)
+    got = b.transfer_map(np.full((3, 10), 1e8, dtype=np.float32))
+    for i in range(3):
+        for j in range(10):
+            assert np.all(got[i, j] == tm[0])
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_kat2_composition_of_1051_maps(lx, dtype):
+    """docs/examples/optimize_speed.ipynb:47-67, printed result :270 (fp32 torch, 5 digits)."""
+    cell = [("quadrupole", dict(length=[0.1], k1=[4.2])), ("drift", dict(length=[0.2])),
+            ("quadrupole", dict(length=[0.1], k1=[-4.2])), ("drift", dict(length=[0.2])), ("marker", dict()),
+            ("quadrupole", dict(length=[0.1], k1=[0.0])), ("drift", dict(length=[0.2]))]
+    desc = [("drift", dict(length=[0.3]))] + cell * 150
+    elements, specs = make_lattice(desc, dtype, lx)
+    energy = np.array([107315902.44394557], dtype=dtype)
+    seg = lx.Segment(elements)
+    got = seg.transfer_map(energy)
+    ref = o.segment_transfer_map(specs, energy, dtype)
+    assert map_err(got, ref) < (2e-4 if dtype == np.float32 else 1e-10)
+    printed = {(0, 0): 1.3122, (0, 1): -3.4577, (1, 0): 0.18828, (1, 1): 0.26594, (2, 2): 0.30360,
+               (2, 3): -3.2559, (3, 2): 0.18828, (3, 3): 1.2746, (4, 5): -3.0678e-3}
+    for (i, j), v in printed.items():
+        assert abs(got[0, i, j] - v) < 3e-4 * max(1.0, abs(v)) if (i, j) != (4, 5) else abs(got[0, i, j] - v) < 1e-6
+    assert abs(float(seg.length[0]) - 135.2991) < 1e-3
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_segment_transfer_map_batched_fodo(lx, dtype):
+    B = 5
+    scale = np.linspace(0.5, 1.5, B)
+    f = lambda v: np.full(B, v)  # noqa: E731
+    desc = []
+    for _ in range(32):
+        desc += [("quadrupole", dict(length=f(0.2), k1=4.2 * scale)), ("drift", dict(length=f(0.5))),
+                 ("quadrupole", dict(length=f(0.2), k1=-4.2 * scale)), ("drift", dict(length=f(0.5)))]
+    elements, specs = make_lattice(desc, dtype, lx)
+    energy = np.full(B, 1e8, dtype=dtype)
+    got = lx.Segment(elements).transfer_map(energy)
+    ref = o.segment_transfer_map(specs, energy, dtype)
+    assert map_err(got, ref) < (5e-4 if dtype == np.float32 else 1e-10)
+
+
+# ---------------------------------------------------------------------------------------------
+# particles
+# ---------------------------------------------------------------------------------------------
+
+ARES = [("bpm", {}), ("drift", dict(length=[1.0])), ("bpm", {}), ("drift", dict(length=[1.0])),
+        ("vcor", dict(length=[0.3], angle=[3.142e-3])), ("drift", dict(length=[0.2])),
+        ("hcor", dict(length=[0.3], angle=[1e-4])), ("drift", dict(length=[7.0])),
+        ("hcor", dict(length=[0.3], angle=[-1e-4])), ("drift", dict(length=[0.05])), ("bpm", {})]
+
+
+@pytest.mark.parametrize("n", [1, 3, 255, 1000, 100_000])
+def test_c2_ares_segment_particles(lx, n):
+    """BASELINE config 2: the 11-element README segment, fp32, B = 1 (and ragged N)."""
+    out, ref = _particle_case(lx, ARES, np.float32, (1,), n, seed=0,
+                              sigma=[175e-9, 2e-7, 175e-9, 2e-7, 1e-6, 1e-6])
+    _assert_particles(out, ref, np.float32)
+    if n >= 1000:
+        _assert_moments(out, ref, np.float32)
+
+
+@pytest.mark.parametrize("dtype,n", [(np.float32, 4096), (np.float32, 4099), (np.float64, 2048), (np.float64, 2047)])
+def test_fodo_scan_particles(lx, dtype, n):
+    """BASELINE configs 3/4 in small: 128-element FODO, k1 scan over the batch; odd N takes
+    the unaligned (scalar-access) kernel variant."""
+    B = 6
+    scale = 0.5 + np.arange(B) / (B - 1)
+    f = lambda v: np.full(B, v)  # noqa: E731
+    desc = []
+    for _ in range(32):
+        desc += [("quadrupole", dict(length=f(0.2), k1=4.2 * scale)), ("drift", dict(length=f(0.5))),
+                 ("quadrupole", dict(length=f(0.2), k1=-4.2 * scale)), ("drift", dict(length=f(0.5)))]
+    out, ref = _particle_case(lx, desc, dtype, (B,), n, seed=2)
+    # the composed fp32 map of 128 elements carries ~1e-5; scale-relative particle tolerance
+    got = np.asarray(out.particles)
+    tol = 1e-3 if dtype == np.float32 else 1e-9
+    for c in range(7):
+        assert rel_err(got[..., c], ref["particles"][..., c]) < tol, c
+    # and exactly consistent with the GPU's own composed map (isolates the streaming kernel)
+    elements, _ = make_lattice(desc, dtype, lx)
+    tm = lx.Segment(elements).transfer_map(np.full(B, 1e8, dtype=dtype))
+    P = o.gaussian_particles((B,), n, seed=2, dtype=dtype, sigma=[1e-4, 1e-5, 1e-4, 1e-5, 1e-5, 1e-3])
+    via_map = np.matmul(P.astype(np.float64), np.swapaxes(tm.astype(np.float64), -1, -2))
+    for c in range(7):
+        assert rel_err(got[..., c], via_map[..., c]) < (2e-6 if dtype == np.float32 else 1e-14), c
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_multidim_batch_and_mixed_elements(lx, dtype):
+    shape = (3, 2)
+    rng = np.random.default_rng(5)
+    f = lambda v: np.full(shape, v)  # noqa: E731
+    desc = [("drift", dict(length=f(0.6))),
+            ("quadrupole", dict(length=f(0.2), k1=rng.uniform(-5, 5, shape), tilt=rng.uniform(-1, 1, shape),
+                                misalignment=rng.normal(0, 1e-4, (*shape, 2)))),
+            ("marker", {}),
+            ("dipole", dict(length=f(0.5), angle=rng.uniform(-0.2, 0.2, shape), e1=f(0.05), e2=f(0.02),
+                            fringe_integral=f(0.4), gap=f(0.02), tilt=f(0.1))),
+            ("hcor", dict(length=f(0.1), angle=rng.normal(0, 1e-4, shape))),
+            ("rbend", dict(length=f(0.3), angle=f(0.05))),
+            ("vcor", dict(length=f(0.1), angle=rng.normal(0, 1e-4, shape))),
+            ("drift", dict(length=f(0.4)))]
+    out, ref = _particle_case(lx, desc, dtype, shape, 3000, seed=11)
+    assert np.asarray(out.particles).shape == (3, 2, 3000, 7)
+    _assert_particles(out, ref, dtype)
+    _assert_moments(out, ref, dtype)
+    assert out.mu_x.shape == shape and out.sigma_p.shape == shape and out.energy.shape == shape
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_c5_cavity_lattice_particles(lx, dtype):
+    """BASELINE config 5 in small: [Drift, misaligned Quad, Drift, Cavity] x 8, E_in = 6 MeV."""
+    B = 4
+    rng = np.random.default_rng(3)
+    f = lambda v: np.full(B, v)  # noqa: E731
+    desc = []
+    for _ in range(8):
+        desc += [("drift", dict(length=f(0.3))),
+                 ("quadrupole", dict(length=f(0.1), k1=rng.uniform(-5, 5, B), misalignment=rng.normal(0, 1e-4, (B, 2)))),
+                 ("drift", dict(length=f(0.3))),
+                 ("cavity", dict(length=f(1.0377), voltage=rng.uniform(5e6, 2e7, B), phase=rng.uniform(-10, 10, B),
+                                 frequency=f(1.3e9)))]
+    out, ref = _particle_case(lx, desc, dtype, (B,), 2500, seed=3, energy=6e6,
+                              sigma=[1e-4, 1e-5, 1e-4, 1e-5, 1e-4, 1e-3])
+    got = np.asarray(out.particles)
+    # delta goes through cos(phi + eps) - cos(phi) in the working precision (cavity.py:150-160):
+    # fp32 agreement is bounded by that cancellation, not by the kernel
+    tol = {np.float32: [2e-4] * 4 + [2e-3, 2e-3, 1e-6], np.float64: [1e-9] * 7}[dtype]
+    for c in range(7):
+        assert rel_err(got[..., c], ref["particles"][..., c]) < tol[c], (c, rel_err(got[..., c], ref["particles"][..., c]))
+    assert rel_err(out.energy, ref["energy"]) < 1e-6
+    assert np.all(out.energy > 6e6)
+
+
+def test_cavity_mixed_zero_voltage_batch_matches_reference_nan(lx):
+    """reference tests/test_vectorized.py:423-439: no error; V = 0 rows carry the reference's NaN."""
+    desc = [("cavity", dict(length=[3.0441] * 3, voltage=[0.0, 48198468.0, 0.0], phase=[48198468.0] * 3,
+                            frequency=[2.8560e09] * 3))]
+    out, ref = _particle_case(lx, desc, np.float32, (3,), 500, seed=1, sigma=[1e-5, 2e-7, 175e-9, 2e-7, 1e-6, 1e-6])
+    got = np.asarray(out.particles)
+    assert np.array_equal(np.isnan(got), np.isnan(ref["particles"]))
+    assert np.isnan(got[0, :, 0]).all() and not np.isnan(got[1]).any()
+
+
+# ---------------------------------------------------------------------------------------------
+# ParameterBeam
+# ---------------------------------------------------------------------------------------------
+
+
+def test_kat1_parameter_beam_drift(lx):
+    """try_batched.ipynb: from_twiss -> sigma_x etc, then Drift([1, 2])."""
+    beam = lx.ParameterBeam.from_twiss(
+        beta_x=np.array([61.47503078, 99.0]), alpha_x=np.array([-1.21242463, -0.9]),
+        emittance_x=np.array([7.1971891e-13, 5e-13]), beta_y=np.array([35.41897281, 60.0]),
+        alpha_y=np.array([0.66554622, 0.5]), emittance_y=np.array([3.5866484e-15, 1e-15]),
+        energy=np.array([150e6, 14.6e9]))
+    assert np.allclose(beam.sigma_x, [6.6517e-06, 7.0356e-06], rtol=1e-4)
+    assert np.allclose(beam.relativistic_gamma, [293.5427, 28571.4863], rtol=1e-6)
+    out = lx.Drift(length=np.array([1.0, 2.0])).track(beam)
+    assert np.allclose(out.sigma_x, [6.7837e-06, 7.1650e-06], rtol=1e-4)
+    assert np.allclose(out.sigma_y, [3.4987e-07, 2.4100e-07], rtol=1e-4)
+    assert np.allclose(out.sigma_xp, beam.sigma_xp) and np.allclose(out.sigma_yp, beam.sigma_yp)
+
+
+def test_kat4_cavity_bmad_twiss(lx):
+    """reference tests/test_compare_ocelot.py:627-654 (Bmad-confirmed Twiss after the cavity)."""
+    beam = lx.ParameterBeam.from_twiss(
+        beta_x=np.array([5.91253677]), alpha_x=np.array([3.55631308]), emittance_x=np.array([3.494768647122823e-09]),
+        beta_y=np.array([5.91253677]), alpha_y=np.array([3.55631308]), emittance_y=np.array([3.497810737006068e-09]),
+        energy=np.array([6e6]), dtype=np.float64)
+    cavity = lx.Cavity(length=np.array([1.0377]), voltage=np.array([0.01815975e9]), frequency=np.array([1.3e9]),
+                       phase=np.array([0.0]), dtype=np.float64)
+    out = cavity.track(beam)
+    assert np.isclose(out.beta_x, 0.23847352510683092, rtol=1e-6)
+    assert np.isclose(out.alpha_x, -1.0160687592932345, rtol=1e-6)
+    assert np.isclose(out.beta_y, 0.23847352512430994, rtol=1e-6)
+    assert np.isclose(out.alpha_y, -1.0160687593664295, rtol=1e-6)
+    assert np.isclose(out.energy, 6e6 + 0.01815975e9)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_parameter_beam_through_mixed_lattice(lx, dtype):
+    B = 7
+    rng = np.random.default_rng(9)
+    f = lambda v: np.full(B, v)  # noqa: E731
+    desc = [("drift", dict(length=f(0.6))), ("quadrupole", dict(length=f(0.2), k1=rng.uniform(-5, 5, B))),
+            ("cavity", dict(length=f(1.0377), voltage=rng.uniform(5e6, 2e7, B), phase=rng.uniform(-10, 10, B),
+                            frequency=f(1.3e9))),
+            ("drift", dict(length=f(0.4))), ("hcor", dict(length=f(0.1), angle=f(1e-4))),
+            ("cavity", dict(length=f(1.0377), voltage=rng.uniform(5e6, 2e7, B), phase=f(0.0), frequency=f(1.3e9))),
+            ("dipole", dict(length=f(0.5), angle=f(0.1)))]
+    elements, specs = make_lattice(desc, dtype, lx)
+    kw = dict(sigma_x=f(1e-4), sigma_xp=f(1e-5), sigma_y=f(1e-4), sigma_yp=f(1e-5), sigma_s=f(1e-5),
+              sigma_p=f(1e-3), mu_x=rng.normal(0, 1e-4, B), energy=f(6e6))
+    kw = {k: np.asarray(v, dtype=dtype) for k, v in kw.items()}
+    beam = lx.ParameterBeam.from_parameters(**kw, dtype=dtype)
+    ref_in = o.parameter_beam_from_parameters(dtype=dtype, **kw)
+    out = lx.Segment(elements).track(beam)
+    ref = o.segment_track(specs, ref_in, dtype)
+    tol = 2e-3 if dtype == np.float32 else 1e-9
+    assert rel_err(out._mu, ref["mu"]) < tol
+    for i in range(6):
+        for j in range(6):
+            s = np.sqrt(np.abs(ref["cov"][..., i, i] * ref["cov"][..., j, j])) + 1e-300
+            assert np.max(np.abs(out._cov[..., i, j] - ref["cov"][..., i, j]) / s) < tol * 10, (i, j)
+    assert rel_err(out.energy, ref["energy"]) < 1e-6
+
+
+def test_parameter_beam_huge_batch(lx):
+    """reference tests/test_vectorized.py:298-321 in spirit: (3, 100000) settings at once."""
+    shape = (3, 20_000)
+    k1 = np.tile(np.linspace(-30.0, 30.0, shape[1]), (3, 1)).astype(np.float32)
+    seg = lx.Segment([lx.Drift(np.full(shape, 0.2, np.float32)), lx.Quadrupole(np.full(shape, 0.122, np.float32), k1=k1),
+                      lx.Drift(np.full(shape, 0.4, np.float32))])
+    beam = lx.ParameterBeam.from_parameters(sigma_x=np.full(shape, 1e-4, np.float32))
+    out = seg.track(beam)
+    assert out.mu_x.shape == shape and out.sigma_x.shape == shape and out.energy.shape == shape
+    specs = [o.Drift(np.full(shape, 0.2, np.float32)), o.Quadrupole(np.full(shape, 0.122, np.float32), k1=k1),
+             o.Drift(np.full(shape, 0.4, np.float32))]
+    ref = o.segment_track(specs, o.parameter_beam_from_parameters(sigma_x=np.full(shape, 1e-4, np.float32)), np.float32)
+    assert np.allclose(out.sigma_x, o.beam_moments(ref)["sigma_x"], rtol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------
+# moments, kernel variants, invariants
+# ---------------------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_moment_readout_of_existing_beam(lx, dtype):
+    P = o.gaussian_particles((2, 2), 30_001, seed=4, dtype=dtype, mu=[1e-3, -1e-4, 2e-3, 0, 0, 1e-3],
+                             sigma=[1e-6, 1e-7, 2e-6, 1e-7, 1e-5, 1e-4])
+    beam = lx.ParticleBeam(P, np.full((2, 2), 1e8), dtype=dtype)
+    _assert_moments(beam, o.particle_beam(P, np.full((2, 2), 1e8), dtype), dtype)
+    # |mu| >> sigma: a naive fp32 sum of squares would have no correct digit here
+    assert np.allclose(beam.sigma_x, 1e-6, rtol=2e-2)
+
+
+def test_fused_moments_equal_separate_pass(lx):
+    out, _ = _particle_case(lx, ARES, np.float32, (1,), 50_000, seed=0)
+    fused = out.moment_record().copy()
+    again = lx.ParticleBeam(np.asarray(out.particles), out.energy, dtype=np.float32).moment_record()
+    assert np.allclose(fused[..., :28], again[..., :28], rtol=1e-9, atol=1e-30)
+    assert fused[..., 35] == again[..., 35] == 50_000
+
+
+def test_two_kernel_path_is_bit_identical_to_fused(lx):
+    desc = [("drift", dict(length=[0.6] * 3)), ("quadrupole", dict(length=[0.2] * 3, k1=[4.2, -1.0, 0.0])),
+            ("cavity", dict(length=[1.0] * 3, voltage=[1e7] * 3, phase=[5.0] * 3, frequency=[1.3e9] * 3)),
+            ("drift", dict(length=[0.4] * 3))]
+    lx.config.two_kernel = False
+    a, _ = _particle_case(lx, desc, np.float32, (3,), 5000, seed=8, energy=6e6)
+    lx.config.two_kernel = True
+    try:
+        b, _ = _particle_case(lx, desc, np.float32, (3,), 5000, seed=8, energy=6e6)
+    finally:
+        lx.config.two_kernel = False
+    assert np.array_equal(np.asarray(a.particles), np.asarray(b.particles))
+    assert np.array_equal(a.energy, b.energy)
+
+
+def test_relational_invariants_from_the_reference_suite(lx):
+    f = lambda v: np.array([v], dtype=np.float32)  # noqa: E731
+    beam = lx.ParameterBeam.from_parameters(sigma_xp=f(2e-7), sigma_yp=f(2e-7))
+    # tests/test_quadrupole.py:6-22: k1 = 0 quadrupole == drift
+    quad, drift = lx.Quadrupole(length=f(1.0), k1=f(0.0)), lx.Drift(length=f(1.0))
+    assert np.allclose(quad(beam).sigma_x, drift(beam).sigma_x)
+    quad.k1 = f(1.0)
+    assert not np.allclose(quad(beam).sigma_x, drift(beam).sigma_x)
+    # tests/test_dipole.py:6-22: angle = 0 dipole == drift
+    pbeam = lx.ParticleBeam.from_parameters(num_particles=10_000, sigma_xp=f(2e-7), sigma_yp=f(2e-7), seed=0)
+    dip = lx.Dipole(length=f(1.0), angle=f(0.0))
+    assert np.allclose(dip(pbeam).sigma_x, drift(pbeam).sigma_x)
+    dip.angle = f(1.0)
+    assert not np.allclose(dip(pbeam).sigma_x, drift(pbeam).sigma_x)
+    # tests/test_quadrupole.py:77-98: tilt pi/4 == 5pi/4 != pi/2
+    inc = lx.ParticleBeam.from_parameters(num_particles=20_000, energy=f(1e9), mu_x=f(1e-5), seed=1).broadcast((3,))
+    seg = lx.Segment([lx.Quadrupole(length=np.full(3, 0.5, np.float32), k1=np.ones(3, np.float32),
+                                    tilt=np.array([np.pi / 4, np.pi / 2, np.pi * 5 / 4], dtype=np.float32)),
+                      lx.Drift(length=f(0.5)).broadcast((3,))])
+    out = np.asarray(seg(inc).particles)
+    assert np.allclose(out[0], out[2], atol=1e-9) and not np.allclose(out[0], out[1])
+    # tests/test_dipole.py:25-45: equal batch entries -> equal outputs (bit-exact here)
+    seg = lx.Segment([lx.Dipole(length=np.full(3, 0.5, np.float32), angle=np.array([0.1, 0.2, 0.1], np.float32)),
+                      lx.Drift(length=f(0.5)).broadcast((3,))])
+    out = np.asarray(seg(inc).particles)
+    assert np.array_equal(out[0], out[2]) and not np.allclose(out[0], out[1])
+
+
+def test_broadcast_then_track_equals_track(lx):
+    """tests/test_vectorized.py:324-366 (the cavity case uses exact == there too)."""
+    cavity = lx.Cavity(length=np.array([3.0441]), voltage=np.array([48198468.0]), phase=np.array([-0.0]),
+                       frequency=np.array([2.8560e09]), name="k26_2d")
+    incoming = lx.ParameterBeam.from_parameters(sigma_x=np.array([1e-4], np.float32), energy=np.array([1.07e8], np.float32))
+    outgoing = cavity.track(incoming)
+    b_out = cavity.broadcast((3, 10)).track(incoming.broadcast((3, 10)))
+    for i in range(3):
+        for j in range(10):
+            assert np.all(b_out._mu[i, j] == outgoing._mu[0])
+            assert np.all(b_out._cov[i, j] == outgoing._cov[0])
+
+
+def test_merged_maps_equal_unmerged(lx):
+    """tests/test_speed_optimizations.py:6-75,157-184"""
+    f = lambda v: np.array([v], dtype=np.float32)  # noqa: E731
+    incoming = lx.ParameterBeam.from_parameters(sigma_x=f(1e-4), sigma_xp=f(1e-5), energy=f(1.07e8))
+    seg = lx.Segment([lx.Drift(f(0.6)), lx.Quadrupole(f(0.2), k1=f(4.2), name="Q1"), lx.Drift(f(0.4)),
+                      lx.HorizontalCorrector(f(0.1), angle=f(1e-4), name="HCOR_1"), lx.Drift(f(0.4))])
+    merged = seg.transfer_maps_merged(incoming_beam=incoming)
+    assert len(merged.elements) == 1
+    a, b = seg.track(incoming), merged.track(incoming)
+    for key in ("mu_x", "mu_xp", "sigma_x", "sigma_xp", "sigma_y", "sigma_s", "sigma_p", "energy"):
+        assert np.allclose(getattr(a, key), getattr(b, key), rtol=1e-5), key
+    part = seg.transfer_maps_merged(incoming_beam=incoming, except_for=["Q1", "HCOR_1"])
+    assert [type(e).__name__ for e in part.elements] == ["Drift", "Quadrupole", "Drift", "HorizontalCorrector",
+                                                        "CustomTransferMap"]
+    assert np.allclose(seg.elements[2].transfer_map(incoming.energy), part.elements[2].transfer_map(incoming.energy))
+
+
+def test_active_bpm_reads_the_beam_position(lx):
+    """bpm.py:48-58"""
+    f = lambda v: np.array([v], dtype=np.float32)  # noqa: E731
+    seg = lx.Segment([lx.Drift(f(1.0)), lx.HorizontalCorrector(f(0.1), angle=f(1e-3)), lx.Drift(f(1.0)),
+                      lx.BPM(name="my_bpm"), lx.Drift(f(1.0))])
+    for beam in (lx.ParticleBeam.from_parameters(num_particles=20_000, seed=2), lx.ParameterBeam.from_parameters()):
+        seg.my_bpm.is_active = False
+        ref_out = seg.track(beam)
+        assert seg.my_bpm.reading is None
+        seg.my_bpm.is_active = True
+        out = seg.track(beam)
+        assert seg.my_bpm.reading.shape == (2, 1)
+        assert np.isclose(seg.my_bpm.reading[0, 0], 1e-3 * 1.0, rtol=2e-3)  # kick at the corrector's end, then 1 m
+        assert np.allclose(out.mu_x, ref_out.mu_x, rtol=1e-5)
+        seg.my_bpm.reading = None
+
+
+def test_error_conventions(lx):
+    f = lambda v: np.array([v], dtype=np.float32)  # noqa: E731
+    with pytest.raises(TypeError):
+        lx.Drift(f(1.0)).track("not a beam")
+    assert lx.Drift(f(1.0)).track(lx.Beam.empty) is lx.Beam.empty
+    with pytest.raises(AssertionError):  # drift.py:45-47
+        lx.Drift(np.ones(2, np.float32)).transfer_map(np.ones(3, np.float32))
+    with pytest.raises(AssertionError):
+        lx.Segment([lx.Drift(np.ones(2, np.float32))]).track(lx.ParameterBeam.from_parameters(sigma_x=np.ones(3, np.float32)))
+    with pytest.raises(AssertionError):  # particle_beam.py:35-37
+        lx.ParticleBeam(np.ones((1, 10, 6), np.float32), f(1e8))
+    with pytest.raises(AssertionError):  # cavity.py:260
+        lx.Cavity(f(1.0), voltage=f(1e6), frequency=f(1.3e9)).track(lx.ParameterBeam.from_parameters(energy=f(0.0)))
+    # tests/test_tracking_lengthless_elements.py
+    beam_in = lx.ParticleBeam.from_parameters(num_particles=100, seed=0)
+    assert np.allclose(np.asarray(lx.Segment([lx.Marker(name="start")]).track(beam_in).particles), np.asarray(beam_in.particles))
+    lx.Segment([lx.Cavity(f(0.1), voltage=f(1e6), name="C2"), lx.Marker(name="start"),
+                lx.Cavity(f(0.1), voltage=f(1e6), name="C1")]).track(beam_in)
+
+
+# ---------------------------------------------------------------------------------------------
+# full-size properties (BASELINE sizes, checked through size-independent properties)
+# ---------------------------------------------------------------------------------------------
+
+
+def test_c3_size_round_trip_and_map_consistency(lx):
+    """C3: 128-element FODO, 1 M particles, fp64.  track -> track through the inverse map
+    returns the input; output moments == T Sigma T^T of the input moments."""
+    dtype = np.float64
+    f = lambda v: np.array([v])  # noqa: E731
+    elements = []
+    for _ in range(32):
+        elements += [lx.Quadrupole(f(0.2), k1=f(4.2), dtype=dtype), lx.Drift(f(0.5), dtype=dtype),
+                     lx.Quadrupole(f(0.2), k1=f(-4.2), dtype=dtype), lx.Drift(f(0.5), dtype=dtype)]
+    seg = lx.Segment(elements)
+    beam = lx.ParticleBeam.synthetic((1,), 1_000_000, sigma=[1e-4, 1e-5, 1e-4, 1e-5, 1e-5, 1e-3], energy=1e8, seed=1,
+                                     dtype=dtype)
+    out = seg.track(beam)
+    tm = seg.transfer_map(np.array([1e8]))
+    inv = lx.CustomTransferMap(np.linalg.inv(tm), dtype=dtype)
+    back = inv.track(out)
+    a, b = np.asarray(beam.particles), np.asarray(back.particles)
+    assert np.max(np.abs(a - b) / (np.abs(a).max(axis=(0, 1)) + 1e-300)) < 1e-9
+    rec_in, rec_out = beam.moment_record()[0], out.moment_record()[0]
+    cov_in = np.zeros((6, 6))
+    cov_out = np.zeros((6, 6))
+    k = 7
+    for i in range(6):
+        for j in range(i, 6):
+            cov_in[i, j] = cov_in[j, i] = rec_in[k]
+            cov_out[i, j] = cov_out[j, i] = rec_out[k]
+            k += 1
+    pred = tm[0, :6, :6] @ cov_in @ tm[0, :6, :6].T
+    s = np.sqrt(np.outer(np.diag(pred), np.diag(pred)))
+    assert np.max(np.abs(cov_out - pred) / s) < 1e-9
+    assert rec_out[35] == 1_000_000
+
+
+def test_c4_shard_linearity_fp32(lx):
+    """C4 per-GPU shard in small multiples: 32 samples x 100k x 128 elements, fp32.
+    Linearity: track(2 P) == 2 track(P) exactly (power-of-two scaling commutes with fp32
+    rounding), and sample b's result does not depend on its neighbours."""
+    dtype = np.float32
+    B, N = 32, 100_000
+    scale = (0.5 + np.arange(B) / (B - 1)).astype(dtype)
+    f = lambda v: np.full(B, v, dtype=dtype)  # noqa: E731
+    elements = []
+    for _ in range(32):
+        elements += [lx.Quadrupole(f(0.2), k1=4.2 * scale), lx.Drift(f(0.5)), lx.Quadrupole(f(0.2), k1=-4.2 * scale),
+                     lx.Drift(f(0.5))]
+    seg = lx.Segment(elements)
+    beam = lx.ParticleBeam.synthetic((B,), N, sigma=[1e-4, 1e-5, 1e-4, 1e-5, 1e-5, 1e-3], energy=1e8, seed=2, dtype=dtype)
+    out = np.asarray(seg.track(beam).particles)
+    P = np.asarray(beam.particles)
+    P2 = P.copy()
+    P2[..., :6] *= 2  # 7th coordinate multiplies zeros only (no correctors here)
+    out2 = np.asarray(seg.track(lx.ParticleBeam(P2, np.full(B, 1e8, dtype), dtype=dtype)).particles)
+    assert np.array_equal(out2[..., :6], 2 * out[..., :6])
+    # sample 5 alone, through the same lattice row
+    sub = lx.Segment([lx.Quadrupole(np.array([0.2], dtype), k1=4.2 * scale[5:6]) if i % 4 == 0 else
+                      lx.Quadrupole(np.array([0.2], dtype), k1=-4.2 * scale[5:6]) if i % 4 == 2 else
+                      lx.Drift(np.array([0.5], dtype)) for i in range(128)])
+    alone = np.asarray(sub.track(lx.ParticleBeam(P[5:6], np.array([1e8], dtype), dtype=dtype)).particles)
+    assert np.array_equal(alone[0], out[5])
