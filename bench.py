@@ -194,6 +194,14 @@ def main():
         g = np.asarray(gathered)
         assert g.shape == (world, batch, 36) and np.allclose(g[rank], rec.reshape(batch, 36))
 
+    copy_gbs = None
+    if rank == 0 and world == 1:
+        # practical ceiling on this box: plain 16 B/lane device copy of one pass' bytes
+        try:
+            copy_gbs = rt.copy_bandwidth(min(batch * particles * 7 * np.dtype(dtype).itemsize, 4 << 30))
+        except Exception as exc:  # pragma: no cover
+            print(f"copy calibration failed: {exc}", file=sys.stderr)
+
     if rank == 0:
         itemsize = np.dtype(dtype).itemsize
         steps_per_pass = batch * world * particles * n_elements
@@ -221,6 +229,7 @@ def main():
                          "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": kern_s * 1e3, "launches": launches},
             "hbm_gbs_whole_step": alg_bytes * world * args.steps / elapsed / 1e9,
+            "hbm_copy_kernel_gbs": copy_gbs,
             "device": rt.info(),
         }
         if not args.no_cpu_baseline and world == 1:

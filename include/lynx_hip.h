@@ -117,6 +117,10 @@ int lynx_timer_stop(lynx_ctx* ctx, float* elapsed_ms);
 int lynx_profile_begin(lynx_ctx* ctx);
 int lynx_profile_end(lynx_ctx* ctx, double* total_ms, int64_t* launches);
 
+/* Calibration: average time of a plain 16-byte-per-lane copy of `bytes` (read + write),
+ * i.e. the practical HBM ceiling of this GPU for a stream shaped like a tracking pass. */
+int lynx_diag_copy(lynx_ctx* ctx, void* d_dst, const void* d_src, size_t bytes, int repeats, float* avg_ms);
+
 /* ---- device buffers (reference: jax.Array storage behind `ParticleBeam.particles`,
  *      particle_beam.py:24-45; the Python side owns the handles) ----------------------- */
 int lynx_buf_alloc(lynx_ctx* ctx, size_t bytes, void** d_out);

@@ -101,7 +101,7 @@ __device__ void build_compose_sample(const LatticeDev& lat, int64_t b, T energy_
         info = (s << 3) | (raw ? 4 : 0) | ((e == st.last - 1) ? 2 : 0) | ((e == st.first) ? 1 : 0);
       }
       for (int t = 0; t < ne; ++t) {
-        const int inf = __shfl(info, t, 64);
+        const int inf = __builtin_amdgcn_readlane(info, t);  // t is wave-uniform
         const T* M = s_scratch + t * 49 + ci * 7;
         if ((inf & 5) == 5) {
           tval = M[cj];  // raw first element: the map itself
@@ -162,8 +162,8 @@ __device__ __forceinline__ void apply_program(const LatticeDev& lat, const T* s_
 // ---------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(64) void k_build(LatticeDev lat, const T* __restrict__ energy_in,
-                                               T* __restrict__ steps_out,
-                                               T* __restrict__ energy_out) {
+                                               T* __restrict__ steps_out, T* __restrict__ energy_out,
+                                               const T* __restrict__ p_first, int64_t sample_stride) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* s_scratch = reinterpret_cast<T*>(smem_raw);
   T* s_steps = s_scratch + kBuildChunk * 49;
@@ -173,6 +173,16 @@ __global__ __launch_bounds__(64) void k_build(LatticeDev lat, const T* __restric
   for (int i = threadIdx.x; i < lat.n_steps * LYNX_STEP_STRIDE; i += blockDim.x) s_steps[i] = T(0);
   __syncthreads();
   build_compose_sample<T>(lat, b, energy_in[b], s_steps, s_energy, s_scratch);
+  if (p_first && threadIdx.x == 0) {
+    // reference point of the moment sums: this sample's first particle, tracked
+    T z[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) z[i] = p_first[b * sample_stride + i];
+    apply_program<T>(lat, s_steps, z);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) s_steps[LYNX_SHIFT_OFFSET + i] = z[i];
+  }
+  __syncthreads();
   T* dst = steps_out + b * (int64_t)lat.n_steps * LYNX_STEP_STRIDE;
   for (int i = threadIdx.x; i < lat.n_steps * LYNX_STEP_STRIDE; i += blockDim.x) dst[i] = s_steps[i];
   if (energy_out && threadIdx.x == 0) energy_out[b] = s_energy[lat.n_steps];
@@ -208,6 +218,7 @@ struct TrackArgs {
   int32_t fused_build;   // 1: build+compose in the prologue, 0: read steps_in
   int32_t store;         // 1: write p_out
   int32_t lds_tile_scalars;  // size of the tile/scratch region in scalars
+  int32_t interleave;    // direct kernel: 1 = a workgroup takes every `chunks`-th tile
 };
 
 __device__ __forceinline__ float uniform_value(float v) {
@@ -403,24 +414,231 @@ __global__ __launch_bounds__(kTrackThreads) void k_track(
 }
 
 // ---------------------------------------------------------------------------------------
-// k_finalize_moments: partials [B][chunks][36] -> moment records [B][36].
-// One 64-thread workgroup per sample; chunk sums run in a fixed order (deterministic).
+// k_track_direct: streaming kernel without the LDS transpose.
+//
+// Lane l of a wave owns particle (base + l): it loads its 7 scalars straight from HBM with
+// two (fp32: 16 B + 12 B) or four (fp64: 3 x 16 B + 8 B) dword-aligned vector loads.  A wave
+// instruction therefore sweeps a contiguous 64 x 28 B (or 56 B) span, every byte of every
+// 128-B line is consumed by the wave that touched it, and HBM traffic stays at the
+// algorithmic 2 x 7 x sizeof(T) per particle.  There is no barrier in the loop, the map
+// sits in SGPRs (fp32) or is re-read from LDS (fp64), so occupancy -- not a tile pipeline
+// -- hides the memory latency.  UNROLL particles per lane are in flight per iteration.
+//
+// MOM: 0 = no moments, 1 = float64 accumulation per particle, 2 = per-iteration float32
+// partial sums (UNROLL particles, shifted by the sample's reference point) folded into
+// float64 accumulators once per iteration.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_finalize_moments(const double* __restrict__ partials,
-                                                          int chunks, double* __restrict__ out) {
+typedef float lynx_f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float lynx_f32x3u __attribute__((ext_vector_type(3), aligned(4)));
+typedef double lynx_f64x2u __attribute__((ext_vector_type(2), aligned(8)));
+
+// NT = non-temporal hint: the particle stream is touched exactly once per pass.
+template <bool NT, typename V> __device__ __forceinline__ V ld(const V* p) {
+  return NT ? __builtin_nontemporal_load(p) : *p;
+}
+template <bool NT, typename V> __device__ __forceinline__ void st(V* p, V v) {
+  if (NT) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+
+template <bool NT> __device__ __forceinline__ void load_particle(const float* p, float (&z)[7]) {
+  const lynx_f32x4u a = ld<NT>(reinterpret_cast<const lynx_f32x4u*>(p));
+  const lynx_f32x3u b = ld<NT>(reinterpret_cast<const lynx_f32x3u*>(p + 4));
+  z[0] = a.x; z[1] = a.y; z[2] = a.z; z[3] = a.w; z[4] = b.x; z[5] = b.y; z[6] = b.z;
+}
+template <bool NT> __device__ __forceinline__ void store_particle(float* p, const float (&z)[7]) {
+  lynx_f32x4u a = {z[0], z[1], z[2], z[3]};
+  lynx_f32x3u b = {z[4], z[5], z[6]};
+  st<NT>(reinterpret_cast<lynx_f32x4u*>(p), a);
+  st<NT>(reinterpret_cast<lynx_f32x3u*>(p + 4), b);
+}
+template <bool NT> __device__ __forceinline__ void load_particle(const double* p, double (&z)[7]) {
+  const lynx_f64x2u a = ld<NT>(reinterpret_cast<const lynx_f64x2u*>(p));
+  const lynx_f64x2u b = ld<NT>(reinterpret_cast<const lynx_f64x2u*>(p + 2));
+  const lynx_f64x2u c = ld<NT>(reinterpret_cast<const lynx_f64x2u*>(p + 4));
+  z[0] = a.x; z[1] = a.y; z[2] = b.x; z[3] = b.y; z[4] = c.x; z[5] = c.y; z[6] = ld<NT>(p + 6);
+}
+template <bool NT> __device__ __forceinline__ void store_particle(double* p, const double (&z)[7]) {
+  lynx_f64x2u a = {z[0], z[1]}, b = {z[2], z[3]}, c = {z[4], z[5]};
+  st<NT>(reinterpret_cast<lynx_f64x2u*>(p), a);
+  st<NT>(reinterpret_cast<lynx_f64x2u*>(p + 2), b);
+  st<NT>(reinterpret_cast<lynx_f64x2u*>(p + 4), c);
+  st<NT>(p + 6, z[6]);
+}
+
+template <typename T, int MOM, int UNROLL, bool FUSED>
+__global__ __launch_bounds__(kTrackThreads) void k_track_direct(
+    LatticeDev lat, TrackArgs a, const T* __restrict__ energy_in, const T* p_in, T* p_out,
+    T* __restrict__ energy_out, const T* __restrict__ steps_in, double* __restrict__ partials) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* s_scratch = reinterpret_cast<T*>(smem_raw);                   // build scratch / reduction
+  T* s_steps = s_scratch + a.lds_tile_scalars;                     // [S][64]
+  T* s_energy = s_steps + (size_t)lat.n_steps * LYNX_STEP_STRIDE;  // [S+1]
+
+  const int tid = threadIdx.x;
+  const int64_t b = blockIdx.x / a.chunks;
+  const int chunk = blockIdx.x % a.chunks;
+  const int64_t N = a.n_particles;
+  const int S = lat.n_steps;
+  // This workgroup's `a.tiles_per_wg` tiles of 256*UNROLL particles: either one contiguous
+  // stretch, or (a.interleave) every `chunks`-th tile, so that the workgroups of a sample
+  // advance through it side by side.
+  constexpr int64_t kTile = (int64_t)kTrackThreads * UNROLL;
+  const int64_t end = N;
+
+  if (FUSED) {
+    build_compose_sample<T>(lat, b, energy_in[b], s_steps, s_energy, s_scratch);
+    if (energy_out && chunk == 0 && tid == 0) energy_out[b] = s_energy[S];
+  } else if (S > 0) {
+    load_steps_sample<T>(steps_in + b * (int64_t)S * LYNX_STEP_STRIDE, S, s_steps);
+  }
+
+  const bool one_run = (S == 1) && (lat.steps[0].kind == LYNX_STEP_RUN);
+  constexpr bool kMapInRegs = sizeof(T) == 4;
+  T m0[kMapInRegs ? 49 : 1];
+  if (one_run && kMapInRegs) {
+#pragma unroll
+    for (int i = 0; i < 49; ++i) m0[i] = uniform_value(s_steps[i]);
+  }
+
+  MomentAcc<T> acc;
+  T shift[7];
+  if (MOM) {
+    acc.clear();
+    if (!FUSED && S > 0) {
+#pragma unroll
+      for (int i = 0; i < 7; ++i) shift[i] = s_steps[LYNX_SHIFT_OFFSET + i];  // from k_build
+    } else {
+      const T* p0 = p_in + b * N * 7;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) shift[i] = p0[i];
+      apply_program<T>(lat, s_steps, shift);
+    }
+  }
+
+  const T* src = p_in + b * N * 7;
+  T* dst = p_out + b * N * 7;
+  for (int it = 0; it < a.tiles_per_wg; ++it) {
+    const int64_t tile = a.interleave ? ((int64_t)it * a.chunks + chunk) : ((int64_t)chunk * a.tiles_per_wg + it);
+    const int64_t i0 = tile * kTile + tid;
+    if (i0 >= end) break;
+    T z[UNROLL][7];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int64_t i = i0 + (int64_t)u * kTrackThreads;
+      load_particle<false>(src + (i < end ? i : i0) * 7, z[u]);
+    }
+    float f_d[6], f_dd[21], f_one = 0.f;
+    if (MOM == 2) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) f_d[k] = 0.f;
+#pragma unroll
+      for (int k = 0; k < 21; ++k) f_dd[k] = 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int64_t i = i0 + (int64_t)u * kTrackThreads;
+      const bool live = i < end;
+      if (one_run) {
+        if (kMapInRegs) apply_step<T>(m0, LYNX_STEP_RUN, 0, z[u]);
+        else apply_step<T>(s_steps, LYNX_STEP_RUN, 0, z[u]);
+      } else {
+        apply_program<T>(lat, s_steps, z[u]);
+      }
+      if (live) {
+        if (a.store) store_particle<false>(dst + i * 7, z[u]);
+        if (MOM == 1) acc.add(z[u], shift);
+        if (MOM == 2) {
+          float e[6];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) {
+            e[k] = (float)(z[u][k] - shift[k]);
+            f_d[k] += e[k];
+          }
+          f_one += (float)z[u][6];
+          int k = 0;
+#pragma unroll
+          for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = r; c < 6; ++c) {
+              f_dd[k] = fmaf(e[r], e[c], f_dd[k]);
+              ++k;
+            }
+          acc.cnt += 1.0;
+        }
+      }
+    }
+    if (MOM == 2) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) acc.d[k] += (double)f_d[k];
+#pragma unroll
+      for (int k = 0; k < 21; ++k) acc.dd[k] += (double)f_dd[k];
+      acc.one += (double)f_one;
+    }
+  }
+
+  if (MOM) {
+    __syncthreads();  // build scratch is reused as the reduction buffer
+    double* s_red = reinterpret_cast<double*>(s_scratch);  // 4 waves x 29
+    const int wave = tid >> 6, lane = tid & 63;
+#define LYNX_WAVE_SUM(dst_idx, value)                                        \
+    {                                                                          \
+      double v_ = (value);                                                     \
+      for (int off = 32; off >= 1; off >>= 1) v_ += __shfl_xor(v_, off, 64);   \
+      if (lane == 0) s_red[wave * 29 + (dst_idx)] = v_;                        \
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) LYNX_WAVE_SUM(i, acc.d[i]);
+    LYNX_WAVE_SUM(6, acc.one);
+#pragma unroll
+    for (int i = 0; i < 21; ++i) LYNX_WAVE_SUM(7 + i, acc.dd[i]);
+    LYNX_WAVE_SUM(28, acc.cnt);
+#undef LYNX_WAVE_SUM
+    __syncthreads();
+    double* out = partials + ((int64_t)b * a.chunks + chunk) * kPartialStride;
+    if (tid < 29) {
+      double v = s_red[tid] + s_red[29 + tid] + s_red[58 + tid] + s_red[87 + tid];
+      out[tid == 28 ? 35 : tid] = v;
+    } else if (tid >= 32 && tid < 39) {
+      out[28 + (tid - 32)] = (double)shift[tid - 32];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_finalize_moments: partials [B][chunks][36] -> moment records [B][36].
+// One 256-thread workgroup per sample; fixed thread->chunk assignment and reduction tree
+// (deterministic, no float atomics).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_finalize_moments(const double* __restrict__ partials,
+                                                           int chunks, double* __restrict__ out) {
+  __shared__ double s_w[4][kPartialStride];
   __shared__ double s[kPartialStride];
   const int64_t b = blockIdx.x;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const double* src = partials + b * (int64_t)chunks * kPartialStride;
-  if (tid < kPartialStride) {
-    double v;
-    if (tid >= 28 && tid < 35) {
-      v = src[tid];  // shift: identical in every chunk
-    } else {
-      v = 0.0;
-      for (int c = 0; c < chunks; ++c) v += src[(int64_t)c * kPartialStride + tid];
-    }
-    s[tid] = v;
+  // thread t sums chunks t, t+256, ... (fixed assignment and fixed tree => deterministic)
+  double acc[29];
+#pragma unroll
+  for (int j = 0; j < 29; ++j) acc[j] = 0.0;
+  for (int c = tid; c < chunks; c += 256) {
+    const double* row = src + (int64_t)c * kPartialStride;
+#pragma unroll
+    for (int j = 0; j < 28; ++j) acc[j] += row[j];
+    acc[28] += row[35];
+  }
+#pragma unroll
+  for (int j = 0; j < 29; ++j) {
+    double v = acc[j];
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) s_w[wave][j] = v;
+  }
+  __syncthreads();
+  if (tid < 29) {
+    const double v = ((s_w[0][tid] + s_w[1][tid]) + s_w[2][tid]) + s_w[3][tid];
+    s[tid == 28 ? 35 : tid] = v;
+  } else if (tid >= 32 && tid < 39) {
+    s[28 + (tid - 32)] = src[28 + (tid - 32)];  // shift: identical in every chunk
   }
   __syncthreads();
   double* dst = out + b * LYNX_MOMENT_STRIDE;
@@ -518,6 +736,26 @@ __global__ __launch_bounds__(64) void k_track_moments(LatticeDev lat, const T* _
   if (lane < 7) mu_out[b * 7 + lane] = s_mu[lane];
   if (lane < 49) cov_out[b * 49 + lane] = s_cov[lane];
   if (energy_out && lane == 0) energy_out[b] = s_energy[lat.n_steps];
+}
+
+// ---------------------------------------------------------------------------------------
+// k_diag_copy: plain 16-byte grid-stride copy.  Calibration only: what this box sustains for
+// a read+write stream of the same size as a tracking pass (the practical HBM ceiling).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_diag_copy(const lynx_f32x4* __restrict__ src,
+                                                    lynx_f32x4* __restrict__ dst, int64_t n_vec, int vec_per_thread) {
+  // vec_per_thread == 0: grid-stride; > 0: each workgroup copies one contiguous block of
+  // 256 * vec_per_thread vectors, workgroups in linear order
+  if (vec_per_thread == 0) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += stride) dst[i] = src[i];
+  } else {
+    const int64_t base = (int64_t)blockIdx.x * 256 * vec_per_thread + threadIdx.x;
+    for (int k = 0; k < vec_per_thread; ++k) {
+      const int64_t i = base + (int64_t)k * 256;
+      if (i < n_vec) dst[i] = src[i];
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------

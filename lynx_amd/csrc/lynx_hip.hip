@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -413,12 +414,12 @@ static int allow_lds(lynx_ctx* ctx, K kernel, size_t bytes) {
 
 template <typename T>
 static int launch_build(lynx_ctx* ctx, lynx_lattice* lat, const void* d_energy_in, void* d_steps_out,
-                        void* d_energy_out) {
+                        void* d_energy_out, const void* d_p_first = nullptr, int64_t sample_stride = 0) {
   const size_t lds = ((size_t)kBuildChunk * 49 + (size_t)lat->n_steps * LYNX_STEP_STRIDE + lat->n_steps + 1) * sizeof(T);
   int rc = allow_lds(ctx, k_build<T>, lds);
   if (rc) return rc;
   hipLaunchKernelGGL(k_build<T>, dim3((unsigned)lat->batch), dim3(64), lds, ctx->stream, dev_view(lat),
-                     (const T*)d_energy_in, (T*)d_steps_out, (T*)d_energy_out);
+                     (const T*)d_energy_in, (T*)d_steps_out, (T*)d_energy_out, (const T*)d_p_first, sample_stride);
   HIP_TRY(ctx, hipGetLastError());
   return LYNX_OK;
 }
@@ -437,34 +438,72 @@ int lynx_build_compose(lynx_ctx* ctx, lynx_lattice* lat, const void* d_energy_in
 struct TrackPlan {
   int ppt;
   bool vec;
+  bool direct;   // k_track_direct instead of the LDS-tiled k_track
+  int unroll;    // direct: particles per lane and iteration
+  int mom_mode;  // direct: 1 = float64 per particle, 2 = float32 partial sums per iteration
   TrackArgs a;
   size_t lds;
   unsigned grid;
 };
 
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+
+// Tuning knobs (environment, read per call; defaults are the measured best):
+//   LYNX_KERNEL=direct|lds   LYNX_UNROLL=1|2|4   LYNX_PPT=1|big   LYNX_MOM=1|2
+//   LYNX_WGS_PER_CU=<n>      workgroups per CU over the whole launch
 template <typename T>
 static TrackPlan plan_track(lynx_ctx* ctx, int64_t B, int64_t N, int32_t S, bool fused, const void* p_in,
                             const void* p_out) {
   TrackPlan p;
-  const int ppt_big = sizeof(T) == 4 ? 4 : 2;
+  const char* kern = getenv("LYNX_KERNEL");
+  p.direct = !(kern && strcmp(kern, "lds") == 0);
   const int64_t cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+  const int64_t target = (int64_t)env_int("LYNX_WGS_PER_CU", 128) * cus;
+  p.mom_mode = env_int("LYNX_MOM", sizeof(T) == 4 ? 2 : 1);
+  if (sizeof(T) == 8 || (p.mom_mode != 1 && p.mom_mode != 2)) p.mom_mode = 1;
+  p.a.n_particles = N;
+  p.a.fused_build = (fused && S > 0) ? 1 : 0;
+  p.a.store = p_out ? 1 : 0;
+  p.a.interleave = env_int("LYNX_INTERLEAVE", 0);
+  int64_t scratch_scalars = (4 * 29 * 8 + sizeof(T) - 1) / sizeof(T);
+  if (fused) scratch_scalars = std::max<int64_t>(scratch_scalars, kBuildChunk * 49);
+  if (p.direct) {
+    int u = env_int("LYNX_UNROLL", sizeof(T) == 4 ? 4 : 2);
+    if (u != 1 && u != 2 && u != 4) u = 2;
+    // small jobs: fewer particles per lane so that more workgroups exist
+    while (u > 1 && B * ((N + 256 * u - 1) / (256 * u)) < 4 * cus) u >>= 1;
+    p.unroll = u;
+    p.ppt = u;
+    p.vec = false;
+    const int64_t tile = 256 * (int64_t)u;
+    const int64_t ntiles = (N + tile - 1) / tile;
+    int64_t chunks = std::max<int64_t>(1, std::min<int64_t>(ntiles, (target + B - 1) / B));
+    int64_t tpw = (ntiles + chunks - 1) / chunks;
+    chunks = (ntiles + tpw - 1) / tpw;
+    p.a.chunks = (int32_t)chunks;
+    p.a.tiles_per_wg = (int32_t)tpw;
+    scratch_scalars = (scratch_scalars + 3) / 4 * 4;
+    p.a.lds_tile_scalars = (int32_t)scratch_scalars;
+    p.lds = ((size_t)scratch_scalars + (size_t)S * LYNX_STEP_STRIDE + S + 1) * sizeof(T);
+    p.grid = (unsigned)(B * chunks);
+    return p;
+  }
+  p.unroll = 0;
+  const int ppt_big = sizeof(T) == 4 ? 4 : 2;
   const int64_t tiles_big = B * ((N + 256 * ppt_big - 1) / (256 * ppt_big));
   p.ppt = tiles_big >= 4 * cus ? ppt_big : 1;  // small jobs: smaller tiles, more workgroups
+  if (env_int("LYNX_PPT", 0) == 1) p.ppt = 1;
   const int64_t tile = 256 * p.ppt;
   const int64_t ntiles = (N + tile - 1) / tile;
-  // aim for ~16 workgroups per CU over the whole launch
-  const int64_t target = 16 * cus;
   int64_t chunks = std::max<int64_t>(1, std::min<int64_t>(ntiles, (target + B - 1) / B));
   int64_t tpw = (ntiles + chunks - 1) / chunks;
   chunks = (ntiles + tpw - 1) / tpw;
-  p.a.n_particles = N;
   p.a.chunks = (int32_t)chunks;
   p.a.tiles_per_wg = (int32_t)tpw;
-  p.a.fused_build = fused ? 1 : 0;
-  p.a.store = p_out ? 1 : 0;
-  int64_t tile_scalars = tile * 7;
-  if (fused) tile_scalars = std::max<int64_t>(tile_scalars, kBuildChunk * 49);
-  tile_scalars = std::max<int64_t>(tile_scalars, (4 * 29 * 8 + sizeof(T) - 1) / sizeof(T));
+  int64_t tile_scalars = std::max<int64_t>(tile * 7, scratch_scalars);
   tile_scalars = (tile_scalars + 3) / 4 * 4;
   p.a.lds_tile_scalars = (int32_t)tile_scalars;
   p.lds = ((size_t)tile_scalars + (size_t)S * LYNX_STEP_STRIDE + S + 1) * sizeof(T);
@@ -498,6 +537,52 @@ static int launch_track_inst(lynx_ctx* ctx, const TrackPlan& p, const LatticeDev
   return LYNX_OK;
 }
 
+template <typename T, int MOM, int UNROLL, bool FUSED>
+static int launch_direct_inst(lynx_ctx* ctx, const TrackPlan& p, const LatticeDev& lv, const void* d_energy_in,
+                              const void* d_p_in, void* d_p_out, void* d_energy_out, const void* d_steps,
+                              double* d_partials) {
+  int rc = allow_lds(ctx, k_track_direct<T, MOM, UNROLL, FUSED>, p.lds);
+  if (rc) return rc;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (ctx->profiling) {
+    HIP_TRY(ctx, hipEventCreate(&e0));
+    HIP_TRY(ctx, hipEventCreate(&e1));
+    HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+  }
+  hipLaunchKernelGGL((k_track_direct<T, MOM, UNROLL, FUSED>), dim3(p.grid), dim3(kTrackThreads), p.lds, ctx->stream, lv,
+                     p.a, (const T*)d_energy_in, (const T*)d_p_in, (T*)d_p_out, (T*)d_energy_out,
+                     (const T*)d_steps, d_partials);
+  HIP_TRY(ctx, hipGetLastError());
+  if (ctx->profiling) {
+    HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+    ctx->prof_events.emplace_back(e0, e1);
+  }
+  return LYNX_OK;
+}
+
+template <typename T>
+static int launch_direct(lynx_ctx* ctx, const TrackPlan& p, const LatticeDev& lv, const void* d_energy_in,
+                         const void* d_p_in, void* d_p_out, void* d_energy_out, const void* d_steps,
+                         double* d_partials, bool moments) {
+  const int mom = moments ? p.mom_mode : 0;
+#define LYNX_D(MOM, U)                                                                                   \
+  return p.a.fused_build ? launch_direct_inst<T, MOM, U, true>(ctx, p, lv, d_energy_in, d_p_in, d_p_out,   \
+                                                               d_energy_out, d_steps, d_partials)          \
+                         : launch_direct_inst<T, MOM, U, false>(ctx, p, lv, d_energy_in, d_p_in, d_p_out,  \
+                                                                d_energy_out, d_steps, d_partials)
+#define LYNX_DU(MOM)                   \
+  switch (p.unroll) {                  \
+    case 1: LYNX_D(MOM, 1);            \
+    case 2: LYNX_D(MOM, 2);            \
+    default: LYNX_D(MOM, 4);           \
+  }
+  if (mom == 0) { LYNX_DU(0) }
+  if (mom == 2) { LYNX_DU(2) }
+  LYNX_DU(1)
+#undef LYNX_DU
+#undef LYNX_D
+}
+
 template <typename T, int PPT_BIG>
 static int launch_track(lynx_ctx* ctx, const TrackPlan& p, const LatticeDev& lv, const void* d_energy_in,
                         const void* d_p_in, void* d_p_out, void* d_energy_out, const void* d_steps,
@@ -520,16 +605,22 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
                              double* d_moments_out, int flags) {
   const int32_t S = lv.n_steps;
   const bool moments = (flags & LYNX_TRACK_MOMENTS) != 0;
-  const bool fused = S > 0 && !(flags & LYNX_TRACK_TWO_KERNEL);
+  // Fused prologue vs separate build launch: every workgroup of a sample rebuilds that
+  // sample's maps in its prologue, which is free when a sample has a few workgroups (large
+  // batches) and wasteful when one sample is spread over hundreds of them (batch ~ 1).
+  TrackPlan p = plan_track<T>(ctx, B, N, S, true, d_p_in, d_p_out);
+  bool fused = S > 0 && !(flags & LYNX_TRACK_TWO_KERNEL) && p.a.chunks <= env_int("LYNX_FUSE_MAX_CHUNKS", 8);
+  if (!fused) p = plan_track<T>(ctx, B, N, S, false, d_p_in, d_p_out);
   const void* d_steps = nullptr;
   int rc;
   if (S > 0 && !fused) {
     const size_t need = (size_t)B * S * LYNX_STEP_STRIDE * sizeof(T);
     if ((rc = ensure_scratch(ctx, &ctx->scratch_steps, &ctx->scratch_steps_bytes, need))) return rc;
-    if ((rc = launch_build<T>(ctx, lat, d_energy_in, ctx->scratch_steps, d_energy_out))) return rc;
+    if ((rc = launch_build<T>(ctx, lat, d_energy_in, ctx->scratch_steps, d_energy_out, moments ? d_p_in : nullptr,
+                              N * 7)))
+      return rc;
     d_steps = ctx->scratch_steps;
   }
-  TrackPlan p = plan_track<T>(ctx, B, N, S, fused, d_p_in, d_p_out);
   if ((int64_t)B * p.a.chunks > 0x7fffffffLL) return fail(ctx, LYNX_ERR_INVALID, "grid too large");
   double* d_partials = nullptr;
   if (moments) {
@@ -537,11 +628,15 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
     if ((rc = ensure_scratch(ctx, &ctx->scratch_partials, &ctx->scratch_partials_bytes, need))) return rc;
     d_partials = (double*)ctx->scratch_partials;
   }
-  rc = launch_track<T, (sizeof(T) == 4 ? 4 : 2)>(ctx, p, lv, d_energy_in, d_p_in, d_p_out,
-                                                 fused ? d_energy_out : nullptr, d_steps, d_partials, moments);
+  if (p.direct)
+    rc = launch_direct<T>(ctx, p, lv, d_energy_in, d_p_in, d_p_out, fused ? d_energy_out : nullptr, d_steps,
+                          d_partials, moments);
+  else
+    rc = launch_track<T, (sizeof(T) == 4 ? 4 : 2)>(ctx, p, lv, d_energy_in, d_p_in, d_p_out,
+                                                   fused ? d_energy_out : nullptr, d_steps, d_partials, moments);
   if (rc) return rc;
   if (moments) {
-    hipLaunchKernelGGL(k_finalize_moments, dim3((unsigned)B), dim3(64), 0, ctx->stream, d_partials, p.a.chunks,
+    hipLaunchKernelGGL(k_finalize_moments, dim3((unsigned)B), dim3(256), 0, ctx->stream, d_partials, p.a.chunks,
                        d_moments_out);
     HIP_TRY(ctx, hipGetLastError());
   }
@@ -626,6 +721,29 @@ int lynx_fill_gaussian(lynx_ctx* ctx, int dtype, int64_t batch, int64_t n_partic
   else
     hipLaunchKernelGGL(k_fill_gaussian<float>, dim3(grid), dim3(256), 0, ctx->stream, (float*)d_p, total, seed, g);
   HIP_TRY(ctx, hipGetLastError());
+  return LYNX_OK;
+}
+
+// ---- diagnostics: practical HBM ceiling ------------------------------------------------------
+
+int lynx_diag_copy(lynx_ctx* ctx, void* d_dst, const void* d_src, size_t bytes, int repeats, float* avg_ms) {
+  if (!ctx || !d_dst || !d_src || bytes % 16 || repeats <= 0) return fail(ctx, LYNX_ERR_INVALID, "bad argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int64_t n_vec = (int64_t)(bytes / 16);
+  const int vpt = env_int("LYNX_COPY_VPT", 4);  // 0 = grid-stride
+  const unsigned grid = vpt > 0 ? (unsigned)((n_vec + 256LL * vpt - 1) / (256LL * vpt))
+                                : (unsigned)std::min<int64_t>((n_vec + 255) / 256, 256 * 16);
+  hipLaunchKernelGGL(k_diag_copy, dim3(grid), dim3(256), 0, ctx->stream, (const lynx_f32x4*)d_src,
+                     (lynx_f32x4*)d_dst, n_vec, vpt);  // warm-up
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+  for (int r = 0; r < repeats; ++r)
+    hipLaunchKernelGGL(k_diag_copy, dim3(grid), dim3(256), 0, ctx->stream, (const lynx_f32x4*)d_src,
+                       (lynx_f32x4*)d_dst, n_vec, vpt);
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+  HIP_TRY(ctx, hipEventSynchronize(ctx->ev_stop));
+  float ms = 0.f;
+  HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
+  *avg_ms = ms / repeats;
   return LYNX_OK;
 }
 

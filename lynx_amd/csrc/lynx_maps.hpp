@@ -14,8 +14,13 @@
 
 #if defined(__HIPCC__)
 #define LYNX_HD __host__ __device__ __forceinline__
+// Out-of-line on the device: the builders run once per workgroup, so what matters is their
+// code size (instruction-cache misses dominated the prologue when everything was inlined:
+// 50-70 KB per kernel against a 64 KB I-cache shared by two CUs), not call overhead.
+#define LYNX_FN __host__ __device__ __noinline__
 #else
 #define LYNX_HD inline
+#define LYNX_FN inline
 #endif
 
 #include "../../include/lynx_hip.h"
@@ -43,6 +48,8 @@ namespace lynx {
 // 49 map entries + 8 cavity coefficients, padded to 64
 #define LYNX_STEP_STRIDE 64
 #define LYNX_COEF_OFFSET 49
+// step 0, slots 57..63: reference point of the moment sums (first particle, tracked)
+#define LYNX_SHIFT_OFFSET 57
 // cavity coefficient slots (lynx/accelerator/cavity.py:141-226)
 #define LYNX_C_DSCALE 0   // E*beta0 / (E_out*beta1)
 #define LYNX_C_DKICK 1    // V*beta0 / (E_out*beta1)
@@ -56,40 +63,38 @@ namespace lynx {
 template <typename T> LYNX_HD T t_sqrt(T x);
 template <> LYNX_HD float t_sqrt<float>(float x) { return sqrtf(x); }
 template <> LYNX_HD double t_sqrt<double>(double x) { return sqrt(x); }
-template <typename T> LYNX_HD T t_sin(T x);
-template <> LYNX_HD float t_sin<float>(float x) { return sinf(x); }
-template <> LYNX_HD double t_sin<double>(double x) { return sin(x); }
-template <typename T> LYNX_HD T t_cos(T x);
-template <> LYNX_HD float t_cos<float>(float x) { return cosf(x); }
-template <> LYNX_HD double t_cos<double>(double x) { return cos(x); }
-template <typename T> LYNX_HD T t_tan(T x);
-template <> LYNX_HD float t_tan<float>(float x) { return tanf(x); }
-template <> LYNX_HD double t_tan<double>(double x) { return tan(x); }
-template <typename T> LYNX_HD T t_sinh(T x);
-template <> LYNX_HD float t_sinh<float>(float x) { return sinhf(x); }
-template <> LYNX_HD double t_sinh<double>(double x) { return sinh(x); }
-template <typename T> LYNX_HD T t_cosh(T x);
-template <> LYNX_HD float t_cosh<float>(float x) { return coshf(x); }
-template <> LYNX_HD double t_cosh<double>(double x) { return cosh(x); }
-template <typename T> LYNX_HD T t_log(T x);
-template <> LYNX_HD float t_log<float>(float x) { return logf(x); }
-template <> LYNX_HD double t_log<double>(double x) { return log(x); }
+template <typename T> LYNX_FN T t_sin(T x);
+template <> LYNX_FN float t_sin<float>(float x) { return sinf(x); }
+template <> LYNX_FN double t_sin<double>(double x) { return sin(x); }
+template <typename T> LYNX_FN T t_cos(T x);
+template <> LYNX_FN float t_cos<float>(float x) { return cosf(x); }
+template <> LYNX_FN double t_cos<double>(double x) { return cos(x); }
+template <typename T> LYNX_FN T t_tan(T x);
+template <> LYNX_FN float t_tan<float>(float x) { return tanf(x); }
+template <> LYNX_FN double t_tan<double>(double x) { return tan(x); }
+template <typename T> LYNX_FN T t_sinh(T x);
+template <> LYNX_FN float t_sinh<float>(float x) { return sinhf(x); }
+template <> LYNX_FN double t_sinh<double>(double x) { return sinh(x); }
+template <typename T> LYNX_FN T t_cosh(T x);
+template <> LYNX_FN float t_cosh<float>(float x) { return coshf(x); }
+template <> LYNX_FN double t_cosh<double>(double x) { return cosh(x); }
+template <typename T> LYNX_FN T t_log(T x);
+template <> LYNX_FN float t_log<float>(float x) { return logf(x); }
+template <> LYNX_FN double t_log<double>(double x) { return log(x); }
 template <typename T> LYNX_HD T t_fma(T a, T b, T c);
 template <> LYNX_HD float t_fma<float>(float a, float b, float c) { return fmaf(a, b, c); }
 template <> LYNX_HD double t_fma<double>(double a, double b, double c) { return fma(a, b, c); }
 
-template <typename T> LYNX_HD void mat_identity(T* M) {
-#pragma unroll
-  for (int i = 0; i < 49; ++i) M[i] = T(0);
-#pragma unroll
-  for (int i = 0; i < 7; ++i) M[i * 8] = T(1);
+template <typename T> LYNX_FN void mat_identity(T* M) {
+#pragma unroll 1
+  for (int i = 0; i < 49; ++i) M[i] = (i % 8 == 0) ? T(1) : T(0);
 }
 
 // cos/sin of complex sqrt(k2)*L, reduced to real arithmetic
 // (lynx/track_methods.py:72-79): k2 > 0 -> cos / sin(aL)/a ; k2 < 0 -> cosh / sinh(aL)/a
 // with a = sqrt(|k2|).  k2 == 0: c = 1, s = s_at_zero (0/0 = NaN for the x plane, `length`
 // for the y plane, track_methods.py:76-77).
-template <typename T> LYNX_HD void cs_of(T k2, T L, T s_at_zero, T& c, T& s) {
+template <typename T> LYNX_FN void cs_of(T k2, T L, T s_at_zero, T& c, T& s) {
   if (k2 > T(0)) {
     T a = t_sqrt(k2);
     T x = a * L;
@@ -108,8 +113,8 @@ template <typename T> LYNX_HD void cs_of(T k2, T L, T s_at_zero, T& c, T& s) {
 
 // In-place  M <- rot(angle) . M   (rotation_matrix: lynx/track_methods.py:14-34).
 // Only rows 0..3 change; term order = ascending k of the dense product.
-template <typename T> LYNX_HD void rot_left(T* M, T cs, T sn) {
-#pragma unroll
+template <typename T> LYNX_FN void rot_left(T* M, T cs, T sn) {
+#pragma unroll 1
   for (int j = 0; j < 7; ++j) {
     LYNX_FORGET();
     T r0 = M[0 * 7 + j], r1 = M[1 * 7 + j], r2 = M[2 * 7 + j], r3 = M[3 * 7 + j];
@@ -121,8 +126,8 @@ template <typename T> LYNX_HD void rot_left(T* M, T cs, T sn) {
 }
 
 // In-place  M <- M . rot(angle).  Only columns 0..3 change.
-template <typename T> LYNX_HD void rot_right(T* M, T cs, T sn) {
-#pragma unroll
+template <typename T> LYNX_FN void rot_right(T* M, T cs, T sn) {
+#pragma unroll 1
   for (int i = 0; i < 7; ++i) {
     LYNX_FORGET();
     T c0 = M[i * 7 + 0], c1 = M[i * 7 + 1], c2 = M[i * 7 + 2], c3 = M[i * 7 + 3];
@@ -134,7 +139,7 @@ template <typename T> LYNX_HD void rot_right(T* M, T cs, T sn) {
 }
 
 // lynx/accelerator/drift.py:44-62 (also the body of both correctors)
-template <typename T> LYNX_HD void build_drift(T L, T energy, T* M) {
+template <typename T> LYNX_FN void build_drift(T L, T energy, T* M) {
   T gamma = energy / T(LYNX_REST_ENERGY);
   T igamma2 = T(0);  // zeros where gamma == 0 (drift.py:53)
   if (gamma != T(0)) igamma2 = T(1) / (gamma * gamma);
@@ -146,7 +151,7 @@ template <typename T> LYNX_HD void build_drift(T L, T energy, T* M) {
 }
 
 // lynx/track_methods.py:37-99 without the tilt rotation (applied by the caller)
-template <typename T> LYNX_HD void build_base_rmatrix(T L, T k1, T hx, T energy, T* M) {
+template <typename T> LYNX_FN void build_base_rmatrix(T L, T k1, T hx, T energy, T* M) {
   T gamma = energy / T(LYNX_REST_ENERGY);
   T igamma2 = T(1);  // ones where gamma == 0 (track_methods.py:61)
   if (gamma != T(0)) igamma2 = T(1) / (gamma * gamma);
@@ -180,7 +185,7 @@ template <typename T> LYNX_HD void build_base_rmatrix(T L, T k1, T hx, T energy,
 }
 
 // lynx/accelerator/quadrupole.py:66-80.  p = [L, k1, tilt, mx, my]
-template <typename T> LYNX_HD void build_quadrupole(const T* p, int flags, T energy, T* M) {
+template <typename T> LYNX_FN void build_quadrupole(const T* p, int flags, T energy, T* M) {
   build_base_rmatrix(p[0], p[1], T(0), energy, M);
   if (flags & LYNX_FLAG_TILT) {  // any(tilt != 0) over the batch (track_methods.py:101-104)
     T tilt = p[2];
@@ -191,7 +196,7 @@ template <typename T> LYNX_HD void build_quadrupole(const T* p, int flags, T ene
   if (flags & LYNX_FLAG_MISALIGNED) {  // not all(misalignment == 0) (quadrupole.py:75-80)
     T mx = p[3], my = p[4];
     // R_exit . R : rows 0 and 2 pick up the constant row 6 (track_methods.py:114-116)
-#pragma unroll
+#pragma unroll 1
     for (int j = 0; j < 7; ++j) {
       LYNX_FORGET();
       T r6 = M[6 * 7 + j];
@@ -199,7 +204,7 @@ template <typename T> LYNX_HD void build_quadrupole(const T* p, int flags, T ene
       M[2 * 7 + j] = t_fma(my, r6, M[2 * 7 + j]);
     }
     // (.) . R_entry : column 6 (track_methods.py:118-120)
-#pragma unroll
+#pragma unroll 1
     for (int i = 0; i < 7; ++i) {
       LYNX_FORGET();
       T acc = M[i * 7 + 0] * (-mx);
@@ -212,7 +217,7 @@ template <typename T> LYNX_HD void build_quadrupole(const T* p, int flags, T ene
 // lynx/accelerator/dipole.py:96-181 (RBend's e1/e2 shift, rbend.py:79-80, is applied by
 // the host when the element is constructed, as in the reference).
 // p = [L, angle, e1, e2, tilt, fint, fintx, gap]
-template <typename T> LYNX_HD void build_dipole(const T* p, int flags, T energy, T* M) {
+template <typename T> LYNX_FN void build_dipole(const T* p, int flags, T energy, T* M) {
   T L = p[0], angle = p[1], e1 = p[2], e2 = p[3], tilt = p[4];
   T fint = p[5], fintx = p[6], gap = p[7];
   T hx = T(0);
@@ -238,14 +243,14 @@ template <typename T> LYNX_HD void build_dipole(const T* p, int flags, T energy,
   T a2 = hx * t_tan(e2);
   T b2 = -hx * t_tan(e2 - phi2);
   // R . R_enter : columns 0 and 2 (dipole.py:136 inner product)
-#pragma unroll
+#pragma unroll 1
   for (int i = 0; i < 7; ++i) {
     LYNX_FORGET();
     M[i * 7 + 0] = t_fma(M[i * 7 + 1], a1, M[i * 7 + 0]);
     M[i * 7 + 2] = t_fma(M[i * 7 + 3], b1, M[i * 7 + 2]);
   }
   // R_exit . (.) : rows 1 and 3
-#pragma unroll
+#pragma unroll 1
   for (int j = 0; j < 7; ++j) {
     LYNX_FORGET();
     M[1 * 7 + j] = a2 * M[0 * 7 + j] + M[1 * 7 + j];
@@ -258,7 +263,7 @@ template <typename T> LYNX_HD void build_dipole(const T* p, int flags, T energy,
 }
 
 // lynx/accelerator/horizontal_corrector.py:52-67 / vertical_corrector.py:52-66. p = [L, angle]
-template <typename T> LYNX_HD void build_corrector(const T* p, bool vertical, T energy, T* M) {
+template <typename T> LYNX_FN void build_corrector(const T* p, bool vertical, T energy, T* M) {
   build_drift(p[0], energy, M);
   M[(vertical ? 3 : 1) * 7 + 6] = p[1];
 }
@@ -266,7 +271,7 @@ template <typename T> LYNX_HD void build_corrector(const T* p, bool vertical, T 
 // lynx/accelerator/cavity.py:248-325 (`_cavity_rmatrix`) plus, when `coef` is non-null,
 // the per-sample coefficients of the non-linear step (cavity.py:97-246, `_track_beam`).
 // p = [L, V, phase_deg, f].  Returns the outgoing energy.
-template <typename T> LYNX_HD T build_cavity(const T* p, int flags, T energy, T* M, T* coef) {
+template <typename T> LYNX_FN T build_cavity(const T* p, int flags, T energy, T* M, T* coef) {
   const T me = T(LYNX_ELECTRON_MASS_EV);
   T L = p[0], V = p[1], f = p[3];
   T phi = p[2] * T(LYNX_PI / 180.0);  // deg2rad
@@ -361,7 +366,7 @@ template <typename T> LYNX_HD T build_cavity(const T* p, int flags, T energy, T*
 // One element -> M (49 scalars).  `p` points at the element's parameter row of this
 // sample.  Cavity coefficients are produced only for cavity *steps* (coef != nullptr).
 template <typename T>
-LYNX_HD void build_element(int kind, int flags, const T* p, T energy, T* M, T* coef) {
+LYNX_FN void build_element(int kind, int flags, const T* p, T energy, T* M, T* coef) {
   switch (kind) {
     case LYNX_KIND_DRIFT: build_drift(p[0], energy, M); break;
     case LYNX_KIND_QUADRUPOLE: build_quadrupole(p, flags, energy, M); break;
@@ -370,7 +375,7 @@ LYNX_HD void build_element(int kind, int flags, const T* p, T energy, T* M, T* c
     case LYNX_KIND_VCOR: build_corrector(p, true, energy, M); break;
     case LYNX_KIND_CAVITY: build_cavity(p, flags, energy, M, coef); break;
     case LYNX_KIND_CUSTOM:
-#pragma unroll
+#pragma unroll 1
       for (int i = 0; i < 49; ++i) M[i] = p[i];  // custom_transfer_map.py:87-88
       break;
     default: mat_identity(M); break;  // marker.py:32-35, bpm.py:43-46

@@ -81,6 +81,18 @@ class Runtime:
         self.check(self.lib.lynx_profile_end(self.ctx, C.byref(ms), C.byref(n)))
         return float(ms.value), int(n.value)
 
+    def copy_bandwidth(self, nbytes: int, repeats: int = 10) -> float:
+        """GB/s (read + write bytes) of a plain device copy of `nbytes`: the practical HBM ceiling."""
+        nbytes = int(nbytes) // 16 * 16
+        a, b = self.alloc(nbytes), self.alloc(nbytes)
+        try:
+            ms = C.c_float()
+            self.check(self.lib.lynx_diag_copy(self.ctx, C.c_void_p(b), C.c_void_p(a), nbytes, repeats, C.byref(ms)))
+        finally:
+            self.free(a)
+            self.free(b)
+        return 2 * nbytes / (ms.value * 1e-3) / 1e9
+
     def alloc(self, nbytes: int) -> int:
         ptr = C.c_void_p()
         self.check(self.lib.lynx_buf_alloc(self.ctx, int(nbytes), C.byref(ptr)))
