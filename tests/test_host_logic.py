@@ -1,0 +1,196 @@
+"""
+CPU-side checks of the product's host layer: the C ABI library loads and exports every
+symbol include/lynx_hip.h declares, the lattice packer / partition / flag evaluation, the
+reference's error conventions that are decided on the host, and that compute fails LOUDLY
+(no silent CPU fallback) when no GPU is present.
+"""
+
+import ctypes
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import lynx_amd as lx
+from lynx_amd import _ffi, engine
+from oracle import lynx_oracle as o
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _declared_functions():
+    header = (ROOT / "include" / "lynx_hip.h").read_text()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    return sorted(set(re.findall(r"\b(lynx_[a-z0-9_]+)\s*\(", header)))
+
+
+def test_library_exports_every_declared_symbol(built_library):
+    lib = ctypes.CDLL(str(built_library))
+    names = _declared_functions()
+    assert len(names) >= 30
+    for name in names:
+        assert hasattr(lib, name), f"liblynxhip.so does not export {name}"
+    assert set(names) == set(_ffi.SIGNATURES), set(names) ^ set(_ffi.SIGNATURES)
+    assert _ffi.load().lynx_version().startswith(b"lynxhip")
+
+
+def test_struct_layouts_match_the_header():
+    assert ctypes.sizeof(_ffi.Elem) == 16 and ctypes.sizeof(_ffi.Step) == 16
+    header = (ROOT / "include" / "lynx_hip.h").read_text()
+    for name, value in (("LYNX_KIND_CAVITY", _ffi.KIND_CAVITY), ("LYNX_KIND_CUSTOM", _ffi.KIND_CUSTOM),
+                        ("LYNX_KIND_DIPOLE", _ffi.KIND_DIPOLE)):
+        assert re.search(rf"{name}\s*=\s*{value}\b", header)
+    for name, value in (("LYNX_FLAG_TILT", 1), ("LYNX_FLAG_MISALIGNED", 2), ("LYNX_FLAG_THICK", 4),
+                        ("LYNX_FLAG_CAV_BETA", 8), ("LYNX_FLAG_CAV_GAIN", 16), ("LYNX_FLAG_CAV_T5XX", 32),
+                        ("LYNX_STEP_FLAG_RAW", 64), ("LYNX_MOMENT_STRIDE", 36), ("LYNX_UNIQUE_ID_BYTES", 128)):
+        assert re.search(rf"#define {name} {value}\b", header), name
+
+
+def _gpu_present():
+    n = ctypes.c_int(0)
+    _ffi.load().lynx_device_count(ctypes.byref(n))
+    return n.value > 0
+
+
+def test_compute_fails_loudly_without_a_gpu(built_library):
+    if _gpu_present():
+        pytest.skip("a GPU is present; the loud-failure path is exercised on the CPU-only box")
+    f = lambda v: np.array([v], dtype=np.float32)  # noqa: E731
+    with pytest.raises(_ffi.LynxError, match="no HIP device|no ROCm"):
+        lx.Drift(f(1.0)).track(lx.ParameterBeam.from_parameters())
+    with pytest.raises(_ffi.LynxError):
+        lx.Segment([lx.Drift(f(1.0))]).transfer_map(f(1e8))
+    with pytest.raises(_ffi.LynxError):
+        lx.ParticleBeam(np.ones((1, 4, 7), np.float32), f(1e8)).sigma_x
+
+
+def test_missing_library_is_an_error_not_a_fallback(monkeypatch, tmp_path):
+    monkeypatch.setenv("LYNX_HIP_LIBRARY", str(tmp_path / "nope.so"))
+    monkeypatch.setattr(_ffi, "_lib", None)
+    with pytest.raises(_ffi.LynxError, match="not built"):
+        _ffi.load()
+
+
+def test_no_product_module_imports_the_oracle():
+    for path in (ROOT / "lynx_amd").rglob("*.py"):
+        text = path.read_text()
+        assert "oracle" not in re.sub(r"#.*", "", text).replace("lynx_oracle.py", ""), path
+
+
+def test_partition_matches_segment_track_todos():
+    f = lambda v: np.array([v], dtype=np.float32)  # noqa: E731
+    cav_on = lx.Cavity(f(1.0), voltage=f(1e6), name="on")
+    cav_off = lx.Cavity(f(1.0), voltage=f(0.0), name="off")
+    bpm = lx.BPM(name="bpm", is_active=True)
+    els = [lx.Drift(f(1)), lx.BPM(), cav_on, lx.Marker(), lx.Drift(f(1)), bpm, cav_off, lx.Quadrupole(f(1), k1=f(1))]
+    items = engine.partition(els)
+    assert [type(i).__name__ for i in items] == ["Program", "BPM", "Program"]
+    assert [s[0] for s in items[0].steps] == [_ffi.STEP_RUN, _ffi.STEP_CAVITY, _ffi.STEP_RUN]
+    assert [(s[1], s[2]) for s in items[0].steps] == [(0, 2), (2, 3), (3, 5)]
+    assert items[2].steps == [[_ffi.STEP_RUN, 0, 2]]
+    specs = [o.Drift(f(1)), o.BPM(), o.Cavity(f(1), voltage=f(1e6)), o.Marker(), o.Drift(f(1)), o.BPM(is_active=True),
+             o.Cavity(f(1), voltage=f(0.0)), o.Quadrupole(f(1), k1=f(1))]
+    assert [k for k, _ in o.partition(specs)] == ["run", "single", "run", "single", "run"]
+    # a nested non-skippable segment starts and ends a run; a skippable one joins the current run
+    inner_ns = lx.Segment([lx.Drift(f(1)), lx.Cavity(f(1), voltage=f(1e6)), lx.Drift(f(1))])
+    inner_s = lx.Segment([lx.Drift(f(1)), lx.Drift(f(2))])
+    items = engine.partition([lx.Drift(f(1)), inner_s, inner_ns, lx.Drift(f(1))])
+    assert [(s[0], s[1], s[2]) for s in items[0].steps] == [(0, 0, 3), (0, 3, 4), (1, 4, 5), (0, 5, 6), (0, 6, 7)]
+
+
+def test_packed_lattice_layout_and_flags():
+    B = 3
+    f = lambda v: np.full(B, v, dtype=np.float32)  # noqa: E731
+    quad = lx.Quadrupole(f(0.2), k1=np.array([1.0, 2.0, 3.0], np.float32), tilt=np.array([0, 0.1, 0], np.float32))
+    drift1 = lx.Drift(np.array([0.5], np.float32))  # broadcastable: stored once
+    dip = lx.Dipole(np.array([0.0, 0.5, 0.0], np.float32), angle=f(0.1))
+    cav = lx.Cavity(f(1.0), voltage=np.array([0.0, 1e7, 0.0], np.float32), phase=f(10.0), frequency=f(1.3e9))
+    prog = engine.partition([quad, drift1, lx.Marker(), dip, cav])[0]
+    lat = engine.PackedLattice(prog, (B,), np.float32)
+    kinds = [lat.elems[i].kind for i in range(lat.E)]
+    assert kinds == [_ffi.KIND_QUADRUPOLE, _ffi.KIND_DRIFT, _ffi.KIND_IDENTITY, _ffi.KIND_DIPOLE, _ffi.KIND_CAVITY]
+    assert [lat.elems[i].batch_stride for i in range(lat.E)] == [5, 0, 0, 8, 4]
+    assert [lat.elems[i].param_offset for i in range(lat.E)] == [0, 15, 16, 16, 40]
+    assert lat.pool.size == 15 + 1 + 24 + 12 and lat.pool.dtype == np.float32
+    row1 = lat.pool[5:10]
+    assert np.allclose(row1, [0.2, 2.0, 0.1, 0.0, 0.0])  # sample 1 of the quadrupole: L, k1, tilt, mx, my
+    ef, sf = lat.evaluate_flags(f(1e8))
+    assert ef[0] == _ffi.FLAG_TILT and ef[3] == _ffi.FLAG_THICK
+    gain_t5 = _ffi.FLAG_CAV_BETA | _ffi.FLAG_CAV_GAIN | _ffi.FLAG_CAV_T5XX
+    assert ef[4] == gain_t5 and sf == [0, gain_t5]
+    # decelerating cavity on every sample: dE < 0 -> no T5XX; still E + dE > 0 -> GAIN
+    cav.phase = f(180.0)
+    lat2 = engine.PackedLattice(engine.partition([cav])[0], (B,), np.float32)
+    _, sf2 = lat2.evaluate_flags(f(1e8))
+    assert sf2 == [_ffi.FLAG_CAV_BETA | _ffi.FLAG_CAV_GAIN]
+    with pytest.raises(AssertionError, match="Initial energy must be larger than 0"):  # cavity.py:260
+        lat2.evaluate_flags(f(0.0))
+
+
+def test_shape_mismatch_is_an_assertion_error():
+    prog = engine.partition([lx.Drift(np.ones(2, np.float32))])[0]
+    with pytest.raises(AssertionError, match="does not match element shape"):  # drift.py:45-47
+        engine.PackedLattice(prog, (3,), np.float32)
+
+
+def test_parameter_changes_invalidate_the_cache_key():
+    q = lx.Quadrupole(np.array([0.2], np.float32), k1=np.array([1.0], np.float32), name="Q")
+    seg = lx.Segment([lx.Drift(np.array([1.0], np.float32)), q])
+    v0 = q._version
+    seg.Q.k1 = np.array([4.2], np.float32)  # README.md:60 style mutation
+    assert q._version == v0 + 1
+    cache = engine.LatticeCache()
+    a = cache.get(engine.partition(seg.elements)[0], (1,), np.float32)
+    assert cache.get(engine.partition(seg.elements)[0], (1,), np.float32) is a
+    q.k1 = np.array([5.0], np.float32)
+    b = cache.get(engine.partition(seg.elements)[0], (1,), np.float32)
+    assert b is not a and b.pool[2] == 5.0
+
+
+def test_segment_container_api():
+    f = lambda v: np.array([v], dtype=np.float32)  # noqa: E731
+    seg = lx.Segment([lx.BPM(name="BPM1"), lx.Drift(f(1.0), name="D"), lx.Drift(f(2.0), name="D"),
+                      lx.Quadrupole(f(0.2), k1=f(0.0), name="Q"), lx.Marker(name="M"),
+                      lx.HorizontalCorrector(f(0.3), name="H")])
+    assert isinstance(seg.D, list) and len(seg.D) == 2 and seg.Q.name == "Q"  # segment.py:45-54
+    assert np.isclose(seg.length, 3.5) and seg.is_skippable
+    assert [e.name for e in seg.subcell("D", "Q").elements] == ["D", "D", "Q"]
+    assert not any(isinstance(e, lx.Marker) for e in seg.without_inactive_markers().elements)
+    drifts = seg.inactive_elements_as_drifts().elements
+    assert isinstance(drifts[3], lx.Drift) and isinstance(drifts[5], lx.Drift) and isinstance(drifts[0], lx.BPM)
+    assert [e.name for e in seg.without_inactive_zero_length_elements().elements] == ["D", "D", "Q", "H"]
+    nested = lx.Segment([seg, lx.Drift(f(1.0))])
+    assert len(nested.flattened().elements) == 7
+    b = seg.broadcast((3, 2))
+    assert b.length.shape == (3, 2) and b.Q.k1.shape == (3, 2) and b.Q.misalignment.shape == (3, 2, 2)
+    assert b.H.angle.shape == (1,)  # horizontal_corrector.py:69-72 does not repeat `angle`
+    seg.BPM1.is_active = True
+    assert not seg.is_skippable
+
+
+def test_beam_constructors_follow_the_reference():
+    b = lx.ParameterBeam.from_parameters()
+    assert b._mu.shape == (1, 7) and b._cov.shape == (1, 7, 7) and b.energy[0] == 1e8
+    assert np.isclose(b.sigma_x, 175e-9) and np.isclose(b.sigma_xp, 2e-7) and np.isclose(b.sigma_s, 1e-6)
+    with pytest.raises(AssertionError, match="Arguments must have the same shape"):  # parameter_beam.py:91-94
+        lx.ParameterBeam.from_parameters(mu_x=np.zeros(2), sigma_x=np.ones(3))
+    t = lx.ParameterBeam.from_twiss(beta_x=np.array([5.91253676811640894]), alpha_x=np.array([3.55631307633660354]),
+                                    emittance_x=np.array([3.494768647122823e-09]), energy=np.array([6e6]))
+    assert np.isclose(t.beta_x, 5.91253676811640894) and np.isclose(t.alpha_x, 3.55631307633660354)
+    assert np.isclose(t.emittance_x, 3.494768647122823e-09)
+    assert np.isclose(t.relativistic_gamma, 6e6 / 510998.95069)
+    bb = b.broadcast((3, 10))
+    assert bb._mu.shape == (3, 10, 7) and bb._cov.shape == (3, 10, 7, 7) and bb.energy.shape == (3, 10)
+    tr = b.transformed_to(mu_x=np.array([1e-5], np.float32), sigma_x=np.array([1.75e-7], np.float32))
+    assert np.isclose(tr.mu_x, 1e-5) and np.isclose(tr.sigma_x, 1.75e-7)
+    with pytest.raises(AssertionError, match="7-dimensional"):  # particle_beam.py:35-37
+        lx.ParticleBeam(np.ones((1, 10, 6), np.float32), np.array([1e8]))
+    p = lx.ParticleBeam.from_parameters(num_particles=1000, sigma_x=np.array([1e-5, 2e-5]), seed=0)
+    assert p.particles.shape == (2, 1000, 7) and np.all(p.particles[..., 6] == 1) and p.num_particles == 1000
+    assert p.particle_charges.shape == (2, 1000) and p.total_charge.shape == (2,)
+    assert np.allclose(np.std(p.xs, axis=-1), [1e-5, 2e-5], rtol=0.1)
+    lin = lx.ParticleBeam.make_linspaced(num_particles=11, sigma_x=np.array([1e-3], np.float32))
+    assert np.allclose(lin.xs[0], np.linspace(-1e-3, 1e-3, 11))
+    bp = p.broadcast((3,))
+    assert bp.particles.shape == (6, 1000, 7)  # Tensor.repeat semantics on a (2,)-batch
