@@ -44,16 +44,43 @@ template <typename T> __device__ __forceinline__ T shfl_t(T v, int src) { return
 //            cavities (cavity.py:130: E_out = E + V cos(phi)).
 //   phase 1  up to kBuildChunk elements are built in parallel, one element per thread,
 //            straight into LDS (transcendentals run element-parallel).
-//   phase 2  wave 0 left-multiplies them in lattice order, tm = M_e . tm
-//            (segment.py:334-335): lane (i,j) keeps tm[i][j] in a register, fetches
-//            column j of tm with 7 wave shuffles and row i of M_e from LDS.
+//   phase 2  the chunk's maps of each step are multiplied together by a pairwise tree:
+//            level by level, neighbours (M_{2i+1} . M_{2i}) are merged, blockDim.x/49
+//            products per round with one lane per output entry, then the chunk product is
+//            left-multiplied onto the step's running map, tm = P_chunk . tm.
+//            The product is the reference's tm = M_n ... M_2 M_1 (segment.py:334-335); only
+//            the association differs (tree instead of left-to-right), i.e. rounding-level
+//            differences, in exchange for log2 instead of linear depth: the build is a pure
+//            latency chain and sits on the critical path of every call.
+//
+// LDS scratch: kBuildChunk*49 (maps) + kBuildTree*49 (two ping-pong levels + running map).
 // ---------------------------------------------------------------------------------------
+constexpr int kBuildTreeB = kBuildChunk / 2 + 1;  // level buffers
+constexpr int kBuildTreeC = kBuildChunk / 4 + 1;
+constexpr int kBuildScratch = (kBuildChunk + kBuildTreeB + kBuildTreeC + 1) * 49;  // scalars
+
+template <typename T>
+__device__ __forceinline__ T mat_product_entry(const T* A, const T* Bm, int ij) {
+  // (A . Bm)[i][j] = sum_k A[i][k] * Bm[k][j], ascending k
+  const int i = ij / 7, j = ij - i * 7;
+  T acc = A[i * 7] * Bm[j];
+#pragma unroll
+  for (int k = 1; k < 7; ++k) acc = t_fma(A[i * 7 + k], Bm[k * 7 + j], acc);
+  return acc;
+}
+
 template <typename T>
 __device__ void build_compose_sample(const LatticeDev& lat, int64_t b, T energy_in, T* s_steps,
-                                     T* s_energy, T* s_scratch /* kBuildChunk*49 */) {
+                                     T* s_energy, T* s_scratch /* kBuildScratch */) {
   const int tid = threadIdx.x;
   const int E = lat.n_elems, S = lat.n_steps;
   const T* pool = static_cast<const T*>(lat.pool);
+  T* bufA = s_scratch;
+  T* bufB = bufA + kBuildChunk * 49;
+  T* bufC = bufB + kBuildTreeB * 49;
+  T* carry = bufC + kBuildTreeC * 49;
+  const int per_round = blockDim.x / 49;  // products per round
+  const int my_prod = tid / 49, my_ij = tid - my_prod * 49;
 
   if (tid == 0) {
     T e = energy_in;
@@ -72,11 +99,7 @@ __device__ void build_compose_sample(const LatticeDev& lat, int64_t b, T energy_
   }
   __syncthreads();
 
-  const int lane = tid & 63;
-  const int cl = lane < 49 ? lane : 48;
-  const int ci = cl / 7, cj = cl % 7;
-  T tval = T(0);
-
+  int s_cur = 0;  // first step that may intersect the current chunk (uniform)
   for (int e0 = 0; e0 < E; e0 += kBuildChunk) {
     const int ne = (E - e0) < kBuildChunk ? (E - e0) : kBuildChunk;
     // phase 1
@@ -86,33 +109,53 @@ __device__ void build_compose_sample(const LatticeDev& lat, int64_t b, T energy_
       const int s = lat.elem_step[e];
       const T* p = pool + el.param_offset + b * (int64_t)el.batch_stride;
       const bool cav_step = lat.steps[s].kind == LYNX_STEP_CAVITY;
-      build_element<T>(el.kind, el.flags, p, s_energy[s], s_scratch + t * 49,
+      build_element<T>(el.kind, el.flags, p, s_energy[s], bufA + t * 49,
                        cav_step ? s_steps + s * LYNX_STEP_STRIDE + LYNX_COEF_OFFSET : nullptr);
     }
     __syncthreads();
-    // phase 2 (wave 0)
-    if (tid < 64) {
-      int info = 0;  // lane t: (step << 3) | raw << 2 | is_last << 1 | is_first, for element e0 + t
-      if (lane < ne) {
-        const int e = e0 + lane;
-        const int s = lat.elem_step[e];
-        lynx_step st = lat.steps[s];
-        const bool raw = st.kind == LYNX_STEP_CAVITY || (st.flags & LYNX_STEP_FLAG_RAW);
-        info = (s << 3) | (raw ? 4 : 0) | ((e == st.last - 1) ? 2 : 0) | ((e == st.first) ? 1 : 0);
+    // phase 2: every step that has elements in [e0, e0 + ne)
+    while (s_cur < S) {
+      const lynx_step st = lat.steps[s_cur];
+      if (st.first >= e0 + ne) break;
+      const int lo = (st.first > e0 ? st.first : e0) - e0;
+      const int hi = (st.last < e0 + ne ? st.last : e0 + ne) - e0;
+      const bool starts_here = st.first >= e0;
+      const bool ends_here = st.last <= e0 + ne;
+      const bool raw = st.kind == LYNX_STEP_CAVITY || (st.flags & LYNX_STEP_FLAG_RAW);
+      // pairwise tree over bufA[lo .. hi)
+      const T* src = bufA + lo * 49;
+      int count = hi - lo;
+      int level = 0;
+      while (count > 1) {
+        T* dst = (level & 1) ? bufC : bufB;
+        const int half = count >> 1;
+        for (int pr = my_prod; pr < half; pr += per_round)
+          if (my_prod < per_round) dst[pr * 49 + my_ij] = mat_product_entry<T>(src + (2 * pr + 1) * 49, src + (2 * pr) * 49, my_ij);
+        if ((count & 1) && tid < 49) dst[half * 49 + tid] = src[(count - 1) * 49 + tid];
+        __syncthreads();
+        src = dst;
+        count = half + (count & 1);
+        ++level;
       }
-      for (int t = 0; t < ne; ++t) {
-        const int inf = __builtin_amdgcn_readlane(info, t);  // t is wave-uniform
-        const T* M = s_scratch + t * 49 + ci * 7;
-        if ((inf & 5) == 5) {
-          tval = M[cj];  // raw first element: the map itself
-        } else {
-          if (inf & 1) tval = (ci == cj) ? T(1) : T(0);
-          T acc = M[0] * shfl_t(tval, 0 * 7 + cj);
-#pragma unroll
-          for (int k = 1; k < 7; ++k) acc = t_fma(M[k], shfl_t(tval, k * 7 + cj), acc);
-          tval = acc;
+      // running map of the step: tm = P . tm, starting from eye(7) (segment.py:331) unless raw
+      if (starts_here && raw) {
+        if (tid < 49) carry[tid] = src[tid];
+      } else {
+        if (starts_here) {
+          if (tid < 49) carry[tid] = (tid % 8 == 0) ? T(1) : T(0);
+          __syncthreads();
         }
-        if ((inf & 2) && lane < 49) s_steps[(inf >> 3) * LYNX_STEP_STRIDE + lane] = tval;
+        T v = T(0);
+        if (tid < 49) v = mat_product_entry<T>(src, carry, tid);
+        __syncthreads();
+        if (tid < 49) carry[tid] = v;
+      }
+      __syncthreads();
+      if (ends_here) {
+        if (tid < 49) s_steps[s_cur * LYNX_STEP_STRIDE + tid] = carry[tid];
+        ++s_cur;
+      } else {
+        break;  // the step continues in the next chunk
       }
     }
     __syncthreads();
@@ -158,15 +201,15 @@ __device__ __forceinline__ void apply_program(const LatticeDev& lat, const T* s_
 }
 
 // ---------------------------------------------------------------------------------------
-// k_build: standalone build+compose, one 64-thread workgroup per sample.
+// k_build: standalone build+compose, one 256-thread workgroup per sample.
 // ---------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(64) void k_build(LatticeDev lat, const T* __restrict__ energy_in,
+__global__ __launch_bounds__(256) void k_build(LatticeDev lat, const T* __restrict__ energy_in,
                                                T* __restrict__ steps_out, T* __restrict__ energy_out,
                                                const T* __restrict__ p_first, int64_t sample_stride) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* s_scratch = reinterpret_cast<T*>(smem_raw);
-  T* s_steps = s_scratch + kBuildChunk * 49;
+  T* s_steps = s_scratch + kBuildScratch;
   T* s_energy = s_steps + (size_t)lat.n_steps * LYNX_STEP_STRIDE;
   const int64_t b = blockIdx.x;
   // zero the coefficient slots so that run steps have defined padding
@@ -466,6 +509,10 @@ template <bool NT> __device__ __forceinline__ void store_particle(double* p, con
   st<NT>(p + 6, z[6]);
 }
 
+template <int MOM> struct MomScratch { using type = double; };
+template <> struct MomScratch<2> { using type = float; };  // float32 partial sums
+constexpr int kMomSlabScalars = 4 * 29 * 65;  // per workgroup, in units of MomScratch<MOM>::type
+
 template <typename T, int MOM, int UNROLL, bool FUSED>
 __global__ __launch_bounds__(kTrackThreads) void k_track_direct(
     LatticeDev lat, TrackArgs a, const T* __restrict__ energy_in, const T* p_in, T* p_out,
@@ -486,26 +533,39 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_direct(
   constexpr int64_t kTile = (int64_t)kTrackThreads * UNROLL;
   const int64_t end = N;
 
+  const bool one_run = (S == 1) && (lat.steps[0].kind == LYNX_STEP_RUN);
+  constexpr bool kMapInRegs = sizeof(T) == 4;
+  // Pre-built single-run fp32 program: the map and the moment reference point come straight
+  // from the step table with wave-uniform (scalar) loads -- no LDS staging, no barrier.
+  const bool scalar_table = !FUSED && kMapInRegs && one_run;
+  const T* g_steps = steps_in + b * (int64_t)S * LYNX_STEP_STRIDE;
+
   if (FUSED) {
     build_compose_sample<T>(lat, b, energy_in[b], s_steps, s_energy, s_scratch);
     if (energy_out && chunk == 0 && tid == 0) energy_out[b] = s_energy[S];
-  } else if (S > 0) {
-    load_steps_sample<T>(steps_in + b * (int64_t)S * LYNX_STEP_STRIDE, S, s_steps);
+  } else if (S > 0 && !scalar_table) {
+    load_steps_sample<T>(g_steps, S, s_steps);
   }
 
-  const bool one_run = (S == 1) && (lat.steps[0].kind == LYNX_STEP_RUN);
-  constexpr bool kMapInRegs = sizeof(T) == 4;
   T m0[kMapInRegs ? 49 : 1];
   if (one_run && kMapInRegs) {
+    if (scalar_table) {
 #pragma unroll
-    for (int i = 0; i < 49; ++i) m0[i] = uniform_value(s_steps[i]);
+      for (int i = 0; i < 49; ++i) m0[i] = uniform_value(g_steps[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 49; ++i) m0[i] = uniform_value(s_steps[i]);
+    }
   }
 
   MomentAcc<T> acc;
   T shift[7];
   if (MOM) {
     acc.clear();
-    if (!FUSED && S > 0) {
+    if (scalar_table) {
+#pragma unroll
+      for (int i = 0; i < 7; ++i) shift[i] = uniform_value(g_steps[LYNX_SHIFT_OFFSET + i]);
+    } else if (!FUSED && S > 0) {
 #pragma unroll
       for (int i = 0; i < 7; ++i) shift[i] = s_steps[LYNX_SHIFT_OFFSET + i];  // from k_build
     } else {
@@ -578,22 +638,31 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_direct(
   }
 
   if (MOM) {
-    __syncthreads();  // build scratch is reused as the reduction buffer
-    double* s_red = reinterpret_cast<double*>(s_scratch);  // 4 waves x 29
+    // Workgroup reduction of the 29 sums through LDS: every lane parks its values in a
+    // [29][65] slab of its wave (row pitch 65 -> conflict-free both ways), lanes 0..28 then
+    // each add up one row in float64.  A 64-lane shuffle tree of 29 values costs ~350
+    // ds_bpermute per wave; this costs 29 stores and 64 loads per lane and is the larger part
+    // of a workgroup's fixed cost when it only owns a few thousand particles.
+    using R = typename MomScratch<MOM>::type;
     const int wave = tid >> 6, lane = tid & 63;
-#define LYNX_WAVE_SUM(dst_idx, value)                                        \
-    {                                                                          \
-      double v_ = (value);                                                     \
-      for (int off = 32; off >= 1; off >>= 1) v_ += __shfl_xor(v_, off, 64);   \
-      if (lane == 0) s_red[wave * 29 + (dst_idx)] = v_;                        \
+    __syncthreads();  // the build scratch is reused
+    R* slab = reinterpret_cast<R*>(s_scratch) + wave * (29 * 65);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) slab[i * 65 + lane] = (R)acc.d[i];
+    slab[6 * 65 + lane] = (R)acc.one;
+#pragma unroll
+    for (int i = 0; i < 21; ++i) slab[(7 + i) * 65 + lane] = (R)acc.dd[i];
+    slab[28 * 65 + lane] = (R)acc.cnt;
+    __syncthreads();
+    double tot = 0.0;
+    if (lane < 29) {
+      const R* row = slab + lane * 65;
+#pragma unroll 8
+      for (int k = 0; k < 64; ++k) tot += (double)row[k];
     }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) LYNX_WAVE_SUM(i, acc.d[i]);
-    LYNX_WAVE_SUM(6, acc.one);
-#pragma unroll
-    for (int i = 0; i < 21; ++i) LYNX_WAVE_SUM(7 + i, acc.dd[i]);
-    LYNX_WAVE_SUM(28, acc.cnt);
-#undef LYNX_WAVE_SUM
+    __syncthreads();
+    double* s_red = reinterpret_cast<double*>(s_scratch);  // 4 waves x 29
+    if (lane < 29) s_red[wave * 29 + lane] = tot;
     __syncthreads();
     double* out = partials + ((int64_t)b * a.chunks + chunk) * kPartialStride;
     if (tid < 29) {
@@ -670,7 +739,7 @@ __global__ __launch_bounds__(64) void k_track_moments(LatticeDev lat, const T* _
                                                        T* cov_out, T* __restrict__ energy_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* s_scratch = reinterpret_cast<T*>(smem_raw);
-  T* s_steps = s_scratch + kBuildChunk * 49;
+  T* s_steps = s_scratch + kBuildScratch;
   T* s_energy = s_steps + (size_t)lat.n_steps * LYNX_STEP_STRIDE;
   T* s_mu = s_energy + lat.n_steps + 1;  // 8
   T* s_cov = s_mu + 8;                   // 49

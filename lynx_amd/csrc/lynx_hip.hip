@@ -415,10 +415,10 @@ static int allow_lds(lynx_ctx* ctx, K kernel, size_t bytes) {
 template <typename T>
 static int launch_build(lynx_ctx* ctx, lynx_lattice* lat, const void* d_energy_in, void* d_steps_out,
                         void* d_energy_out, const void* d_p_first = nullptr, int64_t sample_stride = 0) {
-  const size_t lds = ((size_t)kBuildChunk * 49 + (size_t)lat->n_steps * LYNX_STEP_STRIDE + lat->n_steps + 1) * sizeof(T);
+  const size_t lds = ((size_t)kBuildScratch + (size_t)lat->n_steps * LYNX_STEP_STRIDE + lat->n_steps + 1) * sizeof(T);
   int rc = allow_lds(ctx, k_build<T>, lds);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_build<T>, dim3((unsigned)lat->batch), dim3(64), lds, ctx->stream, dev_view(lat),
+  hipLaunchKernelGGL(k_build<T>, dim3((unsigned)lat->batch), dim3(256), lds, ctx->stream, dev_view(lat),
                      (const T*)d_energy_in, (T*)d_steps_out, (T*)d_energy_out, (const T*)d_p_first, sample_stride);
   HIP_TRY(ctx, hipGetLastError());
   return LYNX_OK;
@@ -456,7 +456,7 @@ static int env_int(const char* name, int dflt) {
 //   LYNX_WGS_PER_CU=<n>      workgroups per CU over the whole launch
 template <typename T>
 static TrackPlan plan_track(lynx_ctx* ctx, int64_t B, int64_t N, int32_t S, bool fused, const void* p_in,
-                            const void* p_out) {
+                            const void* p_out, bool moments) {
   TrackPlan p;
   const char* kern = getenv("LYNX_KERNEL");
   p.direct = !(kern && strcmp(kern, "lds") == 0);
@@ -469,7 +469,10 @@ static TrackPlan plan_track(lynx_ctx* ctx, int64_t B, int64_t N, int32_t S, bool
   p.a.store = p_out ? 1 : 0;
   p.a.interleave = env_int("LYNX_INTERLEAVE", 0);
   int64_t scratch_scalars = (4 * 29 * 8 + sizeof(T) - 1) / sizeof(T);
-  if (fused) scratch_scalars = std::max<int64_t>(scratch_scalars, kBuildChunk * 49);
+  if (fused) scratch_scalars = std::max<int64_t>(scratch_scalars, kBuildScratch);
+  // direct kernel: LDS slab of the moment reduction (float32 for MOM 2, float64 for MOM 1)
+  const int64_t slab_bytes = (int64_t)kMomSlabScalars * (p.mom_mode == 2 ? 4 : 8);
+  if (p.direct && moments) scratch_scalars = std::max<int64_t>(scratch_scalars, (slab_bytes + sizeof(T) - 1) / sizeof(T));
   if (p.direct) {
     int u = env_int("LYNX_UNROLL", sizeof(T) == 4 ? 4 : 2);
     if (u != 1 && u != 2 && u != 4) u = 2;
@@ -480,7 +483,11 @@ static TrackPlan plan_track(lynx_ctx* ctx, int64_t B, int64_t N, int32_t S, bool
     p.vec = false;
     const int64_t tile = 256 * (int64_t)u;
     const int64_t ntiles = (N + tile - 1) / tile;
-    int64_t chunks = std::max<int64_t>(1, std::min<int64_t>(ntiles, (target + B - 1) / B));
+    // A workgroup pays a fixed cost (table load, 29-value cross-lane reduction, partial
+    // record), so it gets at least `min_tpw` tiles -- unless that would leave CUs idle.
+    int64_t min_tpw = env_int("LYNX_MIN_TILES_PER_WG", sizeof(T) == 4 ? 3 : 4);
+    while (min_tpw > 1 && B * ((ntiles + min_tpw - 1) / min_tpw) < 4 * cus) --min_tpw;
+    int64_t chunks = std::max<int64_t>(1, std::min<int64_t>((ntiles + min_tpw - 1) / min_tpw, (target + B - 1) / B));
     int64_t tpw = (ntiles + chunks - 1) / chunks;
     chunks = (ntiles + tpw - 1) / tpw;
     p.a.chunks = (int32_t)chunks;
@@ -608,9 +615,9 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
   // Fused prologue vs separate build launch: every workgroup of a sample rebuilds that
   // sample's maps in its prologue, which is free when a sample has a few workgroups (large
   // batches) and wasteful when one sample is spread over hundreds of them (batch ~ 1).
-  TrackPlan p = plan_track<T>(ctx, B, N, S, true, d_p_in, d_p_out);
+  TrackPlan p = plan_track<T>(ctx, B, N, S, true, d_p_in, d_p_out, moments);
   bool fused = S > 0 && !(flags & LYNX_TRACK_TWO_KERNEL) && p.a.chunks <= env_int("LYNX_FUSE_MAX_CHUNKS", 8);
-  if (!fused) p = plan_track<T>(ctx, B, N, S, false, d_p_in, d_p_out);
+  if (!fused) p = plan_track<T>(ctx, B, N, S, false, d_p_in, d_p_out, moments);
   const void* d_steps = nullptr;
   int rc;
   if (S > 0 && !fused) {
@@ -681,7 +688,7 @@ template <typename T>
 static int launch_track_moments(lynx_ctx* ctx, lynx_lattice* lat, const void* d_energy_in, const void* d_mu_in,
                                 const void* d_cov_in, void* d_mu_out, void* d_cov_out, void* d_energy_out) {
   const size_t lds =
-      ((size_t)kBuildChunk * 49 + (size_t)lat->n_steps * LYNX_STEP_STRIDE + lat->n_steps + 1 + 8 + 49 + 49 + 16) * sizeof(T);
+      ((size_t)kBuildScratch + (size_t)lat->n_steps * LYNX_STEP_STRIDE + lat->n_steps + 1 + 8 + 49 + 49 + 16) * sizeof(T);
   int rc = allow_lds(ctx, k_track_moments<T>, lds);
   if (rc) return rc;
   hipLaunchKernelGGL(k_track_moments<T>, dim3((unsigned)lat->batch), dim3(64), lds, ctx->stream, dev_view(lat),
