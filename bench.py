@@ -96,7 +96,7 @@ def cpu_baseline(name, particles, cells, dtype, budget_s=12.0):
             run()
             reps += 1
             dt = time.perf_counter() - t0
-            if dt > budget_s or reps >= 200:
+            if dt > budget_s or reps >= 2000:
                 break
     finally:
         if ctx is not None:
@@ -147,20 +147,44 @@ def main():
                                      seed=2 + rank, dtype=dtype)
 
     comm, gather_kind = None, "none"
-    if world > 1:
+    force_comm = os.environ.get("LYNX_FORCE_COMM") == "1"  # exercise the RCCL path at world_size 1
+    if world > 1 or force_comm:
         def exchange(uid):
+            if dist is None:
+                return uid
             box = [uid]
             dist.broadcast_object_list(box, src=0)
             return box[0]
 
-        comm = RcclCommunicator(world, rank, exchange, rt)
-        gather_kind = "rccl-allgather"
+        try:
+            comm = RcclCommunicator(world, rank, exchange, rt)
+            gather_kind = "rccl-allgather"
+        except Exception as exc:  # the run must still produce its line; say loudly what happened
+            print(f"[rank {rank}] RCCL communicator failed ({exc}); moment records will be gathered through "
+                  "the host with gloo", file=sys.stderr, flush=True)
+            gather_kind = "gloo-host-fallback"
+        if dist is not None:
+            # every rank must use the same transport
+            import torch
+
+            ok = torch.tensor([1 if comm is not None else 0])
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0 and comm is not None:
+                comm.close()
+                comm, gather_kind = None, "gloo-host-fallback"
 
     def step():
         out = segment.track(beam)
-        if comm is not None and out._moments is not None:
+        if out._moments is None or (world == 1 and comm is None):
+            return out, None
+        if comm is not None:
             return out, comm.all_gather(out._moments.device(rt).reshape(batch, 36))
-        return out, None
+        import torch
+
+        local = torch.from_numpy(np.ascontiguousarray(out.moment_record().reshape(batch, 36)))
+        parts = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(parts, local)
+        return out, np.stack([p.numpy() for p in parts])
 
     for _ in range(args.warmup):
         last = step()
@@ -224,7 +248,7 @@ def main():
             "config": {"workload": f"{args.workload}: {descr}", "batch_per_gpu": batch, "global_batch": batch * world,
                        "particles": particles, "elements": n_elements, "fused_moments": not args.no_moments,
                        "gather": gather_kind, "parallelism": f"batch-sharded x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "k_track", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_track_direct", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                          "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": kern_s * 1e3, "launches": launches},

@@ -542,3 +542,19 @@ def test_c4_shard_linearity_fp32(lx):
                       lx.Drift(np.array([0.5], dtype)) for i in range(128)])
     alone = np.asarray(sub.track(lx.ParticleBeam(P[5:6], np.array([1e8], dtype), dtype=dtype)).particles)
     assert np.array_equal(alone[0], out[5])
+
+
+def test_rccl_communicator_single_rank(lx):
+    """The RCCL path of lynx_amd.parallel at world_size 1 (the only size a 1-GPU box allows)."""
+    from lynx_amd.device import get_runtime
+    from lynx_amd.parallel import RcclCommunicator
+
+    rt = get_runtime()
+    comm = RcclCommunicator(1, 0, lambda uid: uid, rt)
+    try:
+        local = rt.to_device(np.arange(5 * 36, dtype=np.float64).reshape(5, 36))
+        out = comm.all_gather(local)
+        assert out.shape == (1, 5, 36)
+        assert np.array_equal(np.asarray(out)[0], np.asarray(local))
+    finally:
+        comm.close()
