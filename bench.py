@@ -42,6 +42,8 @@ WORKLOADS = {
     "c3": (1, 1_000_000, 32, np.float64, "BASELINE config 3: 128-element FODO x 1M particles fp64, batch 1"),
     "c3big": (1, 8_000_000, 32, np.float64, "config 3 at 8M particles (896 MB: defeats the 256 MB Infinity Cache)"),
     "c2": (1, 100_000, 0, np.float32, "BASELINE config 2: 11-element ARES-style segment x 100k particles fp32"),
+    "c5": (4096, 10_000, 8, np.float32,
+           "BASELINE config 5 (forward): 4096 envs x 32-element [Drift, misaligned Quad, Drift, Cavity]x8 x 10k particles fp32"),
 }
 
 
@@ -54,6 +56,17 @@ def build_segment(lx, name, batch, cells, dtype, rank, world):
             lx.Drift(f(0.2), dtype=dtype), lx.HorizontalCorrector(f(0.3), angle=f(1e-4), name="H10SMATCH", dtype=dtype),
             lx.Drift(f(7.0), dtype=dtype), lx.HorizontalCorrector(f(0.3), angle=f(-1e-4), name="H12SMATCH", dtype=dtype),
             lx.Drift(f(0.05), dtype=dtype), lx.BPM(name="BPM13SMATCH")])
+    if name == "c5":
+        rng = np.random.default_rng(3 + rank)
+        elements = []
+        for _ in range(cells):
+            elements += [lx.Drift(f(0.3), dtype=dtype),
+                         lx.Quadrupole(f(0.1), k1=rng.uniform(-5, 5, batch).astype(dtype),
+                                       misalignment=rng.normal(0, 1e-4, (batch, 2)).astype(dtype), dtype=dtype),
+                         lx.Drift(f(0.3), dtype=dtype),
+                         lx.Cavity(f(1.0377), voltage=rng.uniform(5e6, 2e7, batch).astype(dtype),
+                                   phase=rng.uniform(-10, 10, batch).astype(dtype), frequency=f(1.3e9), dtype=dtype)]
+        return lx.Segment(elements)
     # k1 scan over the GLOBAL batch: sample g = rank*batch + b gets k1 = +-4.2 (0.5 + (g mod 1024)/1023)
     g = rank * batch + np.arange(batch)
     scale = (0.5 + (g % 1024) / 1023.0) if batch > 1 else np.ones(1)
@@ -73,6 +86,8 @@ def cpu_baseline(name, particles, cells, dtype, budget_s=12.0):
         from threadpoolctl import threadpool_limits
     except Exception:  # pragma: no cover
         threadpool_limits = None
+    if name == "c5":
+        return None
     bs = 8 if name == "c4" else 1
     n = particles if name != "c3big" else 1_000_000
     if name == "c2":
@@ -143,8 +158,8 @@ def main():
 
     segment = build_segment(lx, args.workload, batch, cells, dtype, rank, world)
     n_elements = len(segment.elements)
-    beam = lx.ParticleBeam.synthetic((batch,), particles, sigma=[1e-4, 1e-5, 1e-4, 1e-5, 1e-5, 1e-3], energy=1e8,
-                                     seed=2 + rank, dtype=dtype)
+    beam = lx.ParticleBeam.synthetic((batch,), particles, sigma=[1e-4, 1e-5, 1e-4, 1e-5, 1e-5, 1e-3],
+                                     energy=6e6 if args.workload == "c5" else 1e8, seed=2 + rank, dtype=dtype)
 
     comm, gather_kind = None, "none"
     force_comm = os.environ.get("LYNX_FORCE_COMM") == "1"  # exercise the RCCL path at world_size 1

@@ -537,7 +537,8 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_direct(
   constexpr bool kMapInRegs = sizeof(T) == 4;
   // Pre-built single-run fp32 program: the map and the moment reference point come straight
   // from the step table with wave-uniform (scalar) loads -- no LDS staging, no barrier.
-  const bool scalar_table = !FUSED && kMapInRegs && one_run;
+  constexpr bool kScalarTable = !FUSED && kMapInRegs;  // address space known at compile time
+  const bool scalar_table = kScalarTable && S > 0;
   const T* g_steps = steps_in + b * (int64_t)S * LYNX_STEP_STRIDE;
 
   if (FUSED) {
@@ -582,6 +583,10 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_direct(
     const int64_t tile = a.interleave ? ((int64_t)it * a.chunks + chunk) : ((int64_t)chunk * a.tiles_per_wg + it);
     const int64_t i0 = tile * kTile + tid;
     if (i0 >= end) break;
+    // fp64: the map is re-read from LDS for every particle (broadcast reads are cheap);
+    // without this fence hipcc hoists all 49 entries (98 VGPRs) out of the loop and the
+    // kernel drops to one wave per SIMD.
+    if (!kMapInRegs) LYNX_FORGET();
     T z[UNROLL][7];
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
@@ -595,6 +600,32 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_direct(
 #pragma unroll
       for (int k = 0; k < 21; ++k) f_dd[k] = 0.f;
     }
+    if (!one_run) {
+      // general program: steps outermost, so that each step's map is fetched once per
+      // iteration (fp32: 57 scalar loads into SGPRs; fp64: read from LDS) for all UNROLL
+      // particles of the lane
+      for (int sidx = 0; sidx < S; ++sidx) {
+        const lynx_step st = lat.steps[sidx];
+        if (kMapInRegs) {
+          T m[57];
+          if (kScalarTable) {
+            const T* tab = g_steps + sidx * LYNX_STEP_STRIDE;  // global: s_load
+#pragma unroll
+            for (int q = 0; q < 57; ++q) m[q] = uniform_value(tab[q]);
+          } else {
+            const T* tab = s_steps + sidx * LYNX_STEP_STRIDE;  // LDS
+#pragma unroll
+            for (int q = 0; q < 57; ++q) m[q] = uniform_value(tab[q]);
+          }
+#pragma unroll
+          for (int u = 0; u < UNROLL; ++u) apply_step<T>(m, st.kind, st.flags, z[u]);
+        } else {
+          const T* tab = s_steps + sidx * LYNX_STEP_STRIDE;
+#pragma unroll
+          for (int u = 0; u < UNROLL; ++u) apply_step<T>(tab, st.kind, st.flags, z[u]);
+        }
+      }
+    }
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       const int64_t i = i0 + (int64_t)u * kTrackThreads;
@@ -602,8 +633,6 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_direct(
       if (one_run) {
         if (kMapInRegs) apply_step<T>(m0, LYNX_STEP_RUN, 0, z[u]);
         else apply_step<T>(s_steps, LYNX_STEP_RUN, 0, z[u]);
-      } else {
-        apply_program<T>(lat, s_steps, z[u]);
       }
       if (live) {
         if (a.store) store_particle<false>(dst + i * 7, z[u]);

@@ -474,7 +474,7 @@ static TrackPlan plan_track(lynx_ctx* ctx, int64_t B, int64_t N, int32_t S, bool
   const int64_t slab_bytes = (int64_t)kMomSlabScalars * (p.mom_mode == 2 ? 4 : 8);
   if (p.direct && moments) scratch_scalars = std::max<int64_t>(scratch_scalars, (slab_bytes + sizeof(T) - 1) / sizeof(T));
   if (p.direct) {
-    int u = env_int("LYNX_UNROLL", sizeof(T) == 4 ? 4 : 2);
+    int u = env_int("LYNX_UNROLL", sizeof(T) == 4 ? (S > 1 ? 2 : 4) : 1);  // multi-step programs: fewer live particles
     if (u != 1 && u != 2 && u != 4) u = 2;
     // small jobs: fewer particles per lane so that more workgroups exist
     while (u > 1 && B * ((N + 256 * u - 1) / (256 * u)) < 4 * cus) u >>= 1;
@@ -612,11 +612,14 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
                              double* d_moments_out, int flags) {
   const int32_t S = lv.n_steps;
   const bool moments = (flags & LYNX_TRACK_MOMENTS) != 0;
-  // Fused prologue vs separate build launch: every workgroup of a sample rebuilds that
-  // sample's maps in its prologue, which is free when a sample has a few workgroups (large
-  // batches) and wasteful when one sample is spread over hundreds of them (batch ~ 1).
+  // Fused prologue vs separate build launch.  Default: separate launch (LYNX_FUSE_MAX_CHUNKS
+  // = 0).  In the fused variant every workgroup of a sample rebuilds that sample's maps in
+  // its prologue; that only pays with few, long-lived workgroups per sample, which stream
+  // ~15 % slower than many small ones, and it forces the step table
+  // through LDS instead of scalar loads.  Set LYNX_FUSE_MAX_CHUNKS=<n> to fuse whenever a
+  // sample is covered by <= n workgroups.
   TrackPlan p = plan_track<T>(ctx, B, N, S, true, d_p_in, d_p_out, moments);
-  bool fused = S > 0 && !(flags & LYNX_TRACK_TWO_KERNEL) && p.a.chunks <= env_int("LYNX_FUSE_MAX_CHUNKS", 8);
+  bool fused = S > 0 && !(flags & LYNX_TRACK_TWO_KERNEL) && p.a.chunks <= env_int("LYNX_FUSE_MAX_CHUNKS", 0);
   if (!fused) p = plan_track<T>(ctx, B, N, S, false, d_p_in, d_p_out, moments);
   const void* d_steps = nullptr;
   int rc;

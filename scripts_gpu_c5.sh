@@ -1,0 +1,17 @@
+#!/bin/bash
+mkdir -p gpurun_out/c5
+timeout -k 10 300 python -m pytest tests -m gpu -q -x 2>&1 | tail -2
+for r in 1 2; do
+for wl in c5 c4 c3 c3big c2; do
+  timeout -k 10 120 python bench.py --workload $wl --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/c5/r${r}_$wl.json 2> gpurun_out/c5/r${r}_$wl.err
+done
+LYNX_UNROLL=2 timeout -k 10 120 python bench.py --workload c5 --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/c5/r${r}_c5_u2.json 2> gpurun_out/c5/r${r}_c5_u2.err
+done
+python3 - <<'PY'
+import json,glob
+for f in sorted(glob.glob('gpurun_out/c5/r*.json')):
+    try:
+        d=json.loads(open(f).read().strip().splitlines()[-1]); r=d['roofline']
+        print(f.split('/')[-1].ljust(28), 'ms/step %.3f'%d['ms_per_step'], 'kern ms %.4f'%r['avg_launch_ms'], 'GB/s %.0f'%r['achieved'], 'steps/s %.3e'%d['value'])
+    except Exception as e: print(f,'ERR',e, open(f.replace('.json','.err')).read()[-500:])
+PY

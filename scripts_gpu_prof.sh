@@ -2,13 +2,13 @@
 # rocprofv3 kernel trace (+stats) and, in separate passes, the HBM traffic counters
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/prof; mkdir -p $OUT
-for w in c4 c3 c2; do
+for w in c4 c3 c5; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$w -- python3 bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline > $OUT/trace_$w.json 2> $OUT/trace_$w.err
 done
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_c4 -- python3 bench.py --workload c4 --steps 5 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch_c4.json 2> $OUT/pmc_fetch_c4.err
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_c4 -- python3 bench.py --workload c4 --steps 5 --warmup 1 --no-cpu-baseline > $OUT/pmc_write_c4.json 2> $OUT/pmc_write_c4.err
 find $OUT -name "*.csv" | head -30
-for w in c4 c3 c2; do echo "== $w"; cat $OUT/trace_$w/*/*kernel_stats.csv | cut -c1-160; done
+for w in c4 c3 c5; do echo "== $w"; cat $OUT/trace_$w/*/*kernel_stats.csv | cut -c1-160; done
 python3 - <<'PY'
 import csv,glob,collections
 for kind in ('fetch','write'):
