@@ -241,6 +241,24 @@ def main():
         except Exception as exc:  # pragma: no cover
             print(f"copy calibration failed: {exc}", file=sys.stderr)
 
+    # HBM traffic of the streaming kernel as measured with rocprofv3 PMC counters (separate
+    # FETCH_SIZE / WRITE_SIZE passes of this same command; profiles/*_pmc_traffic.json).  It
+    # cannot be collected from inside the process, so the committed measurement is quoted and
+    # its provenance named; null for workloads that were not profiled.
+    traffic, traffic_src = None, None
+    pmc = sorted((ROOT / "profiles").glob(f"*_{args.workload}_pmc_traffic.json"))
+    if pmc and batch == WORKLOADS[args.workload][0] and particles == WORKLOADS[args.workload][1]:
+        try:
+            rec = json.loads(pmc[-1].read_text())
+            fetch = next(v["mean_KB"] for k, v in rec.items() if "k_track_direct" in k and k.endswith("FETCH_SIZE"))
+            write = next(v["mean_KB"] for k, v in rec.items() if "k_track_direct" in k and k.endswith("WRITE_SIZE"))
+            # gfx950: FETCH_SIZE counts 64 B per 128-B request -> x2 (MI355X_MICROARCH.md, HBM);
+            # calibrated on k_diag_copy in the same profile run.  Units: KiB.
+            traffic = (2.0 * fetch + write) * 1024.0
+            traffic_src = f"profiles/{pmc[-1].name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH_SIZE x2 on gfx950)"
+        except Exception as exc:  # pragma: no cover
+            print(f"could not read {pmc[-1]}: {exc}", file=sys.stderr)
+
     if rank == 0:
         itemsize = np.dtype(dtype).itemsize
         steps_per_pass = batch * world * particles * n_elements
@@ -265,7 +283,8 @@ def main():
                        "gather": gather_kind, "parallelism": f"batch-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": "k_track_direct", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                         "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": kern_s * 1e3, "launches": launches},
             "hbm_gbs_whole_step": alg_bytes * world * args.steps / elapsed / 1e9,
             "hbm_copy_kernel_gbs": copy_gbs,

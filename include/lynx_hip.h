@@ -42,7 +42,11 @@ enum lynx_kind {
   LYNX_KIND_HCOR = 4,       /* horizontal_corrector.py:52-67 params [L,angle]          */
   LYNX_KIND_VCOR = 5,       /* vertical_corrector.py:52-66  params [L,angle]           */
   LYNX_KIND_CAVITY = 6,     /* cavity.py:97-325             params [L,V,phase_deg,f]   */
-  LYNX_KIND_CUSTOM = 7      /* custom_transfer_map.py:87-88 params [49 map entries]    */
+  LYNX_KIND_CUSTOM = 7,     /* custom_transfer_map.py:87-88 params [49 map entries]    */
+  /* the public helpers of lynx/track_methods.py, exposed as lynx_amd.track_methods */
+  LYNX_KIND_BASE_RMATRIX = 8, /* track_methods.py:37-105    params [L,k1,hx,tilt]      */
+  LYNX_KIND_ROTATION = 9,     /* track_methods.py:14-34     params [angle]             */
+  LYNX_KIND_MISALIGNMENT = 10 /* track_methods.py:108-122   params [mx,my,sign] (sign -1: R_entry, +1: R_exit) */
 };
 
 /*

@@ -20,7 +20,8 @@ F32, F64 = 0, 1
 
 KIND_IDENTITY, KIND_DRIFT, KIND_QUADRUPOLE, KIND_DIPOLE = 0, 1, 2, 3
 KIND_HCOR, KIND_VCOR, KIND_CAVITY, KIND_CUSTOM = 4, 5, 6, 7
-PARAMS_OF_KIND = {0: 0, 1: 1, 2: 5, 3: 8, 4: 2, 5: 2, 6: 4, 7: 49}
+KIND_BASE_RMATRIX, KIND_ROTATION, KIND_MISALIGNMENT = 8, 9, 10
+PARAMS_OF_KIND = {0: 0, 1: 1, 2: 5, 3: 8, 4: 2, 5: 2, 6: 4, 7: 49, 8: 4, 9: 1, 10: 3}
 
 FLAG_TILT, FLAG_MISALIGNED, FLAG_THICK = 1, 2, 4
 FLAG_CAV_BETA, FLAG_CAV_GAIN, FLAG_CAV_T5XX = 8, 16, 32

@@ -469,7 +469,9 @@ __global__ __launch_bounds__(kTrackThreads) void k_track(
 //
 // MOM: 0 = no moments, 1 = float64 accumulation per particle, 2 = per-iteration float32
 // partial sums (UNROLL particles, shifted by the sample's reference point) folded into
-// float64 accumulators once per iteration.
+// float64 accumulators once per iteration, 3 = float32 per-lane sums for the whole
+// workgroup lifetime (only chosen when a lane sees <= 32 particles; 58 fewer VGPRs), the
+// float64 part then starts at the workgroup reduction.
 // ---------------------------------------------------------------------------------------
 typedef float lynx_f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float lynx_f32x3u __attribute__((ext_vector_type(3), aligned(4)));
@@ -511,6 +513,7 @@ template <bool NT> __device__ __forceinline__ void store_particle(double* p, con
 
 template <int MOM> struct MomScratch { using type = double; };
 template <> struct MomScratch<2> { using type = float; };  // float32 partial sums
+template <> struct MomScratch<3> { using type = float; };
 constexpr int kMomSlabScalars = 4 * 29 * 65;  // per workgroup, in units of MomScratch<MOM>::type
 
 template <typename T, int MOM, int UNROLL, bool FUSED>
@@ -562,7 +565,7 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_direct(
   MomentAcc<T> acc;
   T shift[7];
   if (MOM) {
-    acc.clear();
+    if (MOM != 3) acc.clear();
     if (scalar_table) {
 #pragma unroll
       for (int i = 0; i < 7; ++i) shift[i] = uniform_value(g_steps[LYNX_SHIFT_OFFSET + i]);
@@ -577,6 +580,13 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_direct(
     }
   }
 
+  float f_d[6], f_dd[21], f_one = 0.f, f_cnt = 0.f;  // MOM 2: per iteration, MOM 3: per workgroup
+  if (MOM == 3) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) f_d[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 21; ++k) f_dd[k] = 0.f;
+  }
   const T* src = p_in + b * N * 7;
   T* dst = p_out + b * N * 7;
   for (int it = 0; it < a.tiles_per_wg; ++it) {
@@ -593,12 +603,12 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_direct(
       const int64_t i = i0 + (int64_t)u * kTrackThreads;
       load_particle<false>(src + (i < end ? i : i0) * 7, z[u]);
     }
-    float f_d[6], f_dd[21], f_one = 0.f;
     if (MOM == 2) {
 #pragma unroll
       for (int k = 0; k < 6; ++k) f_d[k] = 0.f;
 #pragma unroll
       for (int k = 0; k < 21; ++k) f_dd[k] = 0.f;
+      f_one = 0.f;
     }
     if (!one_run) {
       // general program: steps outermost, so that each step's map is fetched once per
@@ -637,7 +647,7 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_direct(
       if (live) {
         if (a.store) store_particle<false>(dst + i * 7, z[u]);
         if (MOM == 1) acc.add(z[u], shift);
-        if (MOM == 2) {
+        if (MOM == 2 || MOM == 3) {
           float e[6];
 #pragma unroll
           for (int k = 0; k < 6; ++k) {
@@ -653,7 +663,8 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_direct(
               f_dd[k] = fmaf(e[r], e[c], f_dd[k]);
               ++k;
             }
-          acc.cnt += 1.0;
+          if (MOM == 2) acc.cnt += 1.0;
+          else f_cnt += 1.f;
         }
       }
     }
@@ -676,12 +687,21 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_direct(
     const int wave = tid >> 6, lane = tid & 63;
     __syncthreads();  // the build scratch is reused
     R* slab = reinterpret_cast<R*>(s_scratch) + wave * (29 * 65);
+    if (MOM == 3) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) slab[i * 65 + lane] = (R)acc.d[i];
-    slab[6 * 65 + lane] = (R)acc.one;
+      for (int i = 0; i < 6; ++i) slab[i * 65 + lane] = (R)f_d[i];
+      slab[6 * 65 + lane] = (R)f_one;
 #pragma unroll
-    for (int i = 0; i < 21; ++i) slab[(7 + i) * 65 + lane] = (R)acc.dd[i];
-    slab[28 * 65 + lane] = (R)acc.cnt;
+      for (int i = 0; i < 21; ++i) slab[(7 + i) * 65 + lane] = (R)f_dd[i];
+      slab[28 * 65 + lane] = (R)f_cnt;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) slab[i * 65 + lane] = (R)acc.d[i];
+      slab[6 * 65 + lane] = (R)acc.one;
+#pragma unroll
+      for (int i = 0; i < 21; ++i) slab[(7 + i) * 65 + lane] = (R)acc.dd[i];
+      slab[28 * 65 + lane] = (R)acc.cnt;
+    }
     __syncthreads();
     double tot = 0.0;
     if (lane < 29) {
@@ -747,6 +767,43 @@ __global__ __launch_bounds__(256) void k_finalize_moments(const double* __restri
     dst[6] = s[6] / n;
   } else if (tid < 28) {
     // upper-triangle index -> (i, j)
+    int k = tid - 7, i = 0, row = 6;
+    while (k >= row) { k -= row; --row; ++i; }
+    const int j = i + k;
+    dst[tid] = (s[tid] - s[i] * s[j] / n) / n;
+  } else if (tid < 35) {
+    dst[tid] = 0.0;
+  } else if (tid == 35) {
+    dst[35] = n;
+  }
+}
+
+// Few chunks per sample (<= 64): one wave per sample, lane j owns value j and adds the
+// chunks in order (the loads are independent, only the adds chain).
+__global__ __launch_bounds__(64) void k_finalize_moments_small(const double* __restrict__ partials,
+                                                                int chunks, double* __restrict__ out) {
+  __shared__ double s[kPartialStride];
+  const int64_t b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const double* src = partials + b * (int64_t)chunks * kPartialStride;
+  if (tid < kPartialStride) {
+    double v;
+    if (tid >= 28 && tid < 35) {
+      v = src[tid];
+    } else {
+      v = 0.0;
+      for (int c = 0; c < chunks; ++c) v += src[(int64_t)c * kPartialStride + tid];
+    }
+    s[tid] = v;
+  }
+  __syncthreads();
+  double* dst = out + b * LYNX_MOMENT_STRIDE;
+  const double n = s[35];
+  if (tid < 6) {
+    dst[tid] = s[28 + tid] + s[tid] / n;
+  } else if (tid == 6) {
+    dst[6] = s[6] / n;
+  } else if (tid < 28) {
     int k = tid - 7, i = 0, row = 6;
     while (k >= row) { k -= row; --row; ++i; }
     const int j = i + k;

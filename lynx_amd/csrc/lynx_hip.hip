@@ -289,6 +289,9 @@ static int params_of_kind(int kind) {
     case LYNX_KIND_VCOR: return 2;
     case LYNX_KIND_CAVITY: return 4;
     case LYNX_KIND_CUSTOM: return 49;
+    case LYNX_KIND_BASE_RMATRIX: return 4;
+    case LYNX_KIND_ROTATION: return 1;
+    case LYNX_KIND_MISALIGNMENT: return 3;
     default: return -1;
   }
 }
@@ -463,7 +466,7 @@ static TrackPlan plan_track(lynx_ctx* ctx, int64_t B, int64_t N, int32_t S, bool
   const int64_t cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
   const int64_t target = (int64_t)env_int("LYNX_WGS_PER_CU", 128) * cus;
   p.mom_mode = env_int("LYNX_MOM", sizeof(T) == 4 ? 2 : 1);
-  if (sizeof(T) == 8 || (p.mom_mode != 1 && p.mom_mode != 2)) p.mom_mode = 1;
+  if (sizeof(T) == 8 || p.mom_mode < 1 || p.mom_mode > 3) p.mom_mode = 1;
   p.a.n_particles = N;
   p.a.fused_build = (fused && S > 0) ? 1 : 0;
   p.a.store = p_out ? 1 : 0;
@@ -471,7 +474,7 @@ static TrackPlan plan_track(lynx_ctx* ctx, int64_t B, int64_t N, int32_t S, bool
   int64_t scratch_scalars = (4 * 29 * 8 + sizeof(T) - 1) / sizeof(T);
   if (fused) scratch_scalars = std::max<int64_t>(scratch_scalars, kBuildScratch);
   // direct kernel: LDS slab of the moment reduction (float32 for MOM 2, float64 for MOM 1)
-  const int64_t slab_bytes = (int64_t)kMomSlabScalars * (p.mom_mode == 2 ? 4 : 8);
+  const int64_t slab_bytes = (int64_t)kMomSlabScalars * (p.mom_mode >= 2 ? 4 : 8);
   if (p.direct && moments) scratch_scalars = std::max<int64_t>(scratch_scalars, (slab_bytes + sizeof(T) - 1) / sizeof(T));
   if (p.direct) {
     int u = env_int("LYNX_UNROLL", sizeof(T) == 4 ? (S > 1 ? 2 : 4) : 1);  // multi-step programs: fewer live particles
@@ -492,6 +495,9 @@ static TrackPlan plan_track(lynx_ctx* ctx, int64_t B, int64_t N, int32_t S, bool
     chunks = (ntiles + tpw - 1) / tpw;
     p.a.chunks = (int32_t)chunks;
     p.a.tiles_per_wg = (int32_t)tpw;
+    // float32 lane sums for the whole workgroup are fine while a lane sees few particles
+    if (p.mom_mode == 2 && !getenv("LYNX_MOM") && tpw * u <= 32) p.mom_mode = 3;
+    if (p.mom_mode == 3 && tpw * u > 64) p.mom_mode = 2;
     scratch_scalars = (scratch_scalars + 3) / 4 * 4;
     p.a.lds_tile_scalars = (int32_t)scratch_scalars;
     p.lds = ((size_t)scratch_scalars + (size_t)S * LYNX_STEP_STRIDE + S + 1) * sizeof(T);
@@ -585,6 +591,7 @@ static int launch_direct(lynx_ctx* ctx, const TrackPlan& p, const LatticeDev& lv
   }
   if (mom == 0) { LYNX_DU(0) }
   if (mom == 2) { LYNX_DU(2) }
+  if (mom == 3) { LYNX_DU(3) }
   LYNX_DU(1)
 #undef LYNX_DU
 #undef LYNX_D
@@ -646,8 +653,12 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
                                                    fused ? d_energy_out : nullptr, d_steps, d_partials, moments);
   if (rc) return rc;
   if (moments) {
-    hipLaunchKernelGGL(k_finalize_moments, dim3((unsigned)B), dim3(256), 0, ctx->stream, d_partials, p.a.chunks,
-                       d_moments_out);
+    if (p.a.chunks <= 64)
+      hipLaunchKernelGGL(k_finalize_moments_small, dim3((unsigned)B), dim3(64), 0, ctx->stream, d_partials,
+                         p.a.chunks, d_moments_out);
+    else
+      hipLaunchKernelGGL(k_finalize_moments, dim3((unsigned)B), dim3(256), 0, ctx->stream, d_partials, p.a.chunks,
+                         d_moments_out);
     HIP_TRY(ctx, hipGetLastError());
   }
   return LYNX_OK;

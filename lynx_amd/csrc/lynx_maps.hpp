@@ -374,6 +374,31 @@ LYNX_FN void build_element(int kind, int flags, const T* p, T energy, T* M, T* c
     case LYNX_KIND_HCOR: build_corrector(p, false, energy, M); break;
     case LYNX_KIND_VCOR: build_corrector(p, true, energy, M); break;
     case LYNX_KIND_CAVITY: build_cavity(p, flags, energy, M, coef); break;
+    case LYNX_KIND_BASE_RMATRIX:  // track_methods.py:37-105, p = [L, k1, hx, tilt]
+      build_base_rmatrix(p[0], p[1], p[2], energy, M);
+      if (flags & LYNX_FLAG_TILT) {
+        rot_left(M, t_cos(-p[3]), t_sin(-p[3]));
+        rot_right(M, t_cos(p[3]), t_sin(p[3]));
+      }
+      break;
+    case LYNX_KIND_ROTATION: {  // track_methods.py:14-34
+      const T cs = t_cos(p[0]), sn = t_sin(p[0]);
+      mat_identity(M);
+      M[0 * 7 + 0] = cs;
+      M[0 * 7 + 2] = sn;
+      M[1 * 7 + 1] = cs;
+      M[1 * 7 + 3] = sn;
+      M[2 * 7 + 0] = -sn;
+      M[2 * 7 + 2] = cs;
+      M[3 * 7 + 1] = -sn;
+      M[3 * 7 + 3] = cs;
+      break;
+    }
+    case LYNX_KIND_MISALIGNMENT:  // track_methods.py:108-122
+      mat_identity(M);
+      M[0 * 7 + 6] = p[2] * p[0];
+      M[2 * 7 + 6] = p[2] * p[1];
+      break;
     case LYNX_KIND_CUSTOM:
 #pragma unroll 1
       for (int i = 0; i < 49; ++i) M[i] = p[i];  // custom_transfer_map.py:87-88

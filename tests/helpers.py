@@ -51,7 +51,9 @@ def map_err(got, ref):
     assert got.shape == ref.shape
     nan_g, nan_r = np.isnan(got), np.isnan(ref)
     assert np.array_equal(nan_g, nan_r), "NaN pattern differs"
-    g, r = np.where(nan_g, 0.0, got), np.where(nan_r, 0.0, ref)
+    inf_g, inf_r = np.isinf(got), np.isinf(ref)
+    assert np.array_equal(inf_g, inf_r) and np.array_equal(np.sign(got[inf_g]), np.sign(ref[inf_r])), "inf pattern differs"
+    g, r = np.where(nan_g | inf_g, 0.0, got), np.where(nan_r | inf_r, 0.0, ref)
     denom = np.maximum(np.abs(r), 1e-3 * np.max(np.abs(r), axis=(-1, -2), keepdims=True)) + 1e-300
     return float(np.max(np.abs(g - r) / denom))
 

@@ -558,3 +558,27 @@ def test_rccl_communicator_single_rank(lx):
         assert np.array_equal(np.asarray(out)[0], np.asarray(local))
     finally:
         comm.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_track_methods_helpers(lx, dtype):
+    """lynx/track_methods.py public functions: rotation_matrix, base_rmatrix, misalignment_matrix."""
+    from lynx_amd import track_methods as tm
+
+    rng = np.random.default_rng(21)
+    ang = rng.uniform(-3, 3, (2, 3)).astype(dtype)
+    assert map_err(tm.rotation_matrix(ang), o.rotation_matrix(ang)) < TOL_MAP[dtype]
+    L, k1 = rng.uniform(0.1, 1, 5).astype(dtype), np.array([4.2, -4.2, 0.0, 1.0, -30.0], dtype)
+    hx, tilt = rng.uniform(-0.5, 0.5, 5).astype(dtype), np.array([0, 0.3, 0, -1.0, 0.785], dtype)
+    energy = np.array([1e8, 6e6, 2e7, 1e9, 1e8], dtype)
+    got = tm.base_rmatrix(L, k1, hx, tilt, energy)
+    ref = o.base_rmatrix(L, k1, hx, tilt, energy)
+    assert map_err(got, ref) < TOL_MAP[dtype] * 10
+    # energy defaults to 0 => beta = 0: the dispersion entries are 0/0 and inf - inf in the
+    # reference too (track_methods.py:61-83); same NaN pattern, finite entries equal
+    z = np.zeros_like(L)
+    assert map_err(tm.base_rmatrix(L, k1, z), o.base_rmatrix(L, k1, z)) < TOL_MAP[dtype] * 10
+    mis = rng.normal(0, 1e-3, (4, 2)).astype(dtype)
+    (g_in, g_out), (r_in, r_out) = tm.misalignment_matrix(mis), o.misalignment_matrix(mis)
+    assert np.array_equal(g_in, r_in) and np.array_equal(g_out, r_out)
+    assert np.isclose(tm.REST_ENERGY, o.REST_ENERGY, rtol=1e-13)
