@@ -171,6 +171,23 @@ int lynx_track_moments(lynx_ctx* ctx, lynx_lattice* lat, const void* d_energy_in
                        const void* d_mu_in, const void* d_cov_in, void* d_mu_out,
                        void* d_cov_out, void* d_energy_out);
 
+/* Reverse pass of lynx_track_particles: gradient of a scalar function L of the outgoing
+ * beam's moment record with respect to every element parameter and the incoming energy
+ * (the reference only claims differentiability, setup.py:14-17,
+ * tests/test_differentiable.py).
+ *   d_moments_fwd  [B][36] float64  the forward moment record (lynx_track_particles)
+ *   d_grad_moments [B][36] float64  dL/d(record): [0..6] d/dmean, [7..27] d/dcov (upper
+ *                                   triangle, each off-diagonal entry counted once)
+ *   d_grad_params  [B][E][8]        dL/d(parameter j of element e), parameter order of the
+ *                                   element kind; unused slots 0; custom maps: 0
+ *   d_grad_energy_in [B]            dL/d(incoming energy)
+ * Limits of this version: n_steps * 7 states of 256 particles must fit in LDS
+ * (n_steps <= 17 in float32, <= 8 in float64).                                             */
+int lynx_track_particles_backward(lynx_ctx* ctx, lynx_lattice* lat, int64_t n_particles,
+                                  const void* d_energy_in, const void* d_p_in,
+                                  const double* d_moments_fwd, const double* d_grad_moments,
+                                  void* d_grad_params, void* d_grad_energy_in);
+
 /* Moment read-out of an existing ParticleBeam (reference: particle_beam.py:736-836,
  * one fused pass instead of 14 separate reductions).  d_moments_out [B][36] float64.       */
 int lynx_moments(lynx_ctx* ctx, int dtype, int64_t batch, int64_t n_particles, const void* d_p,

@@ -82,6 +82,7 @@ SIGNATURES = {
     "lynx_build_compose": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "lynx_track_particles": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i]),
     "lynx_track_moments": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "lynx_track_particles_backward": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "lynx_moments": (_i, [_vp, _i, _i64, _i64, _vp, _vp]),
     "lynx_fill_gaussian": (_i, [_vp, _i, _i64, _i64, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                 C.c_uint64, _vp]),

@@ -1,0 +1,62 @@
+// Forward-mode dual numbers for the map builders.
+//
+// The reverse pass of the gradient (k_build_bwd) needs dM/dtheta for every element
+// parameter.  Instead of hand-deriving the partials of base_rmatrix / dipole edges / the
+// cavity's T566..T555 terms, the builders of lynx_maps.hpp are instantiated a second time
+// with T = Dual<float|double>: one seeded evaluation per (element, parameter) yields the
+// exact derivative of all 49 map entries and of the 8 cavity coefficients.
+// Comparisons act on the value part, so the builders take the same branches as the forward
+// pass (including `k1 == 0 -> 1e-12`, whose derivative is 0 exactly as in an autograd trace
+// of the reference).
+#pragma once
+
+#include "lynx_maps.hpp"
+
+namespace lynx {
+
+template <typename T> struct Dual {
+  T v, d;
+  LYNX_HD Dual() {}
+  template <typename U> LYNX_HD Dual(U x) : v(T(x)), d(T(0)) {}
+  LYNX_HD Dual(T v_, T d_) : v(v_), d(d_) {}
+};
+
+template <typename T> LYNX_HD Dual<T> operator+(Dual<T> a, Dual<T> b) { return Dual<T>(a.v + b.v, a.d + b.d); }
+template <typename T> LYNX_HD Dual<T> operator-(Dual<T> a, Dual<T> b) { return Dual<T>(a.v - b.v, a.d - b.d); }
+template <typename T> LYNX_HD Dual<T> operator-(Dual<T> a) { return Dual<T>(-a.v, -a.d); }
+template <typename T> LYNX_HD Dual<T> operator*(Dual<T> a, Dual<T> b) {
+  return Dual<T>(a.v * b.v, a.d * b.v + a.v * b.d);
+}
+template <typename T> LYNX_HD Dual<T> operator/(Dual<T> a, Dual<T> b) {
+  const T q = a.v / b.v;
+  return Dual<T>(q, (a.d - q * b.d) / b.v);
+}
+template <typename T> LYNX_HD bool operator==(Dual<T> a, Dual<T> b) { return a.v == b.v; }
+template <typename T> LYNX_HD bool operator!=(Dual<T> a, Dual<T> b) { return a.v != b.v; }
+template <typename T> LYNX_HD bool operator>(Dual<T> a, Dual<T> b) { return a.v > b.v; }
+template <typename T> LYNX_HD bool operator<(Dual<T> a, Dual<T> b) { return a.v < b.v; }
+
+// d/dx: sqrt -> 1/(2 sqrt x); sin -> cos; cos -> -sin; tan -> 1 + tan^2; sinh -> cosh;
+// cosh -> sinh; log -> 1/x
+#define LYNX_DUAL_FN(R, NAME, DERIV)                               \
+  template <> LYNX_FN Dual<R> NAME<Dual<R>>(Dual<R> x) {           \
+    const R f = NAME<R>(x.v);                                      \
+    return Dual<R>(f, (DERIV)*x.d);                                \
+  }
+#define LYNX_DUAL_ALL(R)                                           \
+  LYNX_DUAL_FN(R, t_sqrt, (R(0.5) / f))                            \
+  LYNX_DUAL_FN(R, t_sin, (t_cos<R>(x.v)))                          \
+  LYNX_DUAL_FN(R, t_cos, (-t_sin<R>(x.v)))                         \
+  LYNX_DUAL_FN(R, t_tan, (R(1) + f * f))                           \
+  LYNX_DUAL_FN(R, t_sinh, (t_cosh<R>(x.v)))                        \
+  LYNX_DUAL_FN(R, t_cosh, (t_sinh<R>(x.v)))                        \
+  LYNX_DUAL_FN(R, t_log, (R(1) / x.v))
+LYNX_DUAL_ALL(float)
+LYNX_DUAL_ALL(double)
+#undef LYNX_DUAL_ALL
+#undef LYNX_DUAL_FN
+
+template <> LYNX_HD Dual<float> t_fma<Dual<float>>(Dual<float> a, Dual<float> b, Dual<float> c) { return a * b + c; }
+template <> LYNX_HD Dual<double> t_fma<Dual<double>>(Dual<double> a, Dual<double> b, Dual<double> c) { return a * b + c; }
+
+}  // namespace lynx

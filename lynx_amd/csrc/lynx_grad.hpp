@@ -1,0 +1,384 @@
+// Reverse pass: gradient of a scalar function of the OUTPUT-BEAM MOMENTS with respect to
+// every element parameter and the incoming beam energy (BASELINE
+// config 5).  The reference has no implementation of this (its differentiability tests
+// still assert torch `grad_fn`, tests/test_differentiable.py:28-51); the checker is central
+// finite differences of the oracle's forward pass (tests/test_gpu_grad.py).
+//
+// Forward, per sample:   theta --build--> M_e --compose--> T_s, coef_s --stream--> z_out
+//                        --reduce--> (mean, cov) --user--> L
+// Reverse:
+//   k_track_bwd   z_bar = dL/dz_out from (mean_bar, cov_bar); walks the steps backwards per
+//                 particle (forward states parked in LDS), z_bar <- T_s^T z_bar (+ cavity
+//                 terms), and accumulates  T_bar_s = sum_n z_bar_n (x) z_n^(s)  and the
+//                 cavity-coefficient cotangents.  The 64-lane sum of outer products is done
+//                 as a 7x64 . 64x7 product through a per-wave LDS exchange buffer (one lane
+//                 per output entry), not as 57 separate lane reductions.
+//                 (fp32 MFMA was evaluated for this 7 x K GEMM: it runs at the VALU rate and
+//                 padding 7 -> 16 wastes 81 % of it.)
+//   k_reduce_tbar partial sums over a sample's workgroups -> T_bar[B][S][64]
+//   k_build_bwd   per sample: prefix products P_j = M_j ... M_1, reverse sweep
+//                 M_bar_j = A P_{j-1}^T, A <- M_j^T A, then theta_bar = <M_bar, dM/dtheta>
+//                 with dM/dtheta from a dual-number evaluation of the very same builders, and
+//                 the energy cotangent chained back through the cavities' energy gains.
+#pragma once
+
+#include "lynx_device.hpp"
+#include "lynx_dual.hpp"
+
+namespace lynx {
+
+constexpr int kGradStride = 64;   // per (sample, step): 49 T_bar + 8 coef_bar + padding
+constexpr int kGradParams = 8;    // gradient slots per element (kinds with <= 8 parameters)
+
+struct BwdArgs {
+  int64_t n_particles;
+  int32_t chunks;
+  int32_t tiles_per_wg;  // tiles of 256 particles
+};
+
+// ---------------------------------------------------------------------------------------
+// k_track_bwd: grid = B * chunks workgroups of 256 threads, one particle per thread and tile.
+// LDS: state stack [S][7][256] T | exchange [4][22][64] T | accumulators [4][S][64] T
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
+    LatticeDev lat, BwdArgs a, const T* __restrict__ p_in, const T* __restrict__ steps,
+    const double* __restrict__ moments_fwd, const double* __restrict__ grad_moments,
+    T* __restrict__ partials /* [B][chunks][S][64] */) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int S = lat.n_steps;
+  T* s_stack = reinterpret_cast<T*>(smem_raw);               // [S][7][256]
+  T* s_ex = s_stack + (size_t)S * 7 * kTrackThreads;         // [4][22][64]
+  T* s_acc = s_ex + 4 * 22 * 64;                             // [4][S][64]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t b = blockIdx.x / a.chunks;
+  const int chunk = blockIdx.x % a.chunks;
+  const int64_t N = a.n_particles;
+  const T* g_steps = steps + b * (int64_t)S * LYNX_STEP_STRIDE;
+  T* ex = s_ex + wave * (22 * 64);
+  T* acc = s_acc + wave * (S * 64);
+
+  for (int s = 0; s < S; ++s) acc[s * 64 + lane] = T(0);
+
+  // per-sample constants of the moment cotangent
+  const double* rec = moments_fwd + b * LYNX_MOMENT_STRIDE;
+  const double* gm = grad_moments + b * LYNX_MOMENT_STRIDE;
+  const T inv_n = (T)(1.0 / rec[35]);
+  T mean[6], mu_bar[7], G[21];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) mean[i] = (T)rec[i];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) mu_bar[i] = (T)gm[i];
+#pragma unroll
+  for (int i = 0; i < 21; ++i) G[i] = (T)gm[7 + i];
+
+  const T* src = p_in + b * N * 7;
+  for (int it = 0; it < a.tiles_per_wg; ++it) {
+    const int64_t i = ((int64_t)chunk * a.tiles_per_wg + it) * kTrackThreads + tid;
+    if (((int64_t)chunk * a.tiles_per_wg + it) * kTrackThreads >= N) break;  // uniform
+    const bool live = i < N;
+    T z[7];
+    load_particle<false>(src + (live ? i : 0) * 7, z);
+
+    // forward, parking the input state of every step
+    for (int s = 0; s < S; ++s) {
+      const lynx_step st = lat.steps[s];
+      T m[57];
+#pragma unroll
+      for (int q = 0; q < 57; ++q) m[q] = g_steps[s * LYNX_STEP_STRIDE + q];
+#pragma unroll
+      for (int c = 0; c < 7; ++c) s_stack[(s * 7 + c) * kTrackThreads + tid] = z[c];
+      apply_step<T>(m, st.kind, st.flags, z);
+    }
+
+    // cotangent of the outgoing particle: (1/N) (mu_bar + G_hat (z - mean)), G_hat built from
+    // the upper-triangle cotangent (diagonal counted twice)
+    T zb[7];
+    {
+      T d[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) d[k] = z[k] - mean[k];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        T accv = mu_bar[k];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const int r = k < j ? k : j, c = k < j ? j : k;
+          const T g = G[r * 6 - (r * (r - 1)) / 2 + (c - r)];
+          accv = t_fma(k == j ? g + g : g, d[j], accv);
+        }
+        zb[k] = live ? accv * inv_n : T(0);
+      }
+      zb[6] = live ? mu_bar[6] * inv_n : T(0);
+    }
+
+    for (int s = S - 1; s >= 0; --s) {
+      const lynx_step st = lat.steps[s];
+      T m[57];
+#pragma unroll
+      for (int q = 0; q < 57; ++q) m[q] = g_steps[s * LYNX_STEP_STRIDE + q];
+      T zin[7];
+#pragma unroll
+      for (int c = 0; c < 7; ++c) zin[c] = s_stack[(s * 7 + c) * kTrackThreads + tid];
+
+      T olin[7], cc[8], dir4 = T(0), dir5 = T(0);
+#pragma unroll
+      for (int c = 0; c < 7; ++c) olin[c] = zb[c];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) cc[c] = T(0);
+      if (st.kind == LYNX_STEP_CAVITY && (st.flags & LYNX_FLAG_CAV_GAIN)) {
+        // o5' = z5 c0 + c1 (cos(a) - c4), a = -z4 c2 + c3 ; o4' = o4 + c5 z5^2 + c6 z4 z5 + c7 z4^2
+        const T* cf = m + LYNX_COEF_OFFSET;
+        const T z4 = zin[4], z5 = zin[5], o4b = zb[4], o5b = zb[5];
+        const T arg = T(-1) * z4 * cf[LYNX_C_BK] + cf[LYNX_C_PHI];
+        const T ca = t_cos(arg), sa = t_sin(arg);
+        const T ab = -o5b * cf[LYNX_C_DKICK] * sa;
+        cc[LYNX_C_DSCALE] = o5b * z5;
+        cc[LYNX_C_DKICK] = o5b * (ca - cf[LYNX_C_COSPHI]);
+        cc[LYNX_C_BK] = ab * (-z4);
+        cc[LYNX_C_PHI] = ab;
+        cc[LYNX_C_COSPHI] = -o5b * cf[LYNX_C_DKICK];
+        cc[LYNX_C_T566] = o4b * (z5 * z5);
+        cc[LYNX_C_T556] = o4b * (z4 * z5);
+        cc[LYNX_C_T555] = o4b * (z4 * z4);
+        dir4 = ab * (-cf[LYNX_C_BK]) + o4b * (cf[LYNX_C_T556] * z5 + T(2) * cf[LYNX_C_T555] * z4);
+        dir5 = o5b * cf[LYNX_C_DSCALE] + o4b * (T(2) * cf[LYNX_C_T566] * z5 + cf[LYNX_C_T556] * z4);
+        olin[5] = T(0);  // the linear delta was overwritten
+      }
+
+      // 64-lane sums through the wave's exchange buffer
+#pragma unroll
+      for (int c = 0; c < 7; ++c) ex[c * 64 + lane] = olin[c];
+#pragma unroll
+      for (int c = 0; c < 7; ++c) ex[(7 + c) * 64 + lane] = zin[c];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) ex[(14 + c) * 64 + lane] = cc[c];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (lane < 57) {
+        T sum = T(0);
+        if (lane < 49) {
+          const T* ra = ex + (lane / 7) * 64;
+          const T* rb = ex + (7 + lane % 7) * 64;
+#pragma unroll 16
+          for (int l = 0; l < 64; ++l) sum = t_fma(ra[l], rb[l], sum);
+        } else {
+          const T* rc = ex + (14 + lane - 49) * 64;
+#pragma unroll 16
+          for (int l = 0; l < 64; ++l) sum += rc[l];
+        }
+        acc[s * 64 + lane] += sum;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+      // z_bar_in = T^T o_lin (+ direct cavity terms)
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        T v = m[0 * 7 + j] * olin[0];
+#pragma unroll
+        for (int r = 1; r < 7; ++r) v = t_fma(m[r * 7 + j], olin[r], v);
+        zb[j] = v;
+      }
+      zb[4] += dir4;
+      zb[5] += dir5;
+    }
+  }
+
+  __syncthreads();
+  T* out = partials + (((int64_t)b * a.chunks + chunk) * S) * kGradStride;
+  for (int idx = tid; idx < S * 64; idx += kTrackThreads) {
+    out[idx] = ((s_acc[idx] + s_acc[S * 64 + idx]) + s_acc[2 * S * 64 + idx]) + s_acc[3 * S * 64 + idx];
+  }
+}
+
+// partials [B][chunks][S][64] -> tbar [B][S][64]; one 64-thread workgroup per (sample, step)
+template <typename T>
+__global__ __launch_bounds__(64) void k_reduce_tbar(const T* __restrict__ partials, int chunks, int S,
+                                                     T* __restrict__ tbar) {
+  const int64_t b = blockIdx.x / S;
+  const int s = blockIdx.x % S;
+  const int lane = threadIdx.x;
+  double v = 0.0;
+  for (int c = 0; c < chunks; ++c) v += (double)partials[((b * chunks + c) * S + s) * (int64_t)kGradStride + lane];
+  tbar[(b * S + s) * (int64_t)kGradStride + lane] = (T)v;
+}
+
+// ---------------------------------------------------------------------------------------
+// k_build_bwd: one 256-thread workgroup per sample.
+//   scratch (HBM, per sample): maps [E][49] and prefix/M_bar [E+1][49]
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_build_bwd(LatticeDev lat, const T* __restrict__ energy_in,
+                                                    const T* __restrict__ tbar, T* __restrict__ scratch,
+                                                    T* __restrict__ grad_params /* [B][E][8] */,
+                                                    T* __restrict__ grad_energy /* [B] */) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int E = lat.n_elems, S = lat.n_steps;
+  T* s_energy = reinterpret_cast<T*>(smem_raw);  // [S+1]
+  T* s_ebar = s_energy + (S + 1);                // [S+1] energy cotangent per step
+  T* s_econ = s_ebar + (S + 1);                  // [E]   per-element contribution to its step's energy cotangent
+  T* s_a = s_econ + E;                           // [49]  running cotangent A
+  T* s_t = s_a + 49;                             // [49]  temp
+
+  const int tid = threadIdx.x;
+  const int64_t b = blockIdx.x;
+  const T* pool = static_cast<const T*>(lat.pool);
+  T* g_maps = scratch + b * (int64_t)(2 * E + S + 1) * 49;  // M_e
+  // prefix products of step s live in slots [first+s .. last+s]: slot(first+s) = start
+  // (identity), slot(e+s+1) = M_e ... M_first; the reverse sweep then overwrites slot(e+s+1)
+  // with M_bar_e.  (The +s keeps neighbouring steps from sharing a slot.)
+  T* g_pref = g_maps + (int64_t)E * 49;
+
+  // energies (same walk as the forward build)
+  if (tid == 0) {
+    T e = energy_in[b];
+    for (int s = 0; s < S; ++s) {
+      s_energy[s] = e;
+      lynx_step st = lat.steps[s];
+      if (st.kind == LYNX_STEP_CAVITY && (st.flags & LYNX_FLAG_CAV_GAIN)) {
+        lynx_elem el = lat.elems[st.first];
+        const T* p = pool + el.param_offset + b * (int64_t)el.batch_stride;
+        e = e + p[1] * t_cos(p[2] * T(LYNX_PI / 180.0));
+      }
+    }
+    s_energy[S] = e;
+    for (int s = 0; s <= S; ++s) s_ebar[s] = T(0);
+  }
+  __syncthreads();
+
+  // 1. element maps -> HBM scratch
+  for (int e = tid; e < E; e += blockDim.x) {
+    lynx_elem el = lat.elems[e];
+    const int s = lat.elem_step[e];
+    const T* p = pool + el.param_offset + b * (int64_t)el.batch_stride;
+    T coef_unused[8];
+    build_element<T>(el.kind, el.flags, p, s_energy[s], g_maps + (int64_t)e * 49,
+                     lat.steps[s].kind == LYNX_STEP_CAVITY ? coef_unused : nullptr);
+  }
+  __threadfence_block();
+  __syncthreads();
+
+  // 2. per step: prefix products forward, cotangent sweep backward (49 threads, one per entry)
+  for (int s = 0; s < S; ++s) {
+    const lynx_step st = lat.steps[s];
+    const T* tb = tbar + (b * S + s) * (int64_t)kGradStride;
+    const bool raw = st.kind == LYNX_STEP_CAVITY || (st.flags & LYNX_STEP_FLAG_RAW);
+    // prefix: slot(e) = product of the step's elements up to and including e; slot(first-1)
+    // is the start (identity); a raw step's first element has no predecessor product
+    if (tid < 49) g_pref[(int64_t)(st.first + s) * 49 + tid] = (tid % 8 == 0) ? T(1) : T(0);
+    __threadfence_block();
+    __syncthreads();
+    for (int e = st.first; e < st.last; ++e) {
+      T v = T(0);
+      if (tid < 49) v = mat_product_entry<T>(g_maps + (int64_t)e * 49, g_pref + (int64_t)(e + s) * 49, tid);
+      if (tid < 49) g_pref[(int64_t)(e + s + 1) * 49 + tid] = v;
+      __threadfence_block();
+      __syncthreads();
+    }
+    if (tid < 49) s_a[tid] = tb[tid];
+    __syncthreads();
+    for (int e = st.last - 1; e >= st.first; --e) {
+      // M_bar_e = A . P_{e-1}^T ;  A <- M_e^T . A
+      T mb = T(0), an = T(0);
+      if (tid < 49) {
+        const int i = tid / 7, j = tid - i * 7;
+        const T* P = g_pref + (int64_t)(e + s) * 49;
+        const T* M = g_maps + (int64_t)e * 49;
+        if (raw && e == st.first) {
+          mb = s_a[tid];  // the map itself is the step's product start
+        } else {
+          T accv = s_a[i * 7] * P[j * 7];
+#pragma unroll
+          for (int k = 1; k < 7; ++k) accv = t_fma(s_a[i * 7 + k], P[j * 7 + k], accv);
+          mb = accv;
+        }
+        T acc2 = M[0 * 7 + i] * s_a[0 * 7 + j];
+#pragma unroll
+        for (int k = 1; k < 7; ++k) acc2 = t_fma(M[k * 7 + i], s_a[k * 7 + j], acc2);
+        an = acc2;
+      }
+      __syncthreads();
+      if (tid < 49) {
+        s_a[tid] = an;
+        s_t[tid] = mb;
+      }
+      __syncthreads();
+      if (tid < 49) g_pref[(int64_t)(e + s + 1) * 49 + tid] = s_t[tid];  // this slot now holds M_bar_e
+      __threadfence_block();
+      __syncthreads();
+    }
+  }
+
+  // 3. theta_bar = <M_bar, dM/dtheta> (+ <coef_bar, dcoef/dtheta>) by dual evaluation; one task
+  //    per (element, parameter), parameter index np = derivative w.r.t. the step energy
+  for (int task = tid; task < E * (kGradParams + 1); task += blockDim.x) {
+    const int e = task / (kGradParams + 1), pidx = task % (kGradParams + 1);
+    lynx_elem el = lat.elems[e];
+    int np = 0;
+    switch (el.kind) {
+      case LYNX_KIND_DRIFT: np = 1; break;
+      case LYNX_KIND_QUADRUPOLE: np = 5; break;
+      case LYNX_KIND_DIPOLE: np = 8; break;
+      case LYNX_KIND_HCOR:
+      case LYNX_KIND_VCOR: np = 2; break;
+      case LYNX_KIND_CAVITY: np = 4; break;
+      case LYNX_KIND_BASE_RMATRIX: np = 4; break;
+      case LYNX_KIND_ROTATION: np = 1; break;
+      case LYNX_KIND_MISALIGNMENT: np = 3; break;
+      default: np = 0; break;  // identity; custom maps carry no differentiable parameters here
+    }
+    const bool energy_task = pidx == kGradParams;
+    T g = T(0);
+    if ((pidx < np || energy_task) && np > 0) {
+      const int s = lat.elem_step[e];
+      const T* p = pool + el.param_offset + b * (int64_t)el.batch_stride;
+      Dual<T> dp[8];
+      for (int q = 0; q < 8; ++q) dp[q] = Dual<T>(q < np ? p[q] : T(0), (q == pidx) ? T(1) : T(0));
+      const Dual<T> de(s_energy[s], energy_task ? T(1) : T(0));
+      Dual<T> dM[49], dC[8];
+      const bool cav_step = lat.steps[s].kind == LYNX_STEP_CAVITY;
+      for (int q = 0; q < 8; ++q) dC[q] = Dual<T>(T(0));
+      build_element<Dual<T>>(el.kind, el.flags, dp, de, dM, cav_step ? dC : nullptr);
+      const T* mb = g_pref + (int64_t)(e + s + 1) * 49;
+      for (int q = 0; q < 49; ++q) {
+        const T w = mb[q];
+        if (w != T(0)) g = t_fma(w, dM[q].d, g);  // 0 * (inf or NaN derivative) must not poison the sum
+      }
+      if (cav_step) {
+        const T* cb = tbar + (b * S + s) * (int64_t)kGradStride + LYNX_COEF_OFFSET;
+        for (int q = 0; q < 8; ++q) {
+          const T w = cb[q];
+          if (w != T(0)) g = t_fma(w, dC[q].d, g);
+        }
+      }
+    }
+    if (energy_task) s_econ[e] = g;
+    else grad_params[(b * E + e) * (int64_t)kGradParams + pidx] = g;
+  }
+  __syncthreads();
+
+  // 4. energy cotangent: sum per step, then back through the cavities' energy gains
+  if (tid == 0) {
+    for (int e = 0; e < E; ++e) s_ebar[lat.elem_step[e]] += s_econ[e];
+    T carry = T(0);  // cotangent of the energy leaving step s
+    for (int s = S - 1; s >= 0; --s) {
+      const lynx_step st = lat.steps[s];
+      if (st.kind == LYNX_STEP_CAVITY && (st.flags & LYNX_FLAG_CAV_GAIN)) {
+        lynx_elem el = lat.elems[st.first];
+        const T* p = pool + el.param_offset + b * (int64_t)el.batch_stride;
+        const T phi = p[2] * T(LYNX_PI / 180.0);
+        T* gp = grad_params + (b * E + st.first) * (int64_t)kGradParams;
+        gp[1] += carry * t_cos(phi);                                   // dE_out/dV
+        gp[2] += carry * (-p[1] * t_sin(phi)) * T(LYNX_PI / 180.0);    // dE_out/dphase[deg]
+      }
+      carry += s_ebar[s];
+    }
+    grad_energy[b] = carry;
+  }
+}
+
+}  // namespace lynx

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "lynx_device.hpp"
+#include "lynx_grad.hpp"
 
 using namespace lynx;
 
@@ -32,6 +33,8 @@ struct lynx_ctx {
   size_t scratch_partials_bytes = 0;
   void* scratch_steps = nullptr;
   size_t scratch_steps_bytes = 0;
+  void* scratch_grad[3] = {nullptr, nullptr, nullptr};  // backward: partials, T_bar, build scratch
+  size_t scratch_grad_bytes[3] = {0, 0, 0};
   ncclComm_t comm = nullptr;
   int comm_ranks = 0;
   // per-launch profiling of k_track (lynx_profile_begin / _end)
@@ -173,6 +176,8 @@ int lynx_ctx_destroy(lynx_ctx* ctx) {
   for (auto& kv : ctx->live) (void)hipFree(kv.first);
   if (ctx->scratch_partials) (void)hipFree(ctx->scratch_partials);
   if (ctx->scratch_steps) (void)hipFree(ctx->scratch_steps);
+  for (int i = 0; i < 3; ++i)
+    if (ctx->scratch_grad[i]) (void)hipFree(ctx->scratch_grad[i]);
   (void)hipEventDestroy(ctx->ev_start);
   (void)hipEventDestroy(ctx->ev_stop);
   (void)hipStreamDestroy(ctx->stream);
@@ -679,6 +684,75 @@ int lynx_track_particles(lynx_ctx* ctx, lynx_lattice* lat, int64_t n_particles, 
                                          d_energy_out, d_moments_out, flags)
              : track_particles_t<float>(ctx, lat, lv, lat->batch, n_particles, d_energy_in, d_p_in, d_p_out,
                                         d_energy_out, d_moments_out, flags);
+}
+
+// ---- reverse pass -----------------------------------------------------------------------
+
+template <typename T>
+static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const void* d_energy_in, const void* d_p_in,
+                            const double* d_moments_fwd, const double* d_grad_moments, void* d_grad_params,
+                            void* d_grad_energy_in) {
+  const int64_t B = lat->batch;
+  const int32_t S = lat->n_steps, E = lat->n_elems;
+  int rc;
+  // forward step tables
+  const size_t steps_bytes = (size_t)B * S * LYNX_STEP_STRIDE * sizeof(T);
+  if ((rc = ensure_scratch(ctx, &ctx->scratch_steps, &ctx->scratch_steps_bytes, steps_bytes))) return rc;
+  if ((rc = launch_build<T>(ctx, lat, d_energy_in, ctx->scratch_steps, nullptr))) return rc;
+
+  const int64_t cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+  const int64_t ntiles = (N + kTrackThreads - 1) / kTrackThreads;
+  int64_t chunks = std::max<int64_t>(1, std::min<int64_t>(ntiles, (8 * cus + B - 1) / B));
+  const int64_t tpw = (ntiles + chunks - 1) / chunks;
+  chunks = (ntiles + tpw - 1) / tpw;
+  BwdArgs a;
+  a.n_particles = N;
+  a.chunks = (int32_t)chunks;
+  a.tiles_per_wg = (int32_t)tpw;
+  const size_t lds = ((size_t)S * 7 * kTrackThreads + 4 * 22 * 64 + (size_t)4 * S * 64) * sizeof(T);
+  if (lds > 160 * 1024)
+    return fail(ctx, LYNX_ERR_INVALID,
+                "lynx_track_particles_backward: " + std::to_string(S) + " steps need " + std::to_string(lds) +
+                    " B of LDS for the state stack (limit 160 KiB: 17 steps in float32, 8 in float64)");
+  if ((rc = allow_lds(ctx, k_track_bwd<T>, lds))) return rc;
+  if ((int64_t)B * chunks > 0x7fffffffLL || (int64_t)B * S > 0x7fffffffLL) return fail(ctx, LYNX_ERR_INVALID, "grid too large");
+  if ((rc = ensure_scratch(ctx, &ctx->scratch_grad[0], &ctx->scratch_grad_bytes[0],
+                           (size_t)B * chunks * S * kGradStride * sizeof(T))))
+    return rc;
+  if ((rc = ensure_scratch(ctx, &ctx->scratch_grad[1], &ctx->scratch_grad_bytes[1], (size_t)B * S * kGradStride * sizeof(T))))
+    return rc;
+  if ((rc = ensure_scratch(ctx, &ctx->scratch_grad[2], &ctx->scratch_grad_bytes[2],
+                           (size_t)B * (2 * E + S + 1) * 49 * sizeof(T))))
+    return rc;
+  LatticeDev lv = dev_view(lat);
+  hipLaunchKernelGGL(k_track_bwd<T>, dim3((unsigned)(B * chunks)), dim3(kTrackThreads), lds, ctx->stream, lv, a,
+                     (const T*)d_p_in, (const T*)ctx->scratch_steps, d_moments_fwd, d_grad_moments,
+                     (T*)ctx->scratch_grad[0]);
+  HIP_TRY(ctx, hipGetLastError());
+  hipLaunchKernelGGL(k_reduce_tbar<T>, dim3((unsigned)(B * S)), dim3(64), 0, ctx->stream, (const T*)ctx->scratch_grad[0],
+                     (int)chunks, (int)S, (T*)ctx->scratch_grad[1]);
+  HIP_TRY(ctx, hipGetLastError());
+  const size_t lds2 = ((size_t)2 * (S + 1) + E + 49 + 49) * sizeof(T);
+  if ((rc = allow_lds(ctx, k_build_bwd<T>, lds2))) return rc;
+  HIP_TRY(ctx, hipMemsetAsync(d_grad_params, 0, (size_t)B * E * kGradParams * sizeof(T), ctx->stream));
+  hipLaunchKernelGGL(k_build_bwd<T>, dim3((unsigned)B), dim3(256), lds2, ctx->stream, lv, (const T*)d_energy_in,
+                     (const T*)ctx->scratch_grad[1], (T*)ctx->scratch_grad[2], (T*)d_grad_params, (T*)d_grad_energy_in);
+  HIP_TRY(ctx, hipGetLastError());
+  return LYNX_OK;
+}
+
+int lynx_track_particles_backward(lynx_ctx* ctx, lynx_lattice* lat, int64_t n_particles, const void* d_energy_in,
+                                  const void* d_p_in, const double* d_moments_fwd, const double* d_grad_moments,
+                                  void* d_grad_params, void* d_grad_energy_in) {
+  if (!ctx || !lat || !d_energy_in || !d_p_in || !d_moments_fwd || !d_grad_moments || !d_grad_params || !d_grad_energy_in)
+    return fail(ctx, LYNX_ERR_INVALID, "null argument");
+  if (n_particles <= 0 || lat->n_steps <= 0) return fail(ctx, LYNX_ERR_INVALID, "empty program or beam");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  return lat->dtype == LYNX_F64
+             ? track_backward_t<double>(ctx, lat, n_particles, d_energy_in, d_p_in, d_moments_fwd, d_grad_moments,
+                                        d_grad_params, d_grad_energy_in)
+             : track_backward_t<float>(ctx, lat, n_particles, d_energy_in, d_p_in, d_moments_fwd, d_grad_moments,
+                                       d_grad_params, d_grad_energy_in);
 }
 
 int lynx_moments(lynx_ctx* ctx, int dtype, int64_t batch, int64_t n_particles, const void* d_p,

@@ -159,6 +159,39 @@ class ParticleBeam(Beam):
                                    total_charge=d("total_charge", 0.0), dtype=dtype, seed=seed)
 
     @classmethod
+    def uniform_3d_ellipsoid(cls, num_particles=None, radius_x=None, radius_y=None, radius_s=None, sigma_xp=None,
+                             sigma_yp=None, sigma_p=None, energy=None, total_charge=None, device=None,
+                             dtype=np.float32, seed=None) -> "ParticleBeam":
+        """
+        Particles uniformly distributed inside an ellipsoid in (x, y, s) (waterbag), Gaussian in
+        the momenta (particle_beam.py:266-385; rejection sampling as there).
+        """
+        dtype = np.dtype(dtype)
+        g, shape = _batch_args(dict(radius_x=radius_x, radius_y=radius_y, radius_s=radius_s, sigma_xp=sigma_xp,
+                                    sigma_yp=sigma_yp, sigma_p=sigma_p, energy=energy, total_charge=total_charge),
+                               dtype)
+        n = int(num_particles) if num_particles is not None else 1_000_000
+        rx, ry, rs = (g.get(k, np.full(shape, 1e-3, dtype)) for k in ("radius_x", "radius_y", "radius_s"))
+        rng = np.random.default_rng(seed)
+        xyz = np.empty((int(np.prod(shape)), n, 3), dtype=dtype)
+        for i, (a, b, c) in enumerate(zip(rx.reshape(-1), ry.reshape(-1), rs.reshape(-1))):
+            filled = 0
+            while filled < n:
+                cand = (rng.random((n, 3)) - 0.5) * 2 * np.array([a, b, c])
+                inside = cand[(cand[:, 0] / a) ** 2 + (cand[:, 1] / b) ** 2 + (cand[:, 2] / c) ** 2 < 1]
+                take = min(n - filled, len(inside))
+                xyz[i, filled:filled + take] = inside[:take]
+                filled += take
+        beam = cls.from_parameters(num_particles=n, mu_xp=np.full(shape, 0.0, dtype), mu_yp=np.full(shape, 0.0, dtype),
+                                   sigma_xp=g.get("sigma_xp"), sigma_yp=g.get("sigma_yp"), sigma_p=g.get("sigma_p"),
+                                   energy=g.get("energy"), total_charge=g.get("total_charge"), dtype=dtype, seed=seed)
+        host = np.array(beam._particles.host())
+        xyz = xyz.reshape(*shape, n, 3)
+        host[..., 0], host[..., 2], host[..., 4] = xyz[..., 0], xyz[..., 1], xyz[..., 2]
+        beam._particles = Dual(host)
+        return beam
+
+    @classmethod
     def make_linspaced(cls, num_particles=None, mu_x=None, mu_y=None, mu_xp=None, mu_yp=None, sigma_x=None,
                        sigma_y=None, sigma_xp=None, sigma_yp=None, sigma_s=None, sigma_p=None, energy=None,
                        total_charge=None, device=None, dtype=np.float32) -> "ParticleBeam":

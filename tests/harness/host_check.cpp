@@ -24,3 +24,17 @@ void harness_kick_f64(const double* coef, double s_in, double d_in, double* s_io
   lynx::cavity_kick<double>(coef, s_in, d_in, *s_io, *d_out);
 }
 }
+
+// Dual-number evaluation of the same builders (lynx_dual.hpp): value and derivative w.r.t.
+// parameter `seed` (seed == n_params: derivative w.r.t. the beam energy).
+#include "../../lynx_amd/csrc/lynx_dual.hpp"
+extern "C" void harness_build_dual_f64(int kind, int flags, const double* p, int n_params, double energy, int seed,
+                                       double* M, double* dM, double* coef, double* dcoef, int want_coef) {
+  lynx::Dual<double> dp[49], dm[49], dc[8];
+  for (int q = 0; q < 49; ++q) dp[q] = lynx::Dual<double>(q < n_params ? p[q] : 0.0, q == seed ? 1.0 : 0.0);
+  for (int q = 0; q < 8; ++q) dc[q] = lynx::Dual<double>(0.0);
+  lynx::Dual<double> de(energy, seed == n_params ? 1.0 : 0.0);
+  lynx::build_element<lynx::Dual<double>>(kind, flags, dp, de, dm, want_coef ? dc : nullptr);
+  for (int q = 0; q < 49; ++q) { M[q] = dm[q].v; dM[q] = dm[q].d; }
+  for (int q = 0; q < 8; ++q) { coef[q] = dc[q].v; dcoef[q] = dc[q].d; }
+}

@@ -1,0 +1,125 @@
+"""
+Gradients of the outgoing moments w.r.t. element parameters (lynx_track_particles_backward)
+against central finite differences of the ORACLE's forward pass in float64.  The reference
+has no gradient implementation to compare with (parity unpinned).
+"""
+
+import numpy as np
+import pytest
+
+from oracle import lynx_oracle as o
+
+from .helpers import make_lattice
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lx(built_library):
+    import lynx_amd
+    import lynx_amd.grad  # noqa: F401
+
+    lynx_amd.device.get_runtime()
+    return lynx_amd
+
+
+def _loss(specs, P, energy, w_mu, w_cov):
+    out = o.segment_track(specs, o.particle_beam(P, energy, np.float64), np.float64)
+    Q = out["particles"][..., :6]
+    mu = Q.mean(axis=-2)
+    d = Q - mu[..., None, :]
+    cov = np.einsum("...ni,...nj->...ij", d, d) / Q.shape[-2]
+    return np.sum(w_mu * mu, axis=-1) + np.sum(w_cov * cov, axis=(-1, -2))  # (B,)
+
+
+def _desc(B, rng):
+    f = lambda v: np.full(B, v)  # noqa: E731
+    return [("drift", dict(length=f(0.6))),
+            ("quadrupole", dict(length=f(0.2), k1=rng.uniform(-5, 5, B), tilt=rng.uniform(-0.5, 0.5, B),
+                                misalignment=rng.normal(0, 1e-3, (B, 2)))),
+            ("hcor", dict(length=f(0.1), angle=rng.normal(0, 1e-3, B))),
+            ("cavity", dict(length=f(1.0377), voltage=rng.uniform(5e6, 2e7, B), phase=rng.uniform(-10, 10, B),
+                            frequency=f(1.3e9))),
+            ("dipole", dict(length=f(0.5), angle=rng.uniform(0.05, 0.2, B), e1=f(0.05), e2=f(0.02),
+                            fringe_integral=f(0.4), fringe_integral_exit=f(0.3), gap=f(0.02), tilt=f(0.1))),
+            ("vcor", dict(length=f(0.1), angle=rng.normal(0, 1e-3, B))),
+            ("cavity", dict(length=f(1.0), voltage=rng.uniform(5e6, 2e7, B), phase=f(3.0), frequency=f(1.3e9))),
+            ("quadrupole", dict(length=f(0.3), k1=rng.uniform(-5, 5, B))),
+            ("drift", dict(length=f(0.4)))]
+
+
+PARAMS_TO_CHECK = {"drift": ["length"], "quadrupole": ["length", "k1", "tilt", "misalignment"],
+                   "hcor": ["length", "angle"], "vcor": ["angle"], "cavity": ["length", "voltage", "phase", "frequency"],
+                   "dipole": ["length", "angle", "e1", "e2", "tilt", "fringe_integral", "fringe_integral_exit", "gap"]}
+
+
+def test_gradients_match_finite_differences_fp64(lx):
+    rng = np.random.default_rng(42)
+    B, N = 2, 400
+    desc = _desc(B, rng)
+    elements, specs = make_lattice(desc, np.float64, lx)
+    seg = lx.Segment(elements)
+    P = o.gaussian_particles((B,), N, seed=9, dtype=np.float64, sigma=[1e-3, 1e-4, 1e-3, 1e-4, 1e-3, 1e-3],
+                             mu=[1e-3, -1e-4, 5e-4, 2e-4, 1e-4, 1e-3])
+    energy = np.array([6e6, 8e6])
+    w_mu = rng.normal(size=(B, 6))
+    w_cov = rng.normal(size=(B, 6, 6)) * 1e3
+    vjp = lx.grad.track_vjp(seg, lx.ParticleBeam(P, energy, dtype=np.float64))
+    g = vjp(mu_bar=w_mu, cov_bar=w_cov)
+
+    def fd(apply, x0):
+        h = 1e-6 * max(abs(x0), 1e-2)
+        apply(x0 + h)
+        lp = _loss(specs, P, energy_fd[0], w_mu, w_cov)
+        apply(x0 - h)
+        lm = _loss(specs, P, energy_fd[0], w_mu, w_cov)
+        apply(x0)
+        return (lp - lm) / (2 * h)
+
+    energy_fd = [energy.copy()]
+    checked = 0
+    for e, (kind, _) in enumerate(desc):
+        for name in PARAMS_TO_CHECK.get(kind, []):
+            arr = specs[e][name]
+            if arr is None:  # parameter left at its default in this element
+                continue
+            got = g[elements[e]][name]
+            assert got.shape == arr.shape
+            for idx in np.ndindex(arr.shape):
+                def apply(x, arr=arr, idx=idx):
+                    arr[idx] = x
+                ref = fd(apply, arr[idx])[idx[0]]  # sample idx[0] only depends on its own parameters
+                scale = max(abs(ref), 1e-9 * np.max(np.abs(w_cov)))
+                assert abs(got[idx] - ref) <= 2e-4 * scale + 1e-7 * np.max(np.abs(got)), (kind, e, name, idx, got[idx], ref)
+                checked += 1
+    for bidx in range(B):
+        def apply(x, bidx=bidx):
+            energy_fd[0] = energy.copy()
+            energy_fd[0][bidx] = x
+        ref = fd(apply, energy[bidx])[bidx]
+        energy_fd[0] = energy.copy()
+        assert abs(g.energy[bidx] - ref) <= 2e-4 * abs(ref) + 1e-12, (bidx, g.energy[bidx], ref)
+    assert checked > 50
+
+
+def test_gradient_of_linear_lattice_and_broadcast_parameters(lx):
+    """All-skippable lattice (one composed map), fp32; a parameter shared by the whole batch
+    receives the sum of the per-sample gradients."""
+    rng = np.random.default_rng(1)
+    B, N = 3, 2000
+    k1 = np.array([4.2], dtype=np.float32)  # shared by all samples
+    elements = [lx.Drift(np.array([0.5], np.float32)), lx.Quadrupole(np.array([0.2], np.float32), k1=k1, name="Q"),
+                lx.Drift(np.full(B, 0.7, np.float32))]
+    seg = lx.Segment(elements)
+    P = o.gaussian_particles((B,), N, seed=2, dtype=np.float32, sigma=[1e-3, 1e-4, 1e-3, 1e-4, 1e-3, 1e-3])
+    w_cov = np.zeros((B, 6, 6))
+    w_cov[:, 0, 0] = 1.0  # L = sum_b var(x)_b
+    g = lx.grad.track_vjp(seg, lx.ParticleBeam(P, np.full(B, 1e8, np.float32)))(cov_bar=w_cov)
+    assert g[seg.Q]["k1"].shape == (1,)
+
+    def loss(kv):
+        specs = [o.Drift(np.full(B, 0.5)), o.Quadrupole(np.full(B, 0.2), k1=np.full(B, kv)), o.Drift(np.full(B, 0.7))]
+        return _loss(specs, P.astype(np.float64), np.full(B, 1e8), np.zeros((B, 6)), w_cov).sum()
+
+    ref = (loss(4.2 + 1e-4) - loss(4.2 - 1e-4)) / 2e-4
+    assert np.isclose(g[seg.Q]["k1"][0], ref, rtol=2e-3), (g[seg.Q]["k1"], ref)

@@ -194,3 +194,17 @@ def test_beam_constructors_follow_the_reference():
     assert np.allclose(lin.xs[0], np.linspace(-1e-3, 1e-3, 11))
     bp = p.broadcast((3,))
     assert bp.particles.shape == (6, 1000, 7)  # Tensor.repeat semantics on a (2,)-batch
+
+
+def test_uniform_3d_ellipsoid_sampler():
+    """reference tests/test_particle_beam.py:108-146"""
+    radius_x, radius_y, radius_s = np.array([1e-3, 2e-3]), np.array([1e-4, 2e-4]), np.array([1e-5, 2e-5])
+    beam = lx.ParticleBeam.uniform_3d_ellipsoid(
+        num_particles=20_000, radius_x=radius_x, radius_y=radius_y, radius_s=radius_s, sigma_xp=np.array([2e-7, 1e-7]),
+        sigma_yp=np.array([3e-7, 2e-7]), sigma_p=np.array([1e-6, 2e-6]), energy=np.array([1e7, 2e7]),
+        total_charge=np.array([1e-9, 3e-9]), seed=1)
+    assert beam.num_particles == 20_000
+    assert np.all(np.abs(beam.xs).T <= radius_x) and np.all(np.abs(beam.ys).T <= radius_y)
+    assert np.all(np.abs(beam.ss).T <= radius_s)
+    assert np.allclose(np.std(beam.xps, axis=-1), [2e-7, 1e-7], rtol=0.05)
+    assert np.allclose(beam.energy, [1e7, 2e7]) and np.allclose(beam.total_charge, [1e-9, 3e-9], rtol=1e-5)
