@@ -132,6 +132,8 @@ def main():
     ap.add_argument("--particles", type=int, default=None)
     ap.add_argument("--no-moments", action="store_true", help="track without the fused moment epilogue")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--grad", action="store_true",
+                    help="step = forward + reverse pass (gradient of sum of var(x) w.r.t. every element parameter)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -188,7 +190,18 @@ def main():
                 comm.close()
                 comm, gather_kind = None, "gloo-host-fallback"
 
+    grad_cov_bar = None
+    if args.grad:
+        import lynx_amd.grad as lgrad
+
+        grad_cov_bar = np.zeros((batch, 6, 6))
+        grad_cov_bar[:, 0, 0] = 1.0
+
     def step():
+        if args.grad:
+            vjp = lgrad.track_vjp(segment, beam)
+            grads = vjp(cov_bar=grad_cov_bar)
+            return vjp.outgoing, grads
         out = segment.track(beam)
         if out._moments is None or (world == 1 and comm is None):
             return out, None
@@ -229,7 +242,7 @@ def main():
     if out._moments is not None:
         rec = out.moment_record()
         assert np.all(np.isfinite(rec)) and np.all(rec[..., 35] == particles), "bench: bad moment records"
-    if gathered is not None:
+    if gathered is not None and not args.grad:
         g = np.asarray(gathered)
         assert g.shape == (world, batch, 36) and np.allclose(g[rank], rec.reshape(batch, 36))
 
@@ -279,7 +292,7 @@ def main():
             "dtype": "f32" if itemsize == 4 else "f64",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {descr}", "batch_per_gpu": batch, "global_batch": batch * world,
-                       "particles": particles, "elements": n_elements, "fused_moments": not args.no_moments,
+                       "particles": particles, "elements": n_elements, "fused_moments": not args.no_moments, "reverse_pass": bool(args.grad),
                        "gather": gather_kind, "parallelism": f"batch-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": "k_track_direct", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,

@@ -181,8 +181,8 @@ int lynx_track_moments(lynx_ctx* ctx, lynx_lattice* lat, const void* d_energy_in
  *   d_grad_params  [B][E][8]        dL/d(parameter j of element e), parameter order of the
  *                                   element kind; unused slots 0; custom maps: 0
  *   d_grad_energy_in [B]            dL/d(incoming energy)
- * Limits of this version: n_steps * 7 states of 256 particles must fit in LDS
- * (n_steps <= 17 in float32, <= 8 in float64).                                             */
+ * Limit of this version: every 4th per-particle state and the per-step accumulators live in
+ * LDS, which bounds n_steps to about 60 (float32) / 30 (float64).                           */
 int lynx_track_particles_backward(lynx_ctx* ctx, lynx_lattice* lat, int64_t n_particles,
                                   const void* d_energy_in, const void* d_p_in,
                                   const double* d_moments_fwd, const double* d_grad_moments,

@@ -29,6 +29,7 @@ namespace lynx {
 
 constexpr int kGradStride = 64;   // per (sample, step): 49 T_bar + 8 coef_bar + padding
 constexpr int kGradParams = 8;    // gradient slots per element (kinds with <= 8 parameters)
+constexpr int kExPitch = 68;
 
 struct BwdArgs {
   int64_t n_particles;
@@ -38,25 +39,44 @@ struct BwdArgs {
 
 // ---------------------------------------------------------------------------------------
 // k_track_bwd: grid = B * chunks workgroups of 256 threads, one particle per thread and tile.
-// LDS: state stack [S][7][256] T | exchange [4][22][64] T | accumulators [4][S][64] T
+//
+// The reverse sweep needs the state that ENTERED every step.  Every kBwdGroup-th state is
+// parked in LDS during the forward sweep (stack [ceil(S/K)][7][256]); inside a group the K-1
+// missing states are recomputed into registers (0.75 extra step applications per step for
+// K = 4).  Parking every state needed 476 B per particle for the 16 steps of BASELINE
+// config 5 = one workgroup per CU, and the kernel ran latency-bound at 1 wave per SIMD.
+//
+// LDS: stack [G][7][256] T | exchange [4][22][kExPitch] T | accumulators [4][S][64] T
+// kExPitch = 68: rows stay 16-byte aligned and the 7 rows a 49-lane read touches at the same
+// column fall on different banks (pitch 64 made every such read a 7-way conflict).
 // ---------------------------------------------------------------------------------------
+constexpr int kBwdGroup = 4;
+
+template <typename T>
+__device__ __forceinline__ void load_step_map(const T* g_steps, int s, T (&m)[57]) {
+#pragma unroll
+  for (int q = 0; q < 57; ++q) m[q] = g_steps[s * LYNX_STEP_STRIDE + q];  // wave-uniform: scalar loads
+}
+
 template <typename T>
 __global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
     LatticeDev lat, BwdArgs a, const T* __restrict__ p_in, const T* __restrict__ steps,
     const double* __restrict__ moments_fwd, const double* __restrict__ grad_moments,
     T* __restrict__ partials /* [B][chunks][S][64] */) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int K = kBwdGroup;
   const int S = lat.n_steps;
-  T* s_stack = reinterpret_cast<T*>(smem_raw);               // [S][7][256]
-  T* s_ex = s_stack + (size_t)S * 7 * kTrackThreads;         // [4][22][64]
-  T* s_acc = s_ex + 4 * 22 * 64;                             // [4][S][64]
+  const int G = (S + K - 1) / K;
+  T* s_stack = reinterpret_cast<T*>(smem_raw);               // [G][7][256]
+  T* s_ex = s_stack + (size_t)G * 7 * kTrackThreads;         // [4][22][kExPitch]
+  T* s_acc = s_ex + 4 * 22 * kExPitch;                       // [4][S][64]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t b = blockIdx.x / a.chunks;
   const int chunk = blockIdx.x % a.chunks;
   const int64_t N = a.n_particles;
   const T* g_steps = steps + b * (int64_t)S * LYNX_STEP_STRIDE;
-  T* ex = s_ex + wave * (22 * 64);
+  T* ex = s_ex + wave * (22 * kExPitch);
   T* acc = s_acc + wave * (S * 64);
 
   for (int s = 0; s < S; ++s) acc[s * 64 + lane] = T(0);
@@ -65,13 +85,13 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
   const double* rec = moments_fwd + b * LYNX_MOMENT_STRIDE;
   const double* gm = grad_moments + b * LYNX_MOMENT_STRIDE;
   const T inv_n = (T)(1.0 / rec[35]);
-  T mean[6], mu_bar[7], G[21];
+  T mean[6], mu_bar[7], Gc[21];
 #pragma unroll
   for (int i = 0; i < 6; ++i) mean[i] = (T)rec[i];
 #pragma unroll
   for (int i = 0; i < 7; ++i) mu_bar[i] = (T)gm[i];
 #pragma unroll
-  for (int i = 0; i < 21; ++i) G[i] = (T)gm[7 + i];
+  for (int i = 0; i < 21; ++i) Gc[i] = (T)gm[7 + i];
 
   const T* src = p_in + b * N * 7;
   for (int it = 0; it < a.tiles_per_wg; ++it) {
@@ -81,14 +101,15 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
     T z[7];
     load_particle<false>(src + (live ? i : 0) * 7, z);
 
-    // forward, parking the input state of every step
+    // forward sweep, parking the state that enters every K-th step
     for (int s = 0; s < S; ++s) {
       const lynx_step st = lat.steps[s];
       T m[57];
+      load_step_map<T>(g_steps, s, m);
+      if (s % K == 0) {
 #pragma unroll
-      for (int q = 0; q < 57; ++q) m[q] = g_steps[s * LYNX_STEP_STRIDE + q];
-#pragma unroll
-      for (int c = 0; c < 7; ++c) s_stack[(s * 7 + c) * kTrackThreads + tid] = z[c];
+        for (int c = 0; c < 7; ++c) s_stack[((s / K) * 7 + c) * kTrackThreads + tid] = z[c];
+      }
       apply_step<T>(m, st.kind, st.flags, z);
     }
 
@@ -105,7 +126,7 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
           const int r = k < j ? k : j, c = k < j ? j : k;
-          const T g = G[r * 6 - (r * (r - 1)) / 2 + (c - r)];
+          const T g = Gc[r * 6 - (r * (r - 1)) / 2 + (c - r)];
           accv = t_fma(k == j ? g + g : g, d[j], accv);
         }
         zb[k] = live ? accv * inv_n : T(0);
@@ -113,78 +134,114 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
       zb[6] = live ? mu_bar[6] * inv_n : T(0);
     }
 
-    for (int s = S - 1; s >= 0; --s) {
-      const lynx_step st = lat.steps[s];
-      T m[57];
+    for (int grp = G - 1; grp >= 0; --grp) {
+      // states entering steps grp*K .. grp*K + K-1
+      T zz[K][7];
 #pragma unroll
-      for (int q = 0; q < 57; ++q) m[q] = g_steps[s * LYNX_STEP_STRIDE + q];
-      T zin[7];
+      for (int c = 0; c < 7; ++c) zz[0][c] = s_stack[(grp * 7 + c) * kTrackThreads + tid];
 #pragma unroll
-      for (int c = 0; c < 7; ++c) zin[c] = s_stack[(s * 7 + c) * kTrackThreads + tid];
-
-      T olin[7], cc[8], dir4 = T(0), dir5 = T(0);
+      for (int j = 1; j < K; ++j) {
+        const int sp = grp * K + j - 1;  // step that produces zz[j]
 #pragma unroll
-      for (int c = 0; c < 7; ++c) olin[c] = zb[c];
-#pragma unroll
-      for (int c = 0; c < 8; ++c) cc[c] = T(0);
-      if (st.kind == LYNX_STEP_CAVITY && (st.flags & LYNX_FLAG_CAV_GAIN)) {
-        // o5' = z5 c0 + c1 (cos(a) - c4), a = -z4 c2 + c3 ; o4' = o4 + c5 z5^2 + c6 z4 z5 + c7 z4^2
-        const T* cf = m + LYNX_COEF_OFFSET;
-        const T z4 = zin[4], z5 = zin[5], o4b = zb[4], o5b = zb[5];
-        const T arg = T(-1) * z4 * cf[LYNX_C_BK] + cf[LYNX_C_PHI];
-        const T ca = t_cos(arg), sa = t_sin(arg);
-        const T ab = -o5b * cf[LYNX_C_DKICK] * sa;
-        cc[LYNX_C_DSCALE] = o5b * z5;
-        cc[LYNX_C_DKICK] = o5b * (ca - cf[LYNX_C_COSPHI]);
-        cc[LYNX_C_BK] = ab * (-z4);
-        cc[LYNX_C_PHI] = ab;
-        cc[LYNX_C_COSPHI] = -o5b * cf[LYNX_C_DKICK];
-        cc[LYNX_C_T566] = o4b * (z5 * z5);
-        cc[LYNX_C_T556] = o4b * (z4 * z5);
-        cc[LYNX_C_T555] = o4b * (z4 * z4);
-        dir4 = ab * (-cf[LYNX_C_BK]) + o4b * (cf[LYNX_C_T556] * z5 + T(2) * cf[LYNX_C_T555] * z4);
-        dir5 = o5b * cf[LYNX_C_DSCALE] + o4b * (T(2) * cf[LYNX_C_T566] * z5 + cf[LYNX_C_T556] * z4);
-        olin[5] = T(0);  // the linear delta was overwritten
-      }
-
-      // 64-lane sums through the wave's exchange buffer
-#pragma unroll
-      for (int c = 0; c < 7; ++c) ex[c * 64 + lane] = olin[c];
-#pragma unroll
-      for (int c = 0; c < 7; ++c) ex[(7 + c) * 64 + lane] = zin[c];
-#pragma unroll
-      for (int c = 0; c < 8; ++c) ex[(14 + c) * 64 + lane] = cc[c];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (lane < 57) {
-        T sum = T(0);
-        if (lane < 49) {
-          const T* ra = ex + (lane / 7) * 64;
-          const T* rb = ex + (7 + lane % 7) * 64;
-#pragma unroll 16
-          for (int l = 0; l < 64; ++l) sum = t_fma(ra[l], rb[l], sum);
-        } else {
-          const T* rc = ex + (14 + lane - 49) * 64;
-#pragma unroll 16
-          for (int l = 0; l < 64; ++l) sum += rc[l];
+        for (int c = 0; c < 7; ++c) zz[j][c] = zz[j - 1][c];
+        if (sp + 1 < S) {
+          const lynx_step st = lat.steps[sp];
+          T m[57];
+          load_step_map<T>(g_steps, sp, m);
+          apply_step<T>(m, st.kind, st.flags, zz[j]);
         }
-        acc[s * 64 + lane] += sum;
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-      // z_bar_in = T^T o_lin (+ direct cavity terms)
+      for (int j = K - 1; j >= 0; --j) {
+        const int s = grp * K + j;
+        if (s >= S) continue;  // uniform
+        const lynx_step st = lat.steps[s];
+        T m[57];
+        load_step_map<T>(g_steps, s, m);
+        T zin[7];
 #pragma unroll
-      for (int j = 0; j < 7; ++j) {
-        T v = m[0 * 7 + j] * olin[0];
+        for (int c = 0; c < 7; ++c) {
+          T v = zz[0][c];
 #pragma unroll
-        for (int r = 1; r < 7; ++r) v = t_fma(m[r * 7 + j], olin[r], v);
-        zb[j] = v;
+          for (int q = 1; q < K; ++q) v = (j == q) ? zz[q][c] : v;
+          zin[c] = v;
+        }
+
+        const bool kick = st.kind == LYNX_STEP_CAVITY && (st.flags & LYNX_FLAG_CAV_GAIN);
+        T olin[7], cc[8], dir4 = T(0), dir5 = T(0);
+#pragma unroll
+        for (int c = 0; c < 7; ++c) olin[c] = zb[c];
+        if (kick) {
+          // o5' = z5 c0 + c1 (cos(a) - c4), a = -z4 c2 + c3 ; o4' = o4 + c5 z5^2 + c6 z4 z5 + c7 z4^2
+          const T* cf = m + LYNX_COEF_OFFSET;
+          const T z4 = zin[4], z5 = zin[5], o4b = zb[4], o5b = zb[5];
+          const T arg = T(-1) * z4 * cf[LYNX_C_BK] + cf[LYNX_C_PHI];
+          const T ca = t_cos(arg), sa = t_sin(arg);
+          const T ab = -o5b * cf[LYNX_C_DKICK] * sa;
+          cc[LYNX_C_DSCALE] = o5b * z5;
+          cc[LYNX_C_DKICK] = o5b * (ca - cf[LYNX_C_COSPHI]);
+          cc[LYNX_C_BK] = ab * (-z4);
+          cc[LYNX_C_PHI] = ab;
+          cc[LYNX_C_COSPHI] = -o5b * cf[LYNX_C_DKICK];
+          cc[LYNX_C_T566] = o4b * (z5 * z5);
+          cc[LYNX_C_T556] = o4b * (z4 * z5);
+          cc[LYNX_C_T555] = o4b * (z4 * z4);
+          dir4 = ab * (-cf[LYNX_C_BK]) + o4b * (cf[LYNX_C_T556] * z5 + T(2) * cf[LYNX_C_T555] * z4);
+          dir5 = o5b * cf[LYNX_C_DSCALE] + o4b * (T(2) * cf[LYNX_C_T566] * z5 + cf[LYNX_C_T556] * z4);
+          olin[5] = T(0);  // the linear delta was overwritten
+        }
+
+        // 64-lane sums through the wave's exchange buffer
+#pragma unroll
+        for (int c = 0; c < 7; ++c) ex[c * kExPitch + lane] = olin[c];
+#pragma unroll
+        for (int c = 0; c < 7; ++c) ex[(7 + c) * kExPitch + lane] = zin[c];
+        if (kick) {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) ex[(14 + c) * kExPitch + lane] = cc[c];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < 49 || (kick && lane < 57)) {
+          using V = typename VecOf<T, true>::type;  // 16-byte LDS reads
+          constexpr int VW = VecOf<T, true>::width;
+          T sum = T(0);
+          if (lane < 49) {
+            const V* ra = reinterpret_cast<const V*>(ex + (lane / 7) * kExPitch);
+            const V* rb = reinterpret_cast<const V*>(ex + (7 + lane % 7) * kExPitch);
+#pragma unroll 8
+            for (int l = 0; l < 64 / VW; ++l) {
+              const V va = ra[l], vb = rb[l];
+#pragma unroll
+              for (int q = 0; q < VW; ++q) sum = t_fma(va[q], vb[q], sum);
+            }
+          } else {
+            const V* rc = reinterpret_cast<const V*>(ex + (14 + lane - 49) * kExPitch);
+#pragma unroll 8
+            for (int l = 0; l < 64 / VW; ++l) {
+              const V vc = rc[l];
+#pragma unroll
+              for (int q = 0; q < VW; ++q) sum += vc[q];
+            }
+          }
+          acc[s * 64 + lane] += sum;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // z_bar_in = T^T o_lin (+ direct cavity terms)
+#pragma unroll
+        for (int jj = 0; jj < 7; ++jj) {
+          T v = m[0 * 7 + jj] * olin[0];
+#pragma unroll
+          for (int r = 1; r < 7; ++r) v = t_fma(m[r * 7 + jj], olin[r], v);
+          zb[jj] = v;
+        }
+        zb[4] += dir4;
+        zb[5] += dir5;
       }
-      zb[4] += dir4;
-      zb[5] += dir5;
     }
   }
 

@@ -47,17 +47,55 @@ def _unbroadcast(grad: np.ndarray, shape) -> np.ndarray:
 
 
 class Gradients:
-    """dL/d(parameter) per element, `energy` = dL/d(incoming beam energy)."""
+    """
+    dL/d(parameter) per element (`g[element]["k1"]`), `energy` = dL/d(incoming beam energy).
+    The raw `[B][E][8]` result stays in HBM; an element's gradients are copied and shaped on
+    first access.
+    """
 
-    def __init__(self, per_element: dict, energy: np.ndarray):
-        self._per_element = per_element
-        self.energy = energy
+    def __init__(self, program, raw_dev, energy_dev, batch_shape, energy_shape):
+        self._program, self._raw_dev, self._energy_dev = program, raw_dev, energy_dev
+        self._batch_shape, self._energy_shape = tuple(batch_shape), tuple(energy_shape)
+        self._raw = None
+        self._cache = {}
 
-    def __getitem__(self, element) -> dict:
-        return self._per_element[id(element)]
+    def _host(self):
+        if self._raw is None:
+            E = max(len(self._program.leaves), 1)
+            self._raw = self._raw_dev.numpy().reshape(*self._batch_shape, E, 8)
+        return self._raw
+
+    @property
+    def energy(self) -> np.ndarray:
+        return _unbroadcast(self._energy_dev.numpy().reshape(self._batch_shape), self._energy_shape)
 
     def __contains__(self, element) -> bool:
-        return id(element) in self._per_element
+        return any(el is element and el._kind in PARAM_NAMES for el in self._program.leaves)
+
+    def __getitem__(self, element) -> dict:
+        if id(element) in self._cache:
+            return self._cache[id(element)]
+        from .accelerator.dipole import RBend
+
+        raw, total = self._host(), None
+        for e, el in enumerate(self._program.leaves):
+            if el is not element or el._kind not in PARAM_NAMES:
+                continue
+            g = {n: raw[..., e, j] for j, n in enumerate(PARAM_NAMES[el._kind])}
+            out = {}
+            if "misalignment_x" in g:
+                mis = np.stack([g.pop("misalignment_x"), g.pop("misalignment_y")], axis=-1)
+                out["misalignment"] = _unbroadcast(mis, np.asarray(el.misalignment).shape)
+            if isinstance(el, RBend):  # e1 = e1_user + angle/2, e2 = e2_user + angle/2 (rbend.py:79-80)
+                g["angle"] = g["angle"] + 0.5 * (g["e1"] + g["e2"])
+            for n, v in g.items():
+                out[n] = _unbroadcast(v, np.asarray(getattr(el, n)).shape)
+            # the same element object may appear several times in the lattice
+            total = out if total is None else {n: total[n] + out[n] for n in out}
+        if total is None:
+            raise KeyError(f"{element!r} has no differentiable parameters in this lattice")
+        self._cache[id(element)] = total
+        return total
 
 
 class TrackVJP:
@@ -97,30 +135,7 @@ class TrackVJP:
         rt.check(rt.lib.lynx_track_particles_backward(
             rt.ctx, lat.handle, beam.num_particles, C.c_void_p(e_in.ptr), C.c_void_p(beam._particles.device(rt).ptr),
             C.c_void_p(fwd.ptr), C.c_void_p(g_rec.ptr), C.c_void_p(g_par.ptr), C.c_void_p(g_en.ptr)))
-        raw = g_par.numpy().reshape(*batch_shape, max(E, 1), 8)
-        per_element = {}
-        for e, el in enumerate(program.leaves):
-            names = PARAM_NAMES.get(el._kind)
-            if not names:
-                continue
-            g = {n: raw[..., e, j] for j, n in enumerate(names)}
-            out = {}
-            if "misalignment_x" in g:
-                mis = np.stack([g.pop("misalignment_x"), g.pop("misalignment_y")], axis=-1)
-                out["misalignment"] = _unbroadcast(mis, np.asarray(el.misalignment).shape)
-            from .accelerator.dipole import RBend
-
-            if isinstance(el, RBend):  # e1 = e1_user + angle/2, e2 = e2_user + angle/2 (rbend.py:79-80)
-                g["angle"] = g["angle"] + 0.5 * (g["e1"] + g["e2"])
-            for n, v in g.items():
-                out[n] = _unbroadcast(v, np.asarray(getattr(el, n)).shape)
-            if id(el) in per_element:  # the same element object appears twice in the lattice
-                for n in out:
-                    per_element[id(el)][n] = per_element[id(el)][n] + out[n]
-            else:
-                per_element[id(el)] = out
-        energy = _unbroadcast(g_en.numpy().reshape(batch_shape), np.asarray(beam.energy).shape)
-        return Gradients(per_element, energy)
+        return Gradients(program, g_par, g_en, batch_shape, np.asarray(beam.energy).shape)
 
 
 def track_vjp(segment, beam: ParticleBeam) -> TrackVJP:

@@ -208,3 +208,19 @@ def test_uniform_3d_ellipsoid_sampler():
     assert np.all(np.abs(beam.ss).T <= radius_s)
     assert np.allclose(np.std(beam.xps, axis=-1), [2e-7, 1e-7], rtol=0.05)
     assert np.allclose(beam.energy, [1e7, 2e7]) and np.allclose(beam.total_charge, [1e-9, 3e-9], rtol=1e-5)
+
+
+def test_gradient_host_helpers():
+    """Host side of lynx_amd.grad: broadcast parameters receive summed gradients; a full
+    symmetric cov cotangent maps to the upper-triangle record of include/lynx_hip.h."""
+    from lynx_amd.grad import _unbroadcast
+    from lynx_amd.particles.particle_beam import _tri
+
+    g = np.arange(6.0).reshape(3, 2)
+    assert np.array_equal(_unbroadcast(g, (3, 2)), g)
+    assert np.array_equal(_unbroadcast(g, (1,)), [15.0])
+    assert np.array_equal(_unbroadcast(g, (1, 2)), [[6.0, 9.0]])
+    assert np.array_equal(_unbroadcast(g, (2,)), [6.0, 9.0])
+    idx = sorted(_tri(i, j) for i in range(6) for j in range(i, 6))
+    assert idx == list(range(7, 28))  # the 21 upper-triangle slots of a moment record
+    assert _tri(0, 0) == 7 and _tri(0, 5) == 12 and _tri(1, 1) == 13 and _tri(5, 5) == 27
