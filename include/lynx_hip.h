@@ -46,7 +46,9 @@ enum lynx_kind {
   /* the public helpers of lynx/track_methods.py, exposed as lynx_amd.track_methods */
   LYNX_KIND_BASE_RMATRIX = 8, /* track_methods.py:37-105    params [L,k1,hx,tilt]      */
   LYNX_KIND_ROTATION = 9,     /* track_methods.py:14-34     params [angle]             */
-  LYNX_KIND_MISALIGNMENT = 10 /* track_methods.py:108-122   params [mx,my,sign] (sign -1: R_entry, +1: R_exit) */
+  LYNX_KIND_MISALIGNMENT = 10, /* track_methods.py:108-122  params [mx,my,sign] (sign -1: R_entry, +1: R_exit) */
+  LYNX_KIND_SOLENOID = 11,    /* solenoid.py:61-105         params [L,k,mx,my]         */
+  LYNX_KIND_UNDULATOR = 12    /* undulator.py:48-60         params [L]                 */
 };
 
 /*
@@ -192,6 +194,20 @@ int lynx_track_particles_backward(lynx_ctx* ctx, lynx_lattice* lat, int64_t n_pa
  * one fused pass instead of 14 separate reductions).  d_moments_out [B][36] float64.       */
 int lynx_moments(lynx_ctx* ctx, int dtype, int64_t batch, int64_t n_particles, const void* d_p,
                  double* d_moments_out);
+
+/* Screen read-out of a ParticleBeam: per-sample 2-D histogram of (x, y) with the bin edges the
+ * caller supplies (reference: screen.py:196-213, `jnp.histogramdd` with `pixel_bin_edges`
+ * :107-120, then `flipud(hist.T)`).  Bin of a value v: last edge <= v, the right-most edge
+ * included (numpy.histogramdd).  d_image [B][ny][nx] int32 counts, row 0 = highest y; the
+ * call clears it first.  d_xedges [nx+1], d_yedges [ny+1] in the particle dtype.            */
+int lynx_histogram2d(lynx_ctx* ctx, int dtype, int64_t batch, int64_t n_particles, const void* d_p,
+                     const void* d_xedges, const void* d_yedges, int32_t nx, int32_t ny, int32_t* d_image);
+
+/* Screen read-out of a ParameterBeam: density of the bivariate normal of (x, y) on a pixel grid
+ * (reference: screen.py:160-195).  d_xs [nx], d_ys [ny] pixel coordinates, d_mu [B][7],
+ * d_cov [B][7][7]; d_image [B][nx][ny] with the x axis flipped, as the reference returns it. */
+int lynx_gaussian_image(lynx_ctx* ctx, int dtype, int64_t batch, const void* d_mu, const void* d_cov,
+                        const void* d_xs, const void* d_ys, int32_t nx, int32_t ny, void* d_image);
 
 /* Seeded synthetic beam, generated in HBM: uncorrelated 6-D Gaussian per sample, 7th
  * coordinate 1 (shape of ParticleBeam.from_parameters, particle_beam.py:144-170; not the

@@ -8,6 +8,7 @@ restricted to the elements on the path).  Compute runs in hand-written HIP kerne
 from . import config  # noqa: F401
 from .accelerator import (  # noqa: F401
     BPM,
+    Aperture,
     Cavity,
     CustomTransferMap,
     Dipole,
@@ -17,7 +18,10 @@ from .accelerator import (  # noqa: F401
     Marker,
     Quadrupole,
     RBend,
+    Screen,
     Segment,
+    Solenoid,
+    Undulator,
     VerticalCorrector,
 )
 from .particles import Beam, ParameterBeam, ParticleBeam  # noqa: F401

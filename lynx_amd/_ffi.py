@@ -21,7 +21,8 @@ F32, F64 = 0, 1
 KIND_IDENTITY, KIND_DRIFT, KIND_QUADRUPOLE, KIND_DIPOLE = 0, 1, 2, 3
 KIND_HCOR, KIND_VCOR, KIND_CAVITY, KIND_CUSTOM = 4, 5, 6, 7
 KIND_BASE_RMATRIX, KIND_ROTATION, KIND_MISALIGNMENT = 8, 9, 10
-PARAMS_OF_KIND = {0: 0, 1: 1, 2: 5, 3: 8, 4: 2, 5: 2, 6: 4, 7: 49, 8: 4, 9: 1, 10: 3}
+KIND_SOLENOID, KIND_UNDULATOR = 11, 12
+PARAMS_OF_KIND = {0: 0, 1: 1, 2: 5, 3: 8, 4: 2, 5: 2, 6: 4, 7: 49, 8: 4, 9: 1, 10: 3, 11: 4, 12: 1}
 
 FLAG_TILT, FLAG_MISALIGNED, FLAG_THICK = 1, 2, 4
 FLAG_CAV_BETA, FLAG_CAV_GAIN, FLAG_CAV_T5XX = 8, 16, 32
@@ -84,6 +85,8 @@ SIGNATURES = {
     "lynx_track_moments": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "lynx_track_particles_backward": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "lynx_moments": (_i, [_vp, _i, _i64, _i64, _vp, _vp]),
+    "lynx_histogram2d": (_i, [_vp, _i, _i64, _i64, _vp, _vp, _vp, C.c_int32, C.c_int32, _vp]),
+    "lynx_gaussian_image": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _vp, C.c_int32, C.c_int32, _vp]),
     "lynx_fill_gaussian": (_i, [_vp, _i, _i64, _i64, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                 C.c_uint64, _vp]),
     "lynx_comm_unique_id": (_i, [C.c_char_p]),

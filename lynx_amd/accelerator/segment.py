@@ -127,6 +127,20 @@ class Segment(Element):
                 for e in self.elements],
             name=self.name)
 
+    @classmethod
+    def from_lattice_json(cls, filepath: str) -> "Segment":
+        """Load a LatticeJSON file written by `to_lattice_json` or by the reference (segment.py:220-228)."""
+        from ..io.latticejson import load_segment
+
+        return load_segment(filepath)
+
+    def to_lattice_json(self, filepath: str, title: Optional[str] = None,
+                        info: str = "This is a placeholder lattice description") -> None:
+        """Save the segment as LatticeJSON (segment.py:230-247)."""
+        from ..io.latticejson import save_segment
+
+        save_segment(self, filepath, title, info)
+
     @property
     def is_skippable(self) -> bool:
         return all(element.is_skippable for element in self.elements)

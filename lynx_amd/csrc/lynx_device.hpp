@@ -536,6 +536,22 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_direct(
   constexpr int64_t kTile = (int64_t)kTrackThreads * UNROLL;
   const int64_t end = N;
 
+  // Software pipeline: the loads of a tile are issued one iteration ahead (the first ones
+  // right here, before the step table is fetched), so a workgroup always has a tile of HBM
+  // reads in flight while it computes and stores the previous one.
+  const T* src = p_in + b * N * 7;
+  T* dst = p_out + b * N * 7;
+  T zn[UNROLL][7];
+  {
+    const int64_t tile0 = a.interleave ? (int64_t)chunk : (int64_t)chunk * a.tiles_per_wg;
+    const int64_t i0 = tile0 * kTile + tid;
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int64_t i = i0 + (int64_t)u * kTrackThreads;
+      load_particle<false>(src + (i < end ? i : (i0 < end ? i0 : 0)) * 7, zn[u]);
+    }
+  }
+
   const bool one_run = (S == 1) && (lat.steps[0].kind == LYNX_STEP_RUN);
   constexpr bool kMapInRegs = sizeof(T) == 4;
   // Pre-built single-run fp32 program: the map and the moment reference point come straight
@@ -587,21 +603,24 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_direct(
 #pragma unroll
     for (int k = 0; k < 21; ++k) f_dd[k] = 0.f;
   }
-  const T* src = p_in + b * N * 7;
-  T* dst = p_out + b * N * 7;
   for (int it = 0; it < a.tiles_per_wg; ++it) {
     const int64_t tile = a.interleave ? ((int64_t)it * a.chunks + chunk) : ((int64_t)chunk * a.tiles_per_wg + it);
     const int64_t i0 = tile * kTile + tid;
     if (i0 >= end) break;
-    // fp64: the map is re-read from LDS for every particle (broadcast reads are cheap);
-    // without this fence hipcc hoists all 49 entries (98 VGPRs) out of the loop and the
-    // kernel drops to one wave per SIMD.
-    if (!kMapInRegs) LYNX_FORGET();
+    if (!kMapInRegs) LYNX_FORGET();  // fp64: keep the map in LDS, not in 98 hoisted VGPRs
     T z[UNROLL][7];
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      const int64_t i = i0 + (int64_t)u * kTrackThreads;
-      load_particle<false>(src + (i < end ? i : i0) * 7, z[u]);
+    for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+      for (int c = 0; c < 7; ++c) z[u][c] = zn[u][c];
+    if (it + 1 < a.tiles_per_wg) {  // prefetch the next tile of this workgroup
+      const int64_t tn = a.interleave ? ((int64_t)(it + 1) * a.chunks + chunk) : (tile + 1);
+      const int64_t j0 = tn * kTile + tid;
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        const int64_t j = j0 + (int64_t)u * kTrackThreads;
+        load_particle<false>(src + (j < end ? j : i0) * 7, zn[u]);
+      }
     }
     if (MOM == 2) {
 #pragma unroll
@@ -891,6 +910,66 @@ __global__ __launch_bounds__(64) void k_track_moments(LatticeDev lat, const T* _
   if (lane < 7) mu_out[b * 7 + lane] = s_mu[lane];
   if (lane < 49) cov_out[b * 49 + lane] = s_cov[lane];
   if (energy_out && lane == 0) energy_out[b] = s_energy[lat.n_steps];
+}
+
+// ---------------------------------------------------------------------------------------
+// k_histogram2d: Screen read-out of a ParticleBeam.  Edges are staged in LDS; every thread
+// walks particles of one sample (grid.y... folded into blockIdx.x), finds both bins by
+// bisection on the very edge arrays NumPy would use (bit-exact bin assignment) and adds 1
+// with an int atomic (exact, order-independent).
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ int bin_of(const T* edges, int n, T v) {
+  // number of edges <= v, minus one; the last edge belongs to the last bin (numpy.histogramdd)
+  if (!(v >= edges[0]) || !(v <= edges[n])) return -1;
+  int lo = 0, hi = n + 1;  // invariant: edges[lo] <= v, (hi == n + 1 or edges[hi] > v)
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (edges[mid] <= v) lo = mid; else hi = mid;
+  }
+  return lo == n ? n - 1 : lo;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_histogram2d(const T* __restrict__ p, int64_t N, int chunks,
+                                                      const T* __restrict__ xedges, const T* __restrict__ yedges,
+                                                      int nx, int ny, int32_t* __restrict__ image) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* s_x = reinterpret_cast<T*>(smem_raw);
+  T* s_y = s_x + nx + 1;
+  for (int i = threadIdx.x; i <= nx; i += blockDim.x) s_x[i] = xedges[i];
+  for (int i = threadIdx.x; i <= ny; i += blockDim.x) s_y[i] = yedges[i];
+  __syncthreads();
+  const int64_t b = blockIdx.x / chunks;
+  const int chunk = blockIdx.x % chunks;
+  const int64_t per = (N + chunks - 1) / chunks;
+  const int64_t lo = chunk * per, hi = (lo + per) < N ? (lo + per) : N;
+  int32_t* img = image + b * (int64_t)nx * ny;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    const T* q = p + (b * N + i) * 7;
+    const int ix = bin_of<T>(s_x, nx, q[0]);
+    const int iy = bin_of<T>(s_y, ny, q[2]);
+    if (ix >= 0 && iy >= 0) atomicAdd(img + (int64_t)(ny - 1 - iy) * nx + ix, 1);
+  }
+}
+
+// k_gaussian_image: Screen read-out of a ParameterBeam, one thread per pixel.
+template <typename T>
+__global__ __launch_bounds__(256) void k_gaussian_image(const T* __restrict__ mu, const T* __restrict__ cov,
+                                                         const T* __restrict__ xs, const T* __restrict__ ys, int nx,
+                                                         int ny, T* __restrict__ image) {
+  const int64_t b = blockIdx.y;
+  const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= (int64_t)nx * ny) return;
+  const int i = (int)(pix / ny), j = (int)(pix % ny);
+  const T mx = mu[b * 7 + 0], my = mu[b * 7 + 2];
+  const T a = cov[b * 49 + 0], bb = cov[b * 49 + 2], c = cov[b * 49 + 2 * 7 + 2];
+  const T det = a * c - bb * bb;
+  const T dx = xs[i] - mx, dy = ys[j] - my;
+  const T maha = (c * dx * dx - T(2) * bb * dx * dy + a * dy * dy) / det;
+  // exp(log_prob) of MultivariateNormal: -maha/2 - log(2 pi) - log(det)/2
+  const T logp = T(-0.5) * maha - T(1.8378770664093453) - T(0.5) * t_log(det);
+  image[(b * nx + (nx - 1 - i)) * (int64_t)ny + j] = (T)exp((double)logp);
 }
 
 // ---------------------------------------------------------------------------------------

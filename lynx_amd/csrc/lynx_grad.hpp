@@ -386,6 +386,8 @@ __global__ __launch_bounds__(256) void k_build_bwd(LatticeDev lat, const T* __re
       case LYNX_KIND_BASE_RMATRIX: np = 4; break;
       case LYNX_KIND_ROTATION: np = 1; break;
       case LYNX_KIND_MISALIGNMENT: np = 3; break;
+      case LYNX_KIND_SOLENOID: np = 4; break;
+      case LYNX_KIND_UNDULATOR: np = 1; break;
       default: np = 0; break;  // identity; custom maps carry no differentiable parameters here
     }
     const bool energy_task = pidx == kGradParams;

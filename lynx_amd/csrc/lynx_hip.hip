@@ -297,6 +297,8 @@ static int params_of_kind(int kind) {
     case LYNX_KIND_BASE_RMATRIX: return 4;
     case LYNX_KIND_ROTATION: return 1;
     case LYNX_KIND_MISALIGNMENT: return 3;
+    case LYNX_KIND_SOLENOID: return 4;
+    case LYNX_KIND_UNDULATOR: return 1;
     default: return -1;
   }
 }
@@ -469,7 +471,7 @@ static TrackPlan plan_track(lynx_ctx* ctx, int64_t B, int64_t N, int32_t S, bool
   const char* kern = getenv("LYNX_KERNEL");
   p.direct = !(kern && strcmp(kern, "lds") == 0);
   const int64_t cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
-  const int64_t target = (int64_t)env_int("LYNX_WGS_PER_CU", 128) * cus;
+  const int64_t target = (int64_t)env_int("LYNX_WGS_PER_CU", 512) * cus;
   p.mom_mode = env_int("LYNX_MOM", sizeof(T) == 4 ? 2 : 1);
   if (sizeof(T) == 8 || p.mom_mode < 1 || p.mom_mode > 3) p.mom_mode = 1;
   p.a.n_particles = N;
@@ -493,7 +495,7 @@ static TrackPlan plan_track(lynx_ctx* ctx, int64_t B, int64_t N, int32_t S, bool
     const int64_t ntiles = (N + tile - 1) / tile;
     // A workgroup pays a fixed cost (table load, 29-value cross-lane reduction, partial
     // record), so it gets at least `min_tpw` tiles -- unless that would leave CUs idle.
-    int64_t min_tpw = env_int("LYNX_MIN_TILES_PER_WG", sizeof(T) == 4 ? 3 : 4);
+    int64_t min_tpw = env_int("LYNX_MIN_TILES_PER_WG", sizeof(T) == 4 ? 1 : 4);
     while (min_tpw > 1 && B * ((ntiles + min_tpw - 1) / min_tpw) < 4 * cus) --min_tpw;
     int64_t chunks = std::max<int64_t>(1, std::min<int64_t>((ntiles + min_tpw - 1) / min_tpw, (target + B - 1) / B));
     int64_t tpw = (ntiles + chunks - 1) / chunks;
@@ -795,6 +797,50 @@ int lynx_track_moments(lynx_ctx* ctx, lynx_lattice* lat, const void* d_energy_in
   return lat->dtype == LYNX_F64
              ? launch_track_moments<double>(ctx, lat, d_energy_in, d_mu_in, d_cov_in, d_mu_out, d_cov_out, d_energy_out)
              : launch_track_moments<float>(ctx, lat, d_energy_in, d_mu_in, d_cov_in, d_mu_out, d_cov_out, d_energy_out);
+}
+
+// ---- screen read-out -------------------------------------------------------------------------
+
+int lynx_histogram2d(lynx_ctx* ctx, int dtype, int64_t batch, int64_t n_particles, const void* d_p,
+                     const void* d_xedges, const void* d_yedges, int32_t nx, int32_t ny, int32_t* d_image) {
+  if (!ctx || !d_p || !d_xedges || !d_yedges || !d_image || batch <= 0 || n_particles <= 0 || nx <= 0 || ny <= 0)
+    return fail(ctx, LYNX_ERR_INVALID, "bad argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t es = dtype_size(dtype);
+  const size_t lds = ((size_t)nx + ny + 2) * es;
+  if (lds > 64 * 1024) return fail(ctx, LYNX_ERR_INVALID, "screen resolution too large for the edge table");
+  HIP_TRY(ctx, hipMemsetAsync(d_image, 0, (size_t)batch * nx * ny * sizeof(int32_t), ctx->stream));
+  const int64_t cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+  int64_t chunks = std::max<int64_t>(1, std::min<int64_t>((n_particles + 1023) / 1024, (8 * cus + batch - 1) / batch));
+  if (batch * chunks > 0x7fffffffLL) return fail(ctx, LYNX_ERR_INVALID, "grid too large");
+  if (dtype == LYNX_F64)
+    hipLaunchKernelGGL(k_histogram2d<double>, dim3((unsigned)(batch * chunks)), dim3(256), lds, ctx->stream,
+                       (const double*)d_p, n_particles, (int)chunks, (const double*)d_xedges, (const double*)d_yedges,
+                       nx, ny, d_image);
+  else
+    hipLaunchKernelGGL(k_histogram2d<float>, dim3((unsigned)(batch * chunks)), dim3(256), lds, ctx->stream,
+                       (const float*)d_p, n_particles, (int)chunks, (const float*)d_xedges, (const float*)d_yedges, nx,
+                       ny, d_image);
+  HIP_TRY(ctx, hipGetLastError());
+  return LYNX_OK;
+}
+
+int lynx_gaussian_image(lynx_ctx* ctx, int dtype, int64_t batch, const void* d_mu, const void* d_cov,
+                        const void* d_xs, const void* d_ys, int32_t nx, int32_t ny, void* d_image) {
+  if (!ctx || !d_mu || !d_cov || !d_xs || !d_ys || !d_image || batch <= 0 || nx <= 0 || ny <= 0 || batch > 65535)
+    return fail(ctx, LYNX_ERR_INVALID, "bad argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const unsigned gx = (unsigned)(((int64_t)nx * ny + 255) / 256);
+  if (dtype == LYNX_F64)
+    hipLaunchKernelGGL(k_gaussian_image<double>, dim3(gx, (unsigned)batch), dim3(256), 0, ctx->stream,
+                       (const double*)d_mu, (const double*)d_cov, (const double*)d_xs, (const double*)d_ys, nx, ny,
+                       (double*)d_image);
+  else
+    hipLaunchKernelGGL(k_gaussian_image<float>, dim3(gx, (unsigned)batch), dim3(256), 0, ctx->stream,
+                       (const float*)d_mu, (const float*)d_cov, (const float*)d_xs, (const float*)d_ys, nx, ny,
+                       (float*)d_image);
+  HIP_TRY(ctx, hipGetLastError());
+  return LYNX_OK;
 }
 
 // ---- synthetic beams -------------------------------------------------------------------

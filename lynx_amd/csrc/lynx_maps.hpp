@@ -363,6 +363,67 @@ template <typename T> LYNX_FN T build_cavity(const T* p, int flags, T energy, T*
   return energy_out;
 }
 
+// lynx/accelerator/solenoid.py:61-105.  p = [L, k, mx, my]
+template <typename T> LYNX_FN void build_solenoid(const T* p, int flags, T energy, T* M) {
+  const T L = p[0], k = p[1];
+  const T gamma = energy / T(LYNX_REST_ENERGY);
+  const T c = t_cos(L * k), s = t_sin(L * k);
+  T s_k = L;
+  if (k != T(0)) s_k = s / k;  // :68-70
+  T r56 = T(0);
+  if (gamma != T(0)) {  // :73-76
+    const T gamma2 = gamma * gamma;
+    const T beta = t_sqrt(T(1) - T(1) / gamma2);
+    r56 = r56 - L / (beta * beta * gamma2);
+  }
+  mat_identity(M);
+  M[0 * 7 + 0] = c * c;
+  M[0 * 7 + 1] = c * s_k;
+  M[0 * 7 + 2] = s * c;
+  M[0 * 7 + 3] = s * s_k;
+  M[1 * 7 + 0] = -k * s * c;
+  M[1 * 7 + 1] = c * c;
+  M[1 * 7 + 2] = -k * (s * s);
+  M[1 * 7 + 3] = s * c;
+  M[2 * 7 + 0] = -s * c;
+  M[2 * 7 + 1] = -s * s_k;
+  M[2 * 7 + 2] = c * c;
+  M[2 * 7 + 3] = c * s_k;
+  M[3 * 7 + 0] = k * (s * s);
+  M[3 * 7 + 1] = -s * c;
+  M[3 * 7 + 2] = -k * s * c;
+  M[3 * 7 + 3] = c * c;
+  M[4 * 7 + 5] = r56;
+  if (flags & LYNX_FLAG_MISALIGNED) {  // :98-102, same sandwich as the quadrupole's
+    const T mx = p[2], my = p[3];
+#pragma unroll 1
+    for (int j = 0; j < 7; ++j) {
+      LYNX_FORGET();
+      const T r6 = M[6 * 7 + j];
+      M[0 * 7 + j] = t_fma(mx, r6, M[0 * 7 + j]);
+      M[2 * 7 + j] = t_fma(my, r6, M[2 * 7 + j]);
+    }
+#pragma unroll 1
+    for (int i = 0; i < 7; ++i) {
+      LYNX_FORGET();
+      T acc = M[i * 7 + 0] * (-mx);
+      acc = t_fma(M[i * 7 + 2], -my, acc);
+      M[i * 7 + 6] = acc + M[i * 7 + 6];
+    }
+  }
+}
+
+// lynx/accelerator/undulator.py:48-60 (drift-like; note R56 = +L / gamma^2, no beta). p = [L]
+template <typename T> LYNX_FN void build_undulator(T L, T energy, T* M) {
+  const T gamma = energy / T(LYNX_REST_ENERGY);
+  T igamma2 = T(0);
+  if (gamma != T(0)) igamma2 = T(1) / (gamma * gamma);
+  mat_identity(M);
+  M[0 * 7 + 1] = L;
+  M[2 * 7 + 3] = L;
+  M[4 * 7 + 5] = L * igamma2;
+}
+
 // One element -> M (49 scalars).  `p` points at the element's parameter row of this
 // sample.  Cavity coefficients are produced only for cavity *steps* (coef != nullptr).
 template <typename T>
@@ -399,6 +460,8 @@ LYNX_FN void build_element(int kind, int flags, const T* p, T energy, T* M, T* c
       M[0 * 7 + 6] = p[2] * p[0];
       M[2 * 7 + 6] = p[2] * p[1];
       break;
+    case LYNX_KIND_SOLENOID: build_solenoid(p, flags, energy, M); break;
+    case LYNX_KIND_UNDULATOR: build_undulator(p[0], energy, M); break;
     case LYNX_KIND_CUSTOM:
 #pragma unroll 1
       for (int i = 0; i < 49; ++i) M[i] = p[i];  // custom_transfer_map.py:87-88

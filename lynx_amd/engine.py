@@ -331,9 +331,20 @@ def track(owner, elements, incoming, raw: bool = False):
                 beam = run_program_particles(cache, item, beam)
             else:
                 beam = run_program_parameters(cache, item, beam)
-        else:  # active BPM: bpm.py:48-58
+        else:  # host-side barrier: active BPM (bpm.py:48-58) or active Screen (screen.py:126-141)
             item._observe(beam)
-            beam = beam._shallow_copy()
+            if getattr(item, "_swallows_beam", False):
+                beam = Beam.empty
+            elif beam is not Beam.empty:
+                beam = beam._shallow_copy()
+        if beam is Beam.empty:  # everything behind an active screen sees the empty beam
+            seen = False
+            for later in elements:
+                if later is item:
+                    seen = True
+                elif seen and getattr(later, "_host_barrier", False):
+                    later._observe(beam)
+            return beam
     return beam
 
 

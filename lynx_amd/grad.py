@@ -30,6 +30,8 @@ PARAM_NAMES = {
     _ffi.KIND_HCOR: ["length", "angle"],
     _ffi.KIND_VCOR: ["length", "angle"],
     _ffi.KIND_CAVITY: ["length", "voltage", "phase", "frequency"],
+    _ffi.KIND_SOLENOID: ["length", "k", "misalignment_x", "misalignment_y"],
+    _ffi.KIND_UNDULATOR: ["length"],
 }
 
 

@@ -98,6 +98,19 @@ class ParameterBeam(Beam):
             cor_s=d("cor_s", 0.0), cor_x=-emittance_x * alpha_x, cor_y=-emittance_y * alpha_y,
             total_charge=d("total_charge", 0.0), dtype=dtype)
 
+    @classmethod
+    def from_astra(cls, path: str, device=None, dtype=np.float32) -> "ParameterBeam":
+        """Moments of an ASTRA particle distribution (parameter_beam.py:255-276)."""
+        from ..io.astra import read_astra
+
+        particles, energy, charges = read_astra(path)
+        mu = np.ones(7)
+        mu[:6] = particles.mean(axis=0)
+        cov = np.zeros((7, 7))
+        cov[:6, :6] = np.cov(particles.T)
+        return cls(mu=mu[None], cov=cov[None], energy=np.array([energy]), total_charge=np.array([charges.sum()]),
+                   dtype=dtype)
+
     def transformed_to(self, mu_x=None, mu_xp=None, mu_y=None, mu_yp=None, sigma_x=None, sigma_xp=None,
                        sigma_y=None, sigma_yp=None, sigma_s=None, sigma_p=None, energy=None,
                        total_charge=None, device=None, dtype=None) -> "ParameterBeam":

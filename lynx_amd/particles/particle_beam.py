@@ -214,6 +214,16 @@ class ParticleBeam(Beam):
         return cls(particles=particles, energy=d("energy", 1e8), particle_charges=charges, dtype=dtype)
 
     @classmethod
+    def from_astra(cls, path: str, device=None, dtype=np.float32) -> "ParticleBeam":
+        """Load an ASTRA particle distribution (particle_beam.py:563-578)."""
+        from ..io.astra import read_astra
+
+        particles, energy, charges = read_astra(path)
+        p7 = np.ones((1, particles.shape[0], 7))
+        p7[0, :, :6] = particles
+        return cls(particles=p7, energy=np.array([energy]), particle_charges=charges[None, :], dtype=dtype)
+
+    @classmethod
     def synthetic(cls, batch_shape, num_particles: int, mu=None, sigma=None, energy=1e8, seed: int = 0,
                   dtype=np.float32) -> "ParticleBeam":
         """

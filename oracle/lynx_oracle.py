@@ -51,6 +51,8 @@ ELECTRON_MASS_EV = physical_constants["electron mass energy equivalent in MeV"][
 SPEED_OF_LIGHT = constants.speed_of_light
 
 SKIPPABLE_ALWAYS = (
+    "solenoid",
+    "undulator",
     "drift",
     "quadrupole",
     "dipole",
@@ -217,6 +219,14 @@ def Cavity(length, voltage=None, phase=None, frequency=None):
 
 def CustomTransferMap(transfer_map, length=None):
     return {"kind": "custom", "transfer_map": transfer_map, "length": length}
+
+
+def Solenoid(length, k=None, misalignment=None):
+    return {"kind": "solenoid", "length": length, "k": k, "misalignment": misalignment}
+
+
+def Undulator(length):
+    return {"kind": "undulator", "length": length}
 
 
 def BPM(is_active=False):
@@ -417,6 +427,57 @@ def element_transfer_map(spec, energy, dtype=np.float32):
 
     if kind == "cavity":  # cavity.py:72-79
         return cavity_rmatrix(spec, energy, dtype)
+
+    if kind == "undulator":  # undulator.py:48-60
+        with np.errstate(all="ignore"):
+            gamma = energy / dtype.type(REST_ENERGY)
+            igamma2 = np.zeros_like(gamma)
+            nz = gamma != 0
+            igamma2[nz] = 1 / gamma[nz] ** 2
+            tm = _eye(np.broadcast_shapes(length.shape, energy.shape), dtype)
+            tm[..., 0, 1] = length
+            tm[..., 2, 3] = length
+            tm[..., 4, 5] = length * igamma2
+        return tm
+
+    if kind == "solenoid":  # solenoid.py:61-105 (`if gamma != 0` read per sample)
+        k = _p(spec, "k", length, dtype)
+        mis = spec.get("misalignment")
+        mis = (np.zeros((*length.shape, 2), dtype=dtype) if mis is None else np.asarray(mis, dtype=dtype))
+        with np.errstate(all="ignore"):
+            gamma = np.broadcast_to(energy / dtype.type(REST_ENERGY), length.shape)
+            c = np.cos(length * k)
+            s = np.sin(length * k)
+            s_k = length.copy()
+            nz = k != 0
+            s_k[nz] = s[nz] / k[nz]
+            r56 = np.zeros_like(length)
+            g = gamma != 0
+            gamma2 = gamma[g] * gamma[g]
+            beta = np.sqrt(1.0 - 1.0 / gamma2)
+            r56[g] -= length[g] / (beta * beta * gamma2)
+            R = _eye(length.shape, dtype)
+            R[..., 0, 0] = c**2
+            R[..., 0, 1] = c * s_k
+            R[..., 0, 2] = s * c
+            R[..., 0, 3] = s * s_k
+            R[..., 1, 0] = -k * s * c
+            R[..., 1, 1] = c**2
+            R[..., 1, 2] = -k * s**2
+            R[..., 1, 3] = s * c
+            R[..., 2, 0] = -s * c
+            R[..., 2, 1] = -s * s_k
+            R[..., 2, 2] = c**2
+            R[..., 2, 3] = c * s_k
+            R[..., 3, 0] = k * s**2
+            R[..., 3, 1] = -s * c
+            R[..., 3, 2] = -k * s * c
+            R[..., 3, 3] = c**2
+            R[..., 4, 5] = r56
+        if np.all(mis == 0):
+            return R
+        R_entry, R_exit = misalignment_matrix(mis)
+        return _matmul(_matmul(R_exit, R), R_entry)
 
     raise ValueError(f"unknown element kind {kind!r}")
 
@@ -809,3 +870,49 @@ def fodo_segment(n_cells=32, dtype=np.float64, batch_shape=(1,), k1_scale=None):
     for _ in range(n_cells):
         cell += [Quadrupole(f(0.2), k1=k), Drift(f(0.5)), Quadrupole(f(0.2), k1=-k), Drift(f(0.5))]
     return cell
+
+
+# ---------------------------------------------------------------------------------
+# Screen read-out (lynx/accelerator/screen.py:86-216)
+# ---------------------------------------------------------------------------------
+
+
+def screen_bin_edges(resolution, pixel_size, binning, dtype=np.float32):
+    """screen.py:107-120 (`pixel_bin_edges`)."""
+    resolution, pixel_size = np.asarray(resolution, dtype), np.asarray(pixel_size, dtype)
+    eff = resolution / np.asarray(binning, dtype)
+    half = resolution * pixel_size / 2
+    return (np.linspace(-half[0], half[0], int(eff[0]) + 1, dtype=dtype),
+            np.linspace(-half[1], half[1], int(eff[1]) + 1, dtype=dtype))
+
+
+def screen_reading_particles(particles, resolution, pixel_size, binning, dtype=np.float32):
+    """screen.py:196-213: histogramdd of (x, y) per sample, then flipud(hist.T)."""
+    edges = screen_bin_edges(resolution, pixel_size, binning, dtype)
+    P = np.asarray(particles, dtype=dtype)
+    flat = P.reshape(-1, P.shape[-2], 7)
+    images = []
+    for sample in flat:
+        hist, _ = np.histogramdd(np.stack((sample[:, 0], sample[:, 2])).T, bins=edges)
+        images.append(np.flipud(hist.T))
+    return np.stack(images).reshape(*P.shape[:-2], *images[0].shape).astype(dtype)
+
+
+def screen_reading_parameters(mu, cov, resolution, pixel_size, binning, dtype=np.float32):
+    """screen.py:160-195: exp(log_prob) of MultivariateNormal((mu_x, mu_y), cov_xy) on the pixel grid."""
+    dtype = np.dtype(dtype)
+    resolution, pixel_size = np.asarray(resolution, dtype), np.asarray(pixel_size, dtype)
+    half = resolution * pixel_size / 2
+    step = pixel_size * np.asarray(binning, dtype)
+    xs = np.arange(-half[0], half[0], step[0], dtype=dtype).astype(np.float64)
+    ys = np.arange(-half[1], half[1], step[1], dtype=dtype).astype(np.float64)
+    mu, cov = np.asarray(mu, np.float64), np.asarray(cov, np.float64)
+    out = []
+    for m, c in zip(mu.reshape(-1, 7), cov.reshape(-1, 7, 7)):
+        s2 = np.array([[c[0, 0], c[0, 2]], [c[2, 0], c[2, 2]]])
+        inv, det = np.linalg.inv(s2), np.linalg.det(s2)
+        dx, dy = xs[:, None] - m[0], ys[None, :] - m[2]
+        maha = inv[0, 0] * dx * dx + 2 * inv[0, 1] * dx * dy + inv[1, 1] * dy * dy
+        img = np.exp(-0.5 * maha - np.log(2 * np.pi) - 0.5 * np.log(det))
+        out.append(img[::-1])  # flip(dims=[1]) of the stacked (B, nx, ny) image
+    return np.stack(out).reshape(*mu.shape[:-1], len(xs), len(ys))

@@ -14,7 +14,8 @@ def make_lattice(desc, dtype, lx=None):
     """
     ctor_o = {"drift": o.Drift, "quadrupole": o.Quadrupole, "dipole": o.Dipole, "rbend": o.RBend,
               "hcor": o.HorizontalCorrector, "vcor": o.VerticalCorrector, "cavity": o.Cavity,
-              "custom": o.CustomTransferMap, "bpm": o.BPM, "marker": o.Marker}
+              "custom": o.CustomTransferMap, "bpm": o.BPM, "marker": o.Marker, "solenoid": o.Solenoid,
+              "undulator": o.Undulator}
     specs, elements = [], []
     for kind, kw in desc:
         kw_t = {k: (np.asarray(v, dtype=dtype) if isinstance(v, (np.ndarray, list, float)) else v)
@@ -23,7 +24,8 @@ def make_lattice(desc, dtype, lx=None):
         if lx is not None:
             ctor_x = {"drift": lx.Drift, "quadrupole": lx.Quadrupole, "dipole": lx.Dipole, "rbend": lx.RBend,
                       "hcor": lx.HorizontalCorrector, "vcor": lx.VerticalCorrector, "cavity": lx.Cavity,
-                      "custom": lx.CustomTransferMap, "bpm": lx.BPM, "marker": lx.Marker}
+                      "custom": lx.CustomTransferMap, "bpm": lx.BPM, "marker": lx.Marker, "solenoid": lx.Solenoid,
+                      "undulator": lx.Undulator}
             if kind in ("bpm", "marker"):
                 elements.append(ctor_x[kind](**kw_t))
             else:

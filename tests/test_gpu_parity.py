@@ -84,6 +84,9 @@ ELEMENT_CASES = [
                     frequency=[1.3e9, 1.3e9, 1.3e9])),
     ("marker", dict()),
     ("bpm", dict()),
+    ("solenoid", dict(length=[0.5, 0.3, 0.0], k=[2.0, 0.0, 1.0])),
+    ("solenoid", dict(length=[0.5, 0.3, 0.2], k=[2.0, -1.5, 1.0], misalignment=[[1e-3, -2e-3], [0.0, 0.0], [1e-4, 0.0]])),
+    ("undulator", dict(length=[0.25, 1.0, 0.0])),
 ]
 
 

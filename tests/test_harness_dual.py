@@ -25,6 +25,8 @@ CASES = [
     (_ffi.KIND_CAVITY, _ffi.FLAG_CAV_BETA | _ffi.FLAG_CAV_GAIN, [1.0, -3e6, 20.0, 2.856e9], 1e8),
     (_ffi.KIND_BASE_RMATRIX, _ffi.FLAG_TILT, [0.4, 2.0, 0.3, 0.2], 1e8),
     (_ffi.KIND_ROTATION, 0, [0.7], 1e8),
+    (_ffi.KIND_SOLENOID, _ffi.FLAG_MISALIGNED, [0.5, 2.0, 1e-3, -2e-3], 6e6),
+    (_ffi.KIND_UNDULATOR, 0, [0.8], 6e6),
 ]
 
 

@@ -143,3 +143,15 @@ def test_custom_and_identity(host_harness):
     assert np.array_equal(got, tm)
     got, _ = harness_map(host_harness, _ffi.KIND_IDENTITY, 0, [], 1e8, np.float64)
     assert np.array_equal(got, np.eye(7))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_solenoid_and_undulator(host_harness, dtype):
+    a = lambda v: np.array([v], dtype=dtype)  # noqa: E731
+    for L, k, mis, energy in ((0.5, 2.0, (0.0, 0.0), 1e8), (0.3, 0.0, (0.0, 0.0), 6e6), (0.4, -1.5, (1e-3, -2e-3), 1e8),
+                              (0.2, 1.0, (0.0, 0.0), 0.0)):
+        flags = _ffi.FLAG_MISALIGNED if any(mis) else 0
+        spec = o.Solenoid(a(L), k=a(k), misalignment=np.asarray([mis], dtype=dtype))
+        _check(host_harness, _ffi.KIND_SOLENOID, flags, [L, k, mis[0], mis[1]], energy, spec, dtype)
+    for L, energy in ((0.25, 1e8), (1.0, 6e6), (0.5, 0.0)):
+        _check(host_harness, _ffi.KIND_UNDULATOR, 0, [L], energy, o.Undulator(a(L)), dtype)
