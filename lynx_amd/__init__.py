@@ -5,25 +5,10 @@ restricted to the elements on the path).  Compute runs in hand-written HIP kerne
 (`lynx_amd/csrc`) behind the C ABI in `include/lynx_hip.h`; there is no CPU fallback.
 """
 
-from . import config  # noqa: F401
-from .accelerator import (  # noqa: F401
-    BPM,
-    Aperture,
-    Cavity,
-    CustomTransferMap,
-    Dipole,
-    Drift,
-    Element,
-    HorizontalCorrector,
-    Marker,
-    Quadrupole,
-    RBend,
-    Screen,
-    Segment,
-    Solenoid,
-    Undulator,
-    VerticalCorrector,
-)
-from .particles import Beam, ParameterBeam, ParticleBeam  # noqa: F401
+from . import config
+from .accelerator import *  # noqa: F401,F403  (the element classes and Segment)
+from .accelerator import __all__ as _elements
+from .particles import Beam, ParameterBeam, ParticleBeam
 
+__all__ = ["config", "Beam", "ParameterBeam", "ParticleBeam", *_elements]
 __version__ = "0.1.0"

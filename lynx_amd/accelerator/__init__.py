@@ -1,12 +1,10 @@
-from .bpm import BPM, Marker  # noqa: F401
-from .cavity import Cavity  # noqa: F401
-from .corrector import HorizontalCorrector, VerticalCorrector  # noqa: F401
-from .custom_transfer_map import CustomTransferMap  # noqa: F401
-from .dipole import Dipole, RBend  # noqa: F401
-from .drift import Drift  # noqa: F401
-from .element import Element  # noqa: F401
-from .quadrupole import Quadrupole  # noqa: F401
-from .aperture import Aperture  # noqa: F401
-from .screen import Screen  # noqa: F401
-from .segment import Segment  # noqa: F401
-from .solenoid import Solenoid, Undulator  # noqa: F401
+"""Lattice description: elements (schema over `Element`), diagnostics, and `Segment`."""
+
+from .diagnostics import BPM, Aperture, Marker, Screen
+from .element import Element
+from .magnets import (Cavity, CustomTransferMap, Dipole, Drift, HorizontalCorrector, Quadrupole, RBend, Solenoid,
+                      Undulator, VerticalCorrector)
+from .segment import Segment
+
+__all__ = ["Aperture", "BPM", "Cavity", "CustomTransferMap", "Dipole", "Drift", "Element", "HorizontalCorrector",
+           "Marker", "Quadrupole", "RBend", "Screen", "Segment", "Solenoid", "Undulator", "VerticalCorrector"]

@@ -1,8 +1,11 @@
 """
-Diagnostic screen (lynx/accelerator/screen.py:22-271).  An active screen swallows the beam
-(`track` returns `Beam.empty`) and renders it on read: 2-D histogram of (x, y) for a
-`ParticleBeam`, bivariate-normal density for a `ParameterBeam` -- both on the GPU
-(`lynx_histogram2d`, `lynx_gaussian_image`).  Plotting is out of scope.
+Elements that observe the beam instead of transforming it: `BPM`, `Marker`, `Screen`,
+`Aperture` (lynx/accelerator/bpm.py:24-80, marker.py:22-64, screen.py:22-271,
+aperture.py:23-153).  All are identity elements for the kernels; an active BPM or Screen is a
+host-side barrier of `engine.track`.  An active screen swallows the beam (`track` returns
+`Beam.empty`) and renders it on read: exact 2-D histogram of (x, y) for a `ParticleBeam`,
+bivariate-normal density for a `ParameterBeam`, both on the GPU (`lynx_histogram2d`,
+`lynx_gaussian_image`).  Plotting is out of scope.
 """
 
 from __future__ import annotations
@@ -14,7 +17,106 @@ import numpy as np
 
 from .. import _ffi
 from ..device import Dual, dtype_code, get_runtime
-from .element import Element, _rep
+from .element import Element
+
+
+def _beam_types():
+    from ..particles.beam import Beam
+    from ..particles.parameter_beam import ParameterBeam
+    from ..particles.particle_beam import ParticleBeam
+
+    return Beam, ParameterBeam, ParticleBeam
+
+
+class Marker(Element):
+    """General Marker / Monitor element (identity map)."""
+
+    _skippable = True
+
+    def track(self, incoming):
+        return incoming  # marker.py:37-40
+
+    def __repr__(self) -> str:
+        return f"{type(self).__name__}(name={self.name!r})"
+
+
+class BPM(Element):
+    """
+    Beam Position Monitor (BPM) in a particle accelerator.
+
+    :param is_active: If `True` the BPM records the beam position `[mu_x, mu_y]` in `reading`.
+    :param name: Unique identifier of the element.
+    """
+
+    _transient = Element._transient + ("reading",)
+    reading = None
+
+    def __init__(self, is_active: bool = False, name: Optional[str] = None) -> None:
+        super().__init__(name=name)
+        self.is_active = is_active
+        self.reading = None
+
+    @property
+    def is_skippable(self) -> bool:
+        return not self.is_active
+
+    @property
+    def _host_barrier(self) -> bool:
+        return bool(self.is_active)
+
+    def _observe(self, incoming) -> None:
+        """bpm.py:48-54."""
+        if incoming is _beam_types()[0].empty:
+            self.reading = None
+        else:
+            self.reading = np.stack([np.asarray(incoming.mu_x), np.asarray(incoming.mu_y)])
+
+    def track(self, incoming):
+        """Record the reading (also when inactive, as bpm.py:48-58 does) and return a copy."""
+        Beam, ParameterBeam, ParticleBeam = _beam_types()
+        if incoming is not Beam.empty and not isinstance(incoming, (ParameterBeam, ParticleBeam)):
+            raise TypeError(f"Parameter incoming is of invalid type {type(incoming)}")
+        self._observe(incoming)
+        return incoming if incoming is Beam.empty else incoming._shallow_copy()
+
+    def __repr__(self) -> str:
+        return f"{type(self).__name__}(name={self.name!r})"
+
+
+class Aperture(Element):
+    """
+    Physical aperture, kept as a parameter holder so that lattices containing one load.  An
+    inactive aperture is an identity element; an active one drops particles, which changes N
+    per batch sample -- out of scope of the fixed-shape streaming path
+    and refused loudly.
+
+    :param x_max: half size horizontal offset in [m]
+    :param y_max: half size vertical offset in [m]
+    :param shape: "rectangular" or "elliptical".
+    :param is_active: If the aperture actually blocks particles.
+    """
+
+    _batched = (("x_max", 0), ("y_max", 0))
+    _settings = ("shape", "is_active")
+
+    def __init__(self, x_max=None, y_max=None, shape: str = "rectangular", is_active: bool = True,
+                 name: Optional[str] = None, device=None, dtype=np.float32) -> None:
+        super().__init__(name=name)
+        self.x_max = np.asarray(np.inf if x_max is None else x_max, dtype=dtype)
+        self.y_max = np.asarray(np.inf if y_max is None else y_max, dtype=dtype)
+        self.shape = shape
+        self.is_active = is_active
+        self.lost_particles = None
+
+    @property
+    def is_skippable(self) -> bool:
+        return not self.is_active
+
+    def track(self, incoming):
+        if self.is_active:
+            raise NotImplementedError("an active Aperture changes the particle count per sample; "
+                                      "lynx_amd does not build ragged particle loss")
+        return incoming
 
 
 class Screen(Element):
@@ -29,7 +131,11 @@ class Screen(Element):
     :param name: Unique identifier of the element.
     """
 
-    _kind = _ffi.KIND_IDENTITY
+    _batched = (("misalignment", 2),)
+    _settings = ("resolution", "pixel_size", "binning", "is_active")
+    _transient = Element._transient + ("_read_beam", "_cached_reading")
+    _read_beam = None
+    _cached_reading = None
 
     def __init__(self, resolution=None, pixel_size=None, binning=None, misalignment=None, is_active: bool = False,
                  name: Optional[str] = None, device=None, dtype=np.float32) -> None:
@@ -78,9 +184,7 @@ class Screen(Element):
 
     def _observe(self, incoming) -> None:
         """screen.py:126-139: park a misalignment-corrected copy of the beam."""
-        from ..particles.beam import Beam
-        from ..particles.parameter_beam import ParameterBeam
-
+        Beam, ParameterBeam, _ = _beam_types()
         if incoming is Beam.empty:
             self.set_read_beam(incoming)
             return
@@ -103,11 +207,9 @@ class Screen(Element):
         self.set_read_beam(copy)
 
     def track(self, incoming):
-        from ..particles.beam import Beam
-
         if self.is_active:
             self._observe(incoming)
-            return Beam.empty
+            return _beam_types()[0].empty
         return incoming
 
     def get_read_beam(self):
@@ -122,10 +224,7 @@ class Screen(Element):
     def reading(self) -> np.ndarray:
         if self._cached_reading is not None:
             return self._cached_reading
-        from ..particles.beam import Beam
-        from ..particles.parameter_beam import ParameterBeam
-        from ..particles.particle_beam import ParticleBeam
-
+        Beam, ParameterBeam, ParticleBeam = _beam_types()
         beam = self.get_read_beam()
         nx, ny = int(self.effective_resolution[0]), int(self.effective_resolution[1])
         if beam is Beam.empty or beam is None:
@@ -159,21 +258,6 @@ class Screen(Element):
         self._cached_reading = image
         return image
 
-    def broadcast(self, shape: tuple) -> Element:
-        new = self.__class__(resolution=self.resolution, pixel_size=self.pixel_size, binning=self.binning,
-                             misalignment=_rep(self.misalignment, (*shape, 1)), is_active=self.is_active,
-                             name=self.name, dtype=self.resolution.dtype)
-        new.length = _rep(self.length, shape)
-        return new
-
-    def split(self, resolution) -> list:
-        return [self]
-
     @property
     def defining_features(self) -> list:
-        return super().defining_features + ["resolution", "pixel_size", "binning", "misalignment", "is_active"]
-
-    def __repr__(self) -> str:
-        return (f"{self.__class__.__name__}(resolution={repr(self.resolution)}, pixel_size={repr(self.pixel_size)}, "
-                f"binning={repr(self.binning)}, misalignment={repr(self.misalignment)}, "
-                f"is_active={repr(self.is_active)}, name={repr(self.name)})")
+        return ["resolution", "pixel_size", "binning", "misalignment", "is_active"]

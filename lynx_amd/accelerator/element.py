@@ -1,19 +1,34 @@
 """
-Base class of the lattice elements: the reference's `Element`
-(lynx/accelerator/element.py:23-149) as a plain Python parameter holder.  `track` and
-`transfer_map` run on the GPU through `lynx_amd.engine`.
+Lattice elements as *parameter holders with a schema*.
+
+The reference spells every element class out by hand (lynx/accelerator/element.py:23-149 and
+one module per kind).  Here a class only declares
+
+* `_kind`      -- the `lynx_kind` the kernels dispatch on (include/lynx_hip.h),
+* `_batched`   -- its per-sample parameters as `(attribute, trailing components)`,
+* `_row`       -- the order of those parameters in the kind's parameter row of the C ABI,
+* `_settings`  -- non-batched attributes that are part of the element's identity,
+
+and the base class derives packing, `broadcast`, `split`, `defining_features` and `repr` from
+that.  `track` / `transfer_map` run on the GPU through `lynx_amd.engine`; nothing here computes.
 """
 
 from __future__ import annotations
 
+import copy
+import itertools
 from typing import Optional
 
 import numpy as np
 
 from .. import _ffi, engine
-from ..utils import UniqueNameGenerator
 
-generate_unique_name = UniqueNameGenerator(prefix="unnamed_element")
+_anonymous = itertools.count()
+
+
+def generate_unique_name() -> str:
+    """Names of elements constructed without one: unnamed_element_0, _1, ... (lynx/utils.py:1-11)."""
+    return f"unnamed_element_{next(_anonymous)}"
 
 
 def _arr(value, dtype):
@@ -22,8 +37,11 @@ def _arr(value, dtype):
 
 def _rep(value, shape):
     """`Tensor.repeat(shape)` as the reference's `broadcast` uses it (e.g. drift.py:64-65)."""
-    value = np.asarray(value)
-    return np.tile(value, tuple(shape))
+    return np.tile(np.asarray(value), tuple(shape))
+
+
+def _float_dtype(energy, fallback):
+    return energy.dtype if energy.dtype in (np.float32, np.float64) else fallback
 
 
 class Element:
@@ -34,7 +52,13 @@ class Element:
     """
 
     _kind = _ffi.KIND_IDENTITY
+    _batched: tuple = ()
+    _row: tuple = ()
+    _settings: tuple = ()
+    _kept_on_broadcast: tuple = ()  # parameters `broadcast` passes on unrepeated
+    _transient: tuple = ("_lattice_cache",)  # never shared between an element and its copies
     _host_barrier = False
+    _skippable: Optional[bool] = None
     _version = 0
     length = np.zeros((1,), dtype=np.float32)
 
@@ -47,10 +71,37 @@ class Element:
         if not key.startswith("_"):
             object.__setattr__(self, "_version", self._version + 1)
 
+    def _adopt(self, dtype, length, **given) -> None:
+        """
+        Store the batched parameters: `length` fixes the batch shape, every parameter left
+        `None` becomes zeros of that shape (plus its trailing components).
+        """
+        self.length = _arr(length, dtype)
+        tails = dict(self._batched)
+        for attr, value in given.items():
+            if value is None:
+                value = np.zeros((*self.length.shape, *((tails[attr],) if tails[attr] else ())), dtype=dtype)
+            setattr(self, attr, _arr(value, dtype))
+
     # -- what the kernels need ---------------------------------------------------------------
     def _param_rows(self, dtype) -> list:
         """Parameter arrays in the kernel's fixed per-kind order (include/lynx_hip.h)."""
-        return []
+        tails = dict(self._batched)
+        rows = []
+        for attr in self._row:
+            value = np.asarray(getattr(self, attr))
+            if tails.get(attr):
+                rows.extend(value[..., i] for i in range(tails[attr]))
+            else:
+                rows.append(value)
+        return rows
+
+    @classmethod
+    def _row_names(cls) -> list:
+        """Names of the parameter-row slots; a vector parameter `v` contributes `v_x`, `v_y`."""
+        tails = dict(cls._batched)
+        return [name for attr in cls._row
+                for name in ([f"{attr}_{axis}" for axis in "xyz"[: tails[attr]]] if tails.get(attr) else [attr])]
 
     def _static_flags(self) -> int:
         return 0
@@ -66,8 +117,7 @@ class Element:
         (lynx/accelerator/element.py:37-59), batched over `energy.shape`.
         """
         energy = np.asarray(energy)
-        dtype = energy.dtype if energy.dtype in (np.float32, np.float64) else self.dtype
-        return engine.transfer_map(self, [self], energy, dtype, raw=True)
+        return engine.transfer_map(self, [self], energy, _float_dtype(energy, self.dtype), raw=True)
 
     def track(self, incoming):
         """Track a `ParameterBeam` or `ParticleBeam` through the element (element.py:61-94)."""
@@ -78,22 +128,50 @@ class Element:
 
     __call__ = forward
 
+    def _twin(self) -> "Element":
+        """Same class, name and parameters; none of the transient state."""
+        twin = copy.copy(self)
+        for key in self._transient:
+            twin.__dict__.pop(key, None)
+        return twin
+
     def broadcast(self, shape: tuple) -> "Element":
-        raise NotImplementedError
+        """Repeat the batched parameters `shape` times (`Tensor.repeat` semantics, e.g. drift.py:64-65)."""
+        twin = self._twin()
+        for attr, tail in (("length", 0), *self._batched):
+            if attr in self._kept_on_broadcast:
+                continue
+            object.__setattr__(twin, attr, _rep(getattr(self, attr), (*shape, *((1,) if tail else ()))))
+        return twin
 
     @property
     def is_skippable(self) -> bool:
-        raise NotImplementedError
+        if self._skippable is None:
+            raise NotImplementedError
+        return self._skippable
 
     @property
     def defining_features(self) -> list:
-        return []
+        names = [attr for attr, _ in self._batched]
+        if "length" in self._row:
+            names.insert(0, "length")
+        return names + list(self._settings)
 
     def split(self, resolution) -> list:
-        raise NotImplementedError
+        """Elements without a lengthwise split return themselves (e.g. dipole.py:196-199)."""
+        return [self]
+
+    def _slices(self, resolution):
+        """Lengths of the pieces of `split`: `resolution` each, the remainder last (drift.py:71-78)."""
+        remaining = float(np.asarray(self.length).reshape(-1)[0])
+        resolution = float(np.asarray(resolution).reshape(-1)[0])
+        while remaining > 0:
+            yield np.array([min(resolution, remaining)], dtype=self.dtype)
+            remaining -= resolution
 
     def plot(self, ax, s: float) -> None:
         raise NotImplementedError("plotting is out of scope of lynx_amd (matplotlib cosmetics)")
 
     def __repr__(self) -> str:
-        return f"{self.__class__.__name__}(name={repr(self.name)})"
+        shown = [f"{attr}={getattr(self, attr)!r}" for attr in self.defining_features]
+        return f"{type(self).__name__}({', '.join(shown + [f'name={self.name!r}'])})"

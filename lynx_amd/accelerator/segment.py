@@ -11,10 +11,9 @@ from typing import Optional
 import numpy as np
 
 from .. import engine
-from .custom_transfer_map import CustomTransferMap
-from .drift import Drift
+from .diagnostics import Marker
+from .magnets import CustomTransferMap, Drift
 from .element import Element
-from .bpm import Marker
 
 
 class Segment(Element):

@@ -23,16 +23,9 @@ from . import _ffi, engine
 from .device import get_runtime
 from .particles.particle_beam import ParticleBeam, _tri
 
-PARAM_NAMES = {
-    _ffi.KIND_DRIFT: ["length"],
-    _ffi.KIND_QUADRUPOLE: ["length", "k1", "tilt", "misalignment_x", "misalignment_y"],
-    _ffi.KIND_DIPOLE: ["length", "angle", "e1", "e2", "tilt", "fringe_integral", "fringe_integral_exit", "gap"],
-    _ffi.KIND_HCOR: ["length", "angle"],
-    _ffi.KIND_VCOR: ["length", "angle"],
-    _ffi.KIND_CAVITY: ["length", "voltage", "phase", "frequency"],
-    _ffi.KIND_SOLENOID: ["length", "k", "misalignment_x", "misalignment_y"],
-    _ffi.KIND_UNDULATOR: ["length"],
-}
+# kinds whose parameter row is differentiated; the slot names come from the element's schema
+DIFFERENTIABLE_KINDS = (_ffi.KIND_DRIFT, _ffi.KIND_QUADRUPOLE, _ffi.KIND_DIPOLE, _ffi.KIND_HCOR, _ffi.KIND_VCOR,
+                        _ffi.KIND_CAVITY, _ffi.KIND_SOLENOID, _ffi.KIND_UNDULATOR)
 
 
 def _unbroadcast(grad: np.ndarray, shape) -> np.ndarray:
@@ -72,18 +65,18 @@ class Gradients:
         return _unbroadcast(self._energy_dev.numpy().reshape(self._batch_shape), self._energy_shape)
 
     def __contains__(self, element) -> bool:
-        return any(el is element and el._kind in PARAM_NAMES for el in self._program.leaves)
+        return any(el is element and el._kind in DIFFERENTIABLE_KINDS for el in self._program.leaves)
 
     def __getitem__(self, element) -> dict:
         if id(element) in self._cache:
             return self._cache[id(element)]
-        from .accelerator.dipole import RBend
+        from .accelerator.magnets import RBend
 
         raw, total = self._host(), None
         for e, el in enumerate(self._program.leaves):
-            if el is not element or el._kind not in PARAM_NAMES:
+            if el is not element or el._kind not in DIFFERENTIABLE_KINDS:
                 continue
-            g = {n: raw[..., e, j] for j, n in enumerate(PARAM_NAMES[el._kind])}
+            g = {n: raw[..., e, j] for j, n in enumerate(el._row_names())}
             out = {}
             if "misalignment_x" in g:
                 mis = np.stack([g.pop("misalignment_x"), g.pop("misalignment_y")], axis=-1)

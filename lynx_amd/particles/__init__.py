@@ -1,3 +1,7 @@
-from .beam import Beam  # noqa: F401
-from .parameter_beam import ParameterBeam  # noqa: F401
-from .particle_beam import ParticleBeam  # noqa: F401
+"""Beam containers: moments-only (`ParameterBeam`) and macro-particles in HBM (`ParticleBeam`)."""
+
+from .beam import Beam
+from .parameter_beam import ParameterBeam
+from .particle_beam import ParticleBeam
+
+__all__ = ["Beam", "ParameterBeam", "ParticleBeam"]
