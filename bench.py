@@ -245,6 +245,13 @@ def main():
     if gathered is not None and not args.grad:
         g = np.asarray(gathered)
         assert g.shape == (world, batch, 36) and np.allclose(g[rank], rec.reshape(batch, 36))
+        if batch == 1 and world > 1:
+            # one sample: the ranks hold disjoint particle slices of one beam (SURVEY.md section 8e,
+            # secondary partitioning); its record is the merge of the gathered slice records
+            from lynx_amd.parallel import merge_records
+
+            whole = merge_records(g)
+            assert whole[0, 35] == world * particles and np.all(np.isfinite(whole)), "bench: bad merged record"
 
     copy_gbs = None
     if rank == 0 and world == 1:
@@ -293,7 +300,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {descr}", "batch_per_gpu": batch, "global_batch": batch * world,
                        "particles": particles, "elements": n_elements, "fused_moments": not args.no_moments, "reverse_pass": bool(args.grad),
-                       "gather": gather_kind, "parallelism": f"batch-sharded x{world}"},
+                       "gather": gather_kind, "parallelism": f"{'particle' if batch == 1 else 'batch'}-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": "k_track_direct", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                          "traffic": traffic, "traffic_source": traffic_src,

@@ -7,6 +7,16 @@ latency-bound, so no bucketing or ring tuning applies.
 The reference has no counterpart (single process); batch samples are independent in
 every function of the path.
 
+Two partitionings:
+
+* **batch-sharded** (C4, C5): `shard_batch` + `assemble_records` -- records are only reordered;
+* **particle-sharded** (C3, one sample with many particles): `shard_particles` gives each rank
+  a contiguous slice of N, every rank builds the same composed map (cheaper than a broadcast),
+  and `merge_records` combines the gathered per-slice records into the record of the whole
+  beam with the pairwise mean / co-moment update (Chan et al.), in rank order, in float64 --
+  deterministic, and no second collective is needed because the gather already delivered every
+  slice's (count, mean, covariance).
+
 Rendezvous: the 128-byte RCCL unique id made by rank 0 has to reach every rank.  The
 package does not choose how (`exchange` callable); bench.py uses torch.distributed's
 store, tests use a gloo broadcast.
@@ -40,6 +50,35 @@ def assemble_records(gathered: np.ndarray, global_batch: int, n_ranks: int) -> n
     for r in range(n_ranks):
         a, b = shard_batch(global_batch, n_ranks, r)
         out[a:b] = gathered[r, : b - a]
+    return out
+
+
+def shard_particles(num_particles: int, n_ranks: int, rank: int) -> tuple:
+    """Contiguous slice [start, stop) of the particle axis owned by `rank`."""
+    return shard_batch(num_particles, n_ranks, rank)
+
+
+def merge_records(gathered: np.ndarray) -> np.ndarray:
+    """
+    (n_ranks, ..., 36) records of disjoint particle slices of the same beam(s) -> (..., 36)
+    record of the union: n = sum n_r; mean = sum n_r mean_r / n (folded pairwise);
+    cov = [n_a cov_a + n_b cov_b + (n_a n_b / n) d d^T] / n with d = mean_b - mean_a
+    (biased covariances, layout of include/lynx_hip.h).
+    """
+    gathered = np.asarray(gathered, dtype=np.float64)
+    out = gathered[0].copy()
+    iu = [(i, j) for i in range(6) for j in range(i, 6)]  # slots 7..27, row-major upper triangle
+    for part in gathered[1:]:
+        na, nb = out[..., 35], part[..., 35]
+        n = na + nb
+        with np.errstate(invalid="ignore", divide="ignore"):
+            wa = np.where(n > 0, na / n, 0.0)
+            wb = np.where(n > 0, nb / n, 0.0)
+        d = part[..., :7] - out[..., :7]
+        for slot, (i, j) in enumerate(iu, start=7):
+            out[..., slot] = wa * out[..., slot] + wb * part[..., slot] + wa * wb * d[..., i] * d[..., j]
+        out[..., :7] = out[..., :7] + wb[..., None] * d
+        out[..., 35] = n
     return out
 
 

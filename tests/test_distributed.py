@@ -11,7 +11,7 @@ import socket
 import numpy as np
 import pytest
 
-from lynx_amd.parallel import assemble_records, shard_batch
+from lynx_amd.parallel import assemble_records, merge_records, shard_batch, shard_particles
 from oracle import lynx_oracle as o
 
 torch = pytest.importorskip("torch")
@@ -40,6 +40,43 @@ def _records(batch_slice):
             k += 1
     rec[:, 35] = N_PART
     return rec
+
+
+def _record_of(Q):
+    """Moment record(s) of particles Q (..., n, 7), layout of include/lynx_hip.h."""
+    rec = np.zeros((*Q.shape[:-2], 36))
+    rec[..., :7] = Q.mean(axis=-2)
+    k = 7
+    for i in range(6):
+        for j in range(i, 6):
+            rec[..., k] = ((Q[..., i] - rec[..., i, None]) * (Q[..., j] - rec[..., j, None])).mean(axis=-1)
+            k += 1
+    rec[..., 35] = Q.shape[-2]
+    return rec
+
+
+def _tracked_single_sample():
+    """C3-style case: one sample, every rank builds the same map, particles are what is sharded."""
+    specs = o.fodo_segment(4, np.float64, (1,))
+    P = o.gaussian_particles((1,), 3001, seed=9, dtype=np.float64, sigma=[1e-4, 1e-5, 1e-4, 1e-5, 1e-5, 1e-3],
+                             mu=[1e-3, 0, -2e-3, 0, 0, 0])
+    return specs, P
+
+
+def _particle_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        specs, P = _tracked_single_sample()
+        a, b = shard_particles(P.shape[1], world, rank)
+        out = o.segment_track(specs, o.particle_beam(P[:, a:b], np.full(1, 1e8), np.float64), np.float64)
+        local = torch.from_numpy(_record_of(out["particles"]))
+        gathered = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        q.put((rank, merge_records(np.stack([g.numpy() for g in gathered]))))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
 
 
 def _worker(rank, world, port, q):
@@ -95,3 +132,41 @@ def test_world_size_2_gather_equals_single_process():
         assert full.shape == (GLOBAL_BATCH, 36)
         assert np.array_equal(full, reference), rank  # every rank holds the whole batch, in batch order
         assert tmax == 2.0
+
+
+def test_merge_records_is_the_record_of_the_union():
+    rng = np.random.default_rng(3)
+    Q = rng.normal(size=(5, 1000, 7)) * [1e-4, 1e-5, 1e-4, 1e-5, 1e-5, 1e-3, 0] + [5e-3, 0, -1e-3, 0, 0, 0, 1]
+    whole = _record_of(Q)
+    for cuts in ([0, 1000], [0, 1, 1000], [0, 333, 334, 1000], [0, 500, 500, 1000]):  # incl. an empty slice
+        parts = []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            part = _record_of(Q[:, a:b]) if b > a else np.zeros((5, 36))
+            parts.append(part)
+        merged = merge_records(np.stack(parts))
+        assert np.array_equal(merged[..., 35], whole[..., 35])
+        np.testing.assert_allclose(merged[..., :7], whole[..., :7], rtol=1e-13, atol=1e-18)
+        np.testing.assert_allclose(merged[..., 7:28], whole[..., 7:28], rtol=1e-10, atol=1e-24)
+
+
+def test_world_size_2_particle_sharding_equals_single_process():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_particle_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    specs, P = _tracked_single_sample()
+    out = o.segment_track(specs, o.particle_beam(P, np.full(1, 1e8), np.float64), np.float64)
+    reference = _record_of(out["particles"])
+    assert np.array_equal(results[0][1], results[1][1])  # same merge order on every rank
+    for _, merged in results:
+        np.testing.assert_allclose(merged[..., :7], reference[..., :7], rtol=1e-12, atol=1e-18)
+        np.testing.assert_allclose(merged[..., 7:28], reference[..., 7:28], rtol=1e-9, atol=1e-24)
+        assert merged[0, 35] == 3001

@@ -563,6 +563,36 @@ def test_rccl_communicator_single_rank(lx):
         comm.close()
 
 
+def test_particle_sharded_moments_merge_to_the_whole_beam(lx):
+    """
+    SURVEY.md section 8e, secondary partitioning: slices of one beam tracked separately (as the
+    ranks of a particle-sharded run do) and merged with `merge_records` give the whole beam's
+    record; the tracked particles of a slice are bit-identical to the same rows of the whole.
+    """
+    from lynx_amd.parallel import merge_records, shard_particles
+
+    desc = []
+    for _ in range(8):
+        desc += [("quadrupole", dict(length=[0.2], k1=[4.2])), ("drift", dict(length=[0.5])),
+                 ("quadrupole", dict(length=[0.2], k1=[-4.2])), ("drift", dict(length=[0.5]))]
+    seg = lx.Segment(make_lattice(desc, np.float64, lx)[0])
+    P = o.gaussian_particles((1,), 50_001, seed=12, dtype=np.float64, sigma=[1e-4, 1e-5, 1e-4, 1e-5, 1e-5, 1e-3],
+                             mu=[2e-3, 0, -1e-3, 0, 0, 0])
+    energy = np.full(1, 1e8)
+    whole = seg.track(lx.ParticleBeam(P, energy, dtype=np.float64))
+    parts, rows = [], []
+    for r in range(3):
+        a, b = shard_particles(P.shape[1], 3, r)
+        out = seg.track(lx.ParticleBeam(P[:, a:b], energy, dtype=np.float64))
+        parts.append(out.moment_record())
+        rows.append(np.asarray(out.particles))
+    assert np.array_equal(np.concatenate(rows, axis=1), np.asarray(whole.particles))
+    merged, ref = merge_records(np.stack(parts)), whole.moment_record()
+    assert merged[0, 35] == ref[0, 35] == 50_001
+    np.testing.assert_allclose(merged[..., :7], ref[..., :7], rtol=1e-12, atol=1e-18)
+    np.testing.assert_allclose(merged[..., 7:28], ref[..., 7:28], rtol=1e-9, atol=1e-24)
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_track_methods_helpers(lx, dtype):
     """lynx/track_methods.py public functions: rotation_matrix, base_rmatrix, misalignment_matrix."""
