@@ -183,12 +183,14 @@ int lynx_track_moments(lynx_ctx* ctx, lynx_lattice* lat, const void* d_energy_in
  *   d_grad_params  [B][E][8]        dL/d(parameter j of element e), parameter order of the
  *                                   element kind; unused slots 0; custom maps: 0
  *   d_grad_energy_in [B]            dL/d(incoming energy)
+ *   d_grad_p_in    [B][N][7] or NULL dL/d(incoming particle coordinates) (the reference's
+ *                                   tests/test_differentiable.py:75-91 differentiates through those)
  * Limit of this version: every 4th per-particle state and the per-step accumulators live in
  * LDS, which bounds n_steps to about 60 (float32) / 30 (float64).                           */
 int lynx_track_particles_backward(lynx_ctx* ctx, lynx_lattice* lat, int64_t n_particles,
                                   const void* d_energy_in, const void* d_p_in,
                                   const double* d_moments_fwd, const double* d_grad_moments,
-                                  void* d_grad_params, void* d_grad_energy_in);
+                                  void* d_grad_params, void* d_grad_energy_in, void* d_grad_p_in);
 
 /* Moment read-out of an existing ParticleBeam (reference: particle_beam.py:736-836,
  * one fused pass instead of 14 separate reductions).  d_moments_out [B][36] float64.       */

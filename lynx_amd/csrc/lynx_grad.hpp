@@ -62,7 +62,7 @@ template <typename T>
 __global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
     LatticeDev lat, BwdArgs a, const T* __restrict__ p_in, const T* __restrict__ steps,
     const double* __restrict__ moments_fwd, const double* __restrict__ grad_moments,
-    T* __restrict__ partials /* [B][chunks][S][64] */) {
+    T* __restrict__ partials /* [B][chunks][S][64] */, T* __restrict__ grad_p /* [B][N][7] or null */) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int K = kBwdGroup;
   const int S = lat.n_steps;
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
     if (((int64_t)chunk * a.tiles_per_wg + it) * kTrackThreads >= N) break;  // uniform
     const bool live = i < N;
     T z[7];
-    load_particle<false>(src + (live ? i : 0) * 7, z);
+    load_particle(src + (live ? i : 0) * 7, z);
 
     // forward sweep, parking the state that enters every K-th step
     for (int s = 0; s < S; ++s) {
@@ -243,6 +243,8 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
         zb[5] += dir5;
       }
     }
+    // what is left after the last (= first) step is dL/d(incoming particle)
+    if (grad_p != nullptr && live) store_particle(grad_p + (b * N + i) * 7, zb);
   }
 
   __syncthreads();

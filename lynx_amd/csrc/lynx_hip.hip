@@ -693,7 +693,7 @@ int lynx_track_particles(lynx_ctx* ctx, lynx_lattice* lat, int64_t n_particles, 
 template <typename T>
 static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const void* d_energy_in, const void* d_p_in,
                             const double* d_moments_fwd, const double* d_grad_moments, void* d_grad_params,
-                            void* d_grad_energy_in) {
+                            void* d_grad_energy_in, void* d_grad_p_in) {
   const int64_t B = lat->batch;
   const int32_t S = lat->n_steps, E = lat->n_elems;
   int rc;
@@ -729,7 +729,7 @@ static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const v
   LatticeDev lv = dev_view(lat);
   hipLaunchKernelGGL(k_track_bwd<T>, dim3((unsigned)(B * chunks)), dim3(kTrackThreads), lds, ctx->stream, lv, a,
                      (const T*)d_p_in, (const T*)ctx->scratch_steps, d_moments_fwd, d_grad_moments,
-                     (T*)ctx->scratch_grad[0]);
+                     (T*)ctx->scratch_grad[0], (T*)d_grad_p_in);
   HIP_TRY(ctx, hipGetLastError());
   hipLaunchKernelGGL(k_reduce_tbar<T>, dim3((unsigned)(B * S)), dim3(64), 0, ctx->stream, (const T*)ctx->scratch_grad[0],
                      (int)chunks, (int)S, (T*)ctx->scratch_grad[1]);
@@ -745,16 +745,16 @@ static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const v
 
 int lynx_track_particles_backward(lynx_ctx* ctx, lynx_lattice* lat, int64_t n_particles, const void* d_energy_in,
                                   const void* d_p_in, const double* d_moments_fwd, const double* d_grad_moments,
-                                  void* d_grad_params, void* d_grad_energy_in) {
+                                  void* d_grad_params, void* d_grad_energy_in, void* d_grad_p_in) {
   if (!ctx || !lat || !d_energy_in || !d_p_in || !d_moments_fwd || !d_grad_moments || !d_grad_params || !d_grad_energy_in)
     return fail(ctx, LYNX_ERR_INVALID, "null argument");
   if (n_particles <= 0 || lat->n_steps <= 0) return fail(ctx, LYNX_ERR_INVALID, "empty program or beam");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   return lat->dtype == LYNX_F64
              ? track_backward_t<double>(ctx, lat, n_particles, d_energy_in, d_p_in, d_moments_fwd, d_grad_moments,
-                                        d_grad_params, d_grad_energy_in)
+                                        d_grad_params, d_grad_energy_in, d_grad_p_in)
              : track_backward_t<float>(ctx, lat, n_particles, d_energy_in, d_p_in, d_moments_fwd, d_grad_moments,
-                                       d_grad_params, d_grad_energy_in);
+                                       d_grad_params, d_grad_energy_in, d_grad_p_in);
 }
 
 int lynx_moments(lynx_ctx* ctx, int dtype, int64_t batch, int64_t n_particles, const void* d_p,

@@ -48,8 +48,9 @@ class Gradients:
     first access.
     """
 
-    def __init__(self, program, raw_dev, energy_dev, batch_shape, energy_shape):
+    def __init__(self, program, raw_dev, energy_dev, batch_shape, energy_shape, particles_dev=None):
         self._program, self._raw_dev, self._energy_dev = program, raw_dev, energy_dev
+        self._particles_dev = particles_dev
         self._batch_shape, self._energy_shape = tuple(batch_shape), tuple(energy_shape)
         self._raw = None
         self._cache = {}
@@ -63,6 +64,13 @@ class Gradients:
     @property
     def energy(self) -> np.ndarray:
         return _unbroadcast(self._energy_dev.numpy().reshape(self._batch_shape), self._energy_shape)
+
+    @property
+    def particles(self):
+        """dL/d(incoming particles), (*batch, N, 7), device-resident; needs `wrt_particles=True`."""
+        if self._particles_dev is None:
+            raise KeyError("call the VJP with wrt_particles=True to get the gradient w.r.t. the incoming particles")
+        return self._particles_dev
 
     def __contains__(self, element) -> bool:
         return any(el is element and el._kind in DIFFERENTIABLE_KINDS for el in self._program.leaves)
@@ -105,7 +113,7 @@ class TrackVJP:
         self.cache = segment.__dict__.setdefault("_lattice_cache", engine.LatticeCache())
         self.outgoing = engine.run_program_particles(self.cache, self.program, beam, moments=True)
 
-    def __call__(self, mu_bar=None, cov_bar=None) -> Gradients:
+    def __call__(self, mu_bar=None, cov_bar=None, wrt_particles: bool = False) -> Gradients:
         rt = get_runtime()
         beam, program = self.beam, self.program
         batch_shape, dtype = beam.batch_shape, beam.dtype
@@ -125,12 +133,14 @@ class TrackVJP:
         g_rec = rt.to_device(rec)
         g_par = rt.empty((B, max(E, 1), 8), dtype)
         g_en = rt.empty((B,), dtype)
+        g_p = rt.empty((*batch_shape, beam.num_particles, 7), dtype) if wrt_particles else None
         fwd = self.outgoing._moments.device(rt)
         e_in = beam._energy.broadcast_device(rt, batch_shape)
         rt.check(rt.lib.lynx_track_particles_backward(
             rt.ctx, lat.handle, beam.num_particles, C.c_void_p(e_in.ptr), C.c_void_p(beam._particles.device(rt).ptr),
-            C.c_void_p(fwd.ptr), C.c_void_p(g_rec.ptr), C.c_void_p(g_par.ptr), C.c_void_p(g_en.ptr)))
-        return Gradients(program, g_par, g_en, batch_shape, np.asarray(beam.energy).shape)
+            C.c_void_p(fwd.ptr), C.c_void_p(g_rec.ptr), C.c_void_p(g_par.ptr), C.c_void_p(g_en.ptr),
+            None if g_p is None else C.c_void_p(g_p.ptr)))
+        return Gradients(program, g_par, g_en, batch_shape, np.asarray(beam.energy).shape, g_p)
 
 
 def track_vjp(segment, beam: ParticleBeam) -> TrackVJP:

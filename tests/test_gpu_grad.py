@@ -123,3 +123,70 @@ def test_gradient_of_linear_lattice_and_broadcast_parameters(lx):
 
     ref = (loss(4.2 + 1e-4) - loss(4.2 - 1e-4)) / 2e-4
     assert np.isclose(g[seg.Q]["k1"][0], ref, rtol=2e-3), (g[seg.Q]["k1"], ref)
+
+
+def test_gradient_wrt_incoming_particles(lx):
+    """
+    reference tests/test_differentiable.py:75-91 makes the incoming particles the leaf.  Here:
+    dL/d(particle coordinates) of a cavity lattice against finite differences of the oracle for a
+    handful of particles and coordinates, and the total against a directional derivative.
+    """
+    rng = np.random.default_rng(7)
+    B, N = 2, 300
+    desc = _desc(B, rng)
+    elements, specs = make_lattice(desc, np.float64, lx)
+    P = o.gaussian_particles((B,), N, seed=3, dtype=np.float64, sigma=[1e-3, 1e-4, 1e-3, 1e-4, 1e-3, 1e-3])
+    energy = np.array([6e6, 8e6])
+    w_mu, w_cov = rng.normal(size=(B, 6)), rng.normal(size=(B, 6, 6)) * 1e3
+    g = lx.grad.track_vjp(lx.Segment(elements), lx.ParticleBeam(P, energy, dtype=np.float64))(
+        mu_bar=w_mu, cov_bar=w_cov, wrt_particles=True)
+    got = np.asarray(g.particles)
+    assert got.shape == (B, N, 7)
+    for b, n, c in [(0, 0, 0), (0, 17, 1), (1, 299, 2), (1, 5, 3), (0, 123, 4), (1, 200, 5)]:
+        h = 1e-7
+        Pp, Pm = P.copy(), P.copy()
+        Pp[b, n, c] += h
+        Pm[b, n, c] -= h
+        ref = (_loss(specs, Pp, energy, w_mu, w_cov)[b] - _loss(specs, Pm, energy, w_mu, w_cov)[b]) / (2 * h)
+        assert abs(got[b, n, c] - ref) <= 1e-4 * abs(ref) + 1e-6 * np.max(np.abs(got[b])), (b, n, c, got[b, n, c], ref)
+    # directional derivative along a random direction of all particles at once
+    D = rng.normal(size=P.shape) * [1e-3, 1e-4, 1e-3, 1e-4, 1e-3, 1e-3, 0]
+    h = 1e-5
+    ref = (_loss(specs, P + h * D, energy, w_mu, w_cov) - _loss(specs, P - h * D, energy, w_mu, w_cov)) / (2 * h)
+    assert np.allclose(np.sum(got * D, axis=(1, 2)), ref, rtol=1e-5)
+    with pytest.raises(KeyError):
+        lx.grad.track_vjp(lx.Segment(elements), lx.ParticleBeam(P, energy, dtype=np.float64))(mu_bar=w_mu).particles
+
+
+def test_ea_magnets_gradients_fp32(lx):
+    """
+    reference tests/test_differentiable.py:31-51: the five magnets of the ARES experimental area
+    are the leaves.  Gradient of the beam size on the screen w.r.t. the three quadrupole strengths
+    and two corrector angles, float32 kernels, against finite differences of the oracle.
+    """
+    f = lambda v: np.array([v], dtype=np.float32)  # noqa: E731
+    settings = dict(q1=10.0, q2=-9.0, cv=1e-3, q3=7.0, ch=-2e-3)
+
+    def lattice(ns, s, dtype):
+        a = lambda v: np.array([v], dtype=dtype)  # noqa: E731
+        return [ns.Drift(a(0.17504)), ns.Quadrupole(a(0.122), k1=a(s["q1"])), ns.Drift(a(0.428)),
+                ns.Quadrupole(a(0.122), k1=a(s["q2"])), ns.Drift(a(0.204)), ns.VerticalCorrector(a(0.02), angle=a(s["cv"])),
+                ns.Drift(a(0.204)), ns.Quadrupole(a(0.122), k1=a(s["q3"])), ns.Drift(a(0.179)),
+                ns.HorizontalCorrector(a(0.02), angle=a(s["ch"])), ns.Drift(a(0.45))]
+
+    P = o.gaussian_particles((1,), 20_000, seed=11, dtype=np.float32,
+                             sigma=[1.75e-4, 3.7e-6, 1.75e-4, 3.7e-6, 8e-6, 2.3e-3])
+    elements = lattice(lx, settings, np.float32)
+    w_mu = np.array([[1.0, 0, 1.0, 0, 0, 0]])
+    w_cov = np.zeros((1, 6, 6))
+    w_cov[0, 0, 0] = w_cov[0, 2, 2] = 1e4  # L = mu_x + mu_y + 1e4 (var x + var y)
+    g = lx.grad.track_vjp(lx.Segment(elements), lx.ParticleBeam(P, f(1.07e8)))(mu_bar=w_mu, cov_bar=w_cov)
+
+    def loss(s):
+        return _loss(lattice(o, s, np.float64), P.astype(np.float64), np.array([1.07e8]), w_mu, w_cov)[0]
+
+    for key, index, name in (("q1", 1, "k1"), ("q2", 3, "k1"), ("cv", 5, "angle"), ("q3", 7, "k1"), ("ch", 9, "angle")):
+        h = 1e-4 * max(abs(settings[key]), 1.0)
+        ref = (loss({**settings, key: settings[key] + h}) - loss({**settings, key: settings[key] - h})) / (2 * h)
+        got = g[elements[index]][name][0]
+        assert abs(got - ref) <= 1e-3 * abs(ref) + 1e-7, (key, got, ref)  # float32 kernels: 1e-3
