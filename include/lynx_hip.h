@@ -185,8 +185,8 @@ int lynx_track_moments(lynx_ctx* ctx, lynx_lattice* lat, const void* d_energy_in
  *   d_grad_energy_in [B]            dL/d(incoming energy)
  *   d_grad_p_in    [B][N][7] or NULL dL/d(incoming particle coordinates) (the reference's
  *                                   tests/test_differentiable.py:75-91 differentiates through those)
- * Limit of this version: every 4th per-particle state and the per-step accumulators live in
- * LDS, which bounds n_steps to about 60 (float32) / 30 (float64).                           */
+ * Limit of this version: n_steps <= 64 (every 4th per-particle state is parked in a
+ * fixed-size private array during the forward sweep).                                       */
 int lynx_track_particles_backward(lynx_ctx* ctx, lynx_lattice* lat, int64_t n_particles,
                                   const void* d_energy_in, const void* d_p_in,
                                   const double* d_moments_fwd, const double* d_grad_moments,

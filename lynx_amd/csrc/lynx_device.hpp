@@ -191,6 +191,41 @@ __device__ __forceinline__ void apply_step(const T* M /*49 + coef*/, int step_ki
   for (int i = 0; i < 7; ++i) z[i] = o[i];
 }
 
+// Two particles per lane as packed float pairs: every multiply-add of the step becomes one
+// v_pk_fma_f32 with the map entry broadcast from an SGPR (op_sel), i.e. half the VALU issue
+// slots of two scalar applications.  Only multi-step float32 programs use it: they are
+// VALU-bound (BASELINE config 5: 16 maps + 8 cosines per particle), whereas the single-map
+// stream is HBM-bound and measured 10 % slower with packed math.  Same operations in the same
+// order per component as apply_step<float>, so the results are bit-identical.
+typedef float lynx_f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ lynx_f32x2 pk_fma(lynx_f32x2 a, float b, lynx_f32x2 c) {
+  return __builtin_elementwise_fma(a, (lynx_f32x2)(b), c);
+}
+
+__device__ __forceinline__ void apply_step_pair(const float* M /*49 + coef*/, int step_kind, int step_flags,
+                                                lynx_f32x2 (&z)[7]) {
+  lynx_f32x2 o[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    lynx_f32x2 acc = z[0] * M[i * 7 + 0];
+#pragma unroll
+    for (int j = 1; j < 7; ++j) acc = pk_fma(z[j], M[i * 7 + j], acc);
+    o[i] = acc;
+  }
+  if (step_kind == LYNX_STEP_CAVITY && (step_flags & LYNX_FLAG_CAV_GAIN)) {
+    const float* coef = M + LYNX_COEF_OFFSET;
+    const lynx_f32x2 s_in = z[4], d_in = z[5];
+    const lynx_f32x2 arg = -1.0f * s_in * coef[LYNX_C_BK] + coef[LYNX_C_PHI];
+    const lynx_f32x2 ca = {t_cos(arg.x), t_cos(arg.y)};
+    o[5] = d_in * coef[LYNX_C_DSCALE] + coef[LYNX_C_DKICK] * (ca - coef[LYNX_C_COSPHI]);
+    o[4] = o[4] + (coef[LYNX_C_T566] * (d_in * d_in) + coef[LYNX_C_T556] * s_in * d_in +
+                   coef[LYNX_C_T555] * (s_in * s_in));
+  }
+#pragma unroll
+  for (int i = 0; i < 7; ++i) z[i] = o[i];
+}
+
 // Whole program on one particle, step data read from LDS.
 template <typename T>
 __device__ __forceinline__ void apply_program(const LatticeDev& lat, const T* s_steps, T (&z)[7]) {
@@ -626,27 +661,50 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_direct(
     if (!one_run) {
       // general program: steps outermost, so that each step's map is fetched once per
       // iteration (fp32: 57 scalar loads into SGPRs; fp64: read from LDS) for all UNROLL
-      // particles of the lane
+      // particles of the lane; fp32 with an even UNROLL runs the particles as packed pairs
+      constexpr bool kPairs = kMapInRegs && UNROLL % 2 == 0;
+      lynx_f32x2 zp[kPairs ? UNROLL / 2 : 1][7];
+      if constexpr (kPairs) {
+#pragma unroll
+        for (int u = 0; u < UNROLL; u += 2)
+#pragma unroll
+          for (int c = 0; c < 7; ++c) zp[u / 2][c] = lynx_f32x2{(float)z[u][c], (float)z[u + 1][c]};
+      }
       for (int sidx = 0; sidx < S; ++sidx) {
         const lynx_step st = lat.steps[sidx];
-        if (kMapInRegs) {
-          T m[57];
+        if constexpr (kMapInRegs) {
+          float m[57];
           if (kScalarTable) {
             const T* tab = g_steps + sidx * LYNX_STEP_STRIDE;  // global: s_load
 #pragma unroll
-            for (int q = 0; q < 57; ++q) m[q] = uniform_value(tab[q]);
+            for (int q = 0; q < 57; ++q) m[q] = (float)uniform_value(tab[q]);
           } else {
             const T* tab = s_steps + sidx * LYNX_STEP_STRIDE;  // LDS
 #pragma unroll
-            for (int q = 0; q < 57; ++q) m[q] = uniform_value(tab[q]);
+            for (int q = 0; q < 57; ++q) m[q] = (float)uniform_value(tab[q]);
           }
+          if constexpr (kPairs) {
 #pragma unroll
-          for (int u = 0; u < UNROLL; ++u) apply_step<T>(m, st.kind, st.flags, z[u]);
+            for (int h = 0; h < UNROLL / 2; ++h) apply_step_pair(m, st.kind, st.flags, zp[h]);
+          } else {
+            float(&zf)[UNROLL][7] = reinterpret_cast<float(&)[UNROLL][7]>(z);
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) apply_step<float>(m, st.kind, st.flags, zf[u]);
+          }
         } else {
           const T* tab = s_steps + sidx * LYNX_STEP_STRIDE;
 #pragma unroll
           for (int u = 0; u < UNROLL; ++u) apply_step<T>(tab, st.kind, st.flags, z[u]);
         }
+      }
+      if constexpr (kPairs) {
+#pragma unroll
+        for (int u = 0; u < UNROLL; u += 2)
+#pragma unroll
+          for (int c = 0; c < 7; ++c) {
+            z[u][c] = (T)zp[u / 2][c].x;
+            z[u + 1][c] = (T)zp[u / 2][c].y;
+          }
       }
     }
 #pragma unroll

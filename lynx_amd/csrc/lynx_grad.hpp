@@ -41,16 +41,67 @@ struct BwdArgs {
 // k_track_bwd: grid = B * chunks workgroups of 256 threads, one particle per thread and tile.
 //
 // The reverse sweep needs the state that ENTERED every step.  Every kBwdGroup-th state is
-// parked in LDS during the forward sweep (stack [ceil(S/K)][7][256]); inside a group the K-1
-// missing states are recomputed into registers (0.75 extra step applications per step for
-// K = 4).  Parking every state needed 476 B per particle for the 16 steps of BASELINE
-// config 5 = one workgroup per CU, and the kernel ran latency-bound at 1 wave per SIMD.
+// parked during the forward sweep; inside a group the K-1 missing states are recomputed into
+// registers (0.75 extra step applications per step for K = 4).  The parked states live in a
+// per-lane private array (scratch memory: 7 dwords written and read per 4 steps, served by
+// L1/L2), not in LDS: history of this kernel on BASELINE config 5 (16 steps) --
+//   every state in LDS (476 B/particle)          1 workgroup/CU   20.7 ms
+//   every 4th state in LDS, exchange pitch 68    2 workgroups/CU  10.0 ms
+//   parked states in scratch, 14-row exchange    4 workgroups/CU   7.2 ms
+//   + k-blocked exchange reads, DPP finishing    (see below)
 //
-// LDS: stack [G][7][256] T | exchange [4][22][kExPitch] T | accumulators [4][S][64] T
+// LDS: exchange [4][21][kExPitch] T | accumulators [4][S][64] T
 // kExPitch = 68: rows stay 16-byte aligned and the 7 rows a 49-lane read touches at the same
 // column fall on different banks (pitch 64 made every such read a 7-way conflict).
 // ---------------------------------------------------------------------------------------
 constexpr int kBwdGroup = 4;
+constexpr int kBwdMaxGroups = 16;  // => at most 64 steps
+constexpr int kExRows = 21;
+
+// LDS hand-over inside one wave: make this wave's LDS writes visible to its own later reads
+// (and keep the compiler from moving accesses across); no workgroup barrier is involved.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Cross-lane sums without LDS traffic (DPP).  quad_perm [1,0,3,2] = 0xB1 and [2,3,0,1] = 0x4E
+// swap within quads, row_half_mirror 0x141 reverses each group of 8 lanes, row_mirror 0x140
+// each row of 16: after the first three every lane of an aligned group of 8 holds the group's
+// sum, after the fourth every lane of a row; the 4 rows of the wave are added through SGPRs.
+template <int CTRL> __device__ __forceinline__ float dpp_take(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL> __device__ __forceinline__ double dpp_take(double v) {
+  const long long bits = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)bits, CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), CTRL, 0xF, 0xF, true);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+template <typename T> __device__ __forceinline__ T sum_over_8_lanes(T v) {
+  v += dpp_take<0xB1>(v);
+  v += dpp_take<0x4E>(v);
+  v += dpp_take<0x141>(v);
+  return v;
+}
+__device__ __forceinline__ float lane_value(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ __forceinline__ double lane_value(double v, int l) {
+  const long long bits = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_readlane((int)bits, l), hi = __builtin_amdgcn_readlane((int)(bits >> 32), l);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+template <typename T> __device__ __forceinline__ T sum_over_wave(T v) {
+  v = sum_over_8_lanes(v);
+  v += dpp_take<0x140>(v);
+  return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
+}
+
+// sine and cosine of the cavity phase share one range reduction
+__device__ __noinline__ void t_sincos(float x, float& s, float& c) { sincosf(x, &s, &c); }
+__device__ __noinline__ void t_sincos(double x, double& s, double& c) { sincos(x, &s, &c); }
 
 template <typename T>
 __device__ __forceinline__ void load_step_map(const T* g_steps, int s, T (&m)[57]) {
@@ -67,16 +118,16 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
   constexpr int K = kBwdGroup;
   const int S = lat.n_steps;
   const int G = (S + K - 1) / K;
-  T* s_stack = reinterpret_cast<T*>(smem_raw);               // [G][7][256]
-  T* s_ex = s_stack + (size_t)G * 7 * kTrackThreads;         // [4][22][kExPitch]
-  T* s_acc = s_ex + 4 * 22 * kExPitch;                       // [4][S][64]
+  T* s_ex = reinterpret_cast<T*>(smem_raw);                  // [4][21][kExPitch]
+  T* s_acc = s_ex + 4 * kExRows * kExPitch;                  // [4][S][64]
+  T stack[kBwdMaxGroups * 7];                                // private: state entering step g*K
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t b = blockIdx.x / a.chunks;
   const int chunk = blockIdx.x % a.chunks;
   const int64_t N = a.n_particles;
   const T* g_steps = steps + b * (int64_t)S * LYNX_STEP_STRIDE;
-  T* ex = s_ex + wave * (22 * kExPitch);
+  T* ex = s_ex + wave * (kExRows * kExPitch);
   T* acc = s_acc + wave * (S * 64);
 
   for (int s = 0; s < S; ++s) acc[s * 64 + lane] = T(0);
@@ -108,7 +159,7 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
       load_step_map<T>(g_steps, s, m);
       if (s % K == 0) {
 #pragma unroll
-        for (int c = 0; c < 7; ++c) s_stack[((s / K) * 7 + c) * kTrackThreads + tid] = z[c];
+        for (int c = 0; c < 7; ++c) stack[(s / K) * 7 + c] = z[c];
       }
       apply_step<T>(m, st.kind, st.flags, z);
     }
@@ -138,7 +189,7 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
       // states entering steps grp*K .. grp*K + K-1
       T zz[K][7];
 #pragma unroll
-      for (int c = 0; c < 7; ++c) zz[0][c] = s_stack[(grp * 7 + c) * kTrackThreads + tid];
+      for (int c = 0; c < 7; ++c) zz[0][c] = stack[grp * 7 + c];
 #pragma unroll
       for (int j = 1; j < K; ++j) {
         const int sp = grp * K + j - 1;  // step that produces zz[j]
@@ -176,7 +227,8 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
           const T* cf = m + LYNX_COEF_OFFSET;
           const T z4 = zin[4], z5 = zin[5], o4b = zb[4], o5b = zb[5];
           const T arg = T(-1) * z4 * cf[LYNX_C_BK] + cf[LYNX_C_PHI];
-          const T ca = t_cos(arg), sa = t_sin(arg);
+          T ca, sa;
+          t_sincos(arg, sa, ca);
           const T ab = -o5b * cf[LYNX_C_DKICK] * sa;
           cc[LYNX_C_DSCALE] = o5b * z5;
           cc[LYNX_C_DKICK] = o5b * (ca - cf[LYNX_C_COSPHI]);
@@ -191,45 +243,59 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
           olin[5] = T(0);  // the linear delta was overwritten
         }
 
-        // 64-lane sums through the wave's exchange buffer
+        // 64-lane sums through the wave's exchange buffer: rows 0..6 o_lin, 7..13 z_in,
+        // 14..20 the first 7 cavity-coefficient cotangents (kick steps only).
+        // Lane (i, kb) = (lane / 8, lane % 8) owns output row i and the 8 particles
+        // [8 kb, 8 kb + 8): it reads its 8 entries of row i once and the same 8 of all z_in
+        // rows (lanes that share kb read the same addresses: broadcast), forms 7 partial
+        // sums, and an 8-lane DPP butterfly finishes them -- 16 wide LDS reads per step instead
+        // of the 32 a lane-per-output mapping needs.  The 8 lanes with i = 7 run the same
+        // instructions on a row of ones against rows 14..20, which sums 7 of the 8 coefficient
+        // cotangents for free; the 8th takes one DPP wave sum.
 #pragma unroll
         for (int c = 0; c < 7; ++c) ex[c * kExPitch + lane] = olin[c];
 #pragma unroll
         for (int c = 0; c < 7; ++c) ex[(7 + c) * kExPitch + lane] = zin[c];
         if (kick) {
 #pragma unroll
-          for (int c = 0; c < 8; ++c) ex[(14 + c) * kExPitch + lane] = cc[c];
+          for (int c = 0; c < 7; ++c) ex[(14 + c) * kExPitch + lane] = cc[c];
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (lane < 49 || (kick && lane < 57)) {
+        wave_lds_sync();
+        {
           using V = typename VecOf<T, true>::type;  // 16-byte LDS reads
           constexpr int VW = VecOf<T, true>::width;
-          T sum = T(0);
-          if (lane < 49) {
-            const V* ra = reinterpret_cast<const V*>(ex + (lane / 7) * kExPitch);
-            const V* rb = reinterpret_cast<const V*>(ex + (7 + lane % 7) * kExPitch);
-#pragma unroll 8
-            for (int l = 0; l < 64 / VW; ++l) {
-              const V va = ra[l], vb = rb[l];
+          const int oi = lane >> 3, kb = lane & 7;
+          const bool coef_lane = oi == 7;
+          const V* ra = reinterpret_cast<const V*>(ex + (coef_lane ? 0 : oi) * kExPitch + kb * 8);
+          const T* rows = ex + (coef_lane ? 14 : 7) * kExPitch + kb * 8;
+          T av[8];
 #pragma unroll
-              for (int q = 0; q < VW; ++q) sum = t_fma(va[q], vb[q], sum);
-            }
-          } else {
-            const V* rc = reinterpret_cast<const V*>(ex + (14 + lane - 49) * kExPitch);
-#pragma unroll 8
-            for (int l = 0; l < 64 / VW; ++l) {
-              const V vc = rc[l];
+          for (int l = 0; l < 8 / VW; ++l) {
+            const V va = ra[l];
 #pragma unroll
-              for (int q = 0; q < VW; ++q) sum += vc[q];
-            }
+            for (int q = 0; q < VW; ++q) av[l * VW + q] = coef_lane ? T(1) : va[q];
           }
-          acc[s * 64 + lane] += sum;
+          T mine = T(0);
+#pragma unroll
+          for (int j = 0; j < 7; ++j) {
+            const V* rb = reinterpret_cast<const V*>(rows + j * kExPitch);
+            T part = T(0);
+#pragma unroll
+            for (int l = 0; l < 8 / VW; ++l) {
+              const V vb = rb[l];
+#pragma unroll
+              for (int q = 0; q < VW; ++q) part = t_fma(av[l * VW + q], vb[q], part);
+            }
+            const T total = sum_over_8_lanes(part);
+            mine = (kb == j) ? total : mine;
+          }
+          if (kb < 7 && (!coef_lane || kick)) acc[s * 64 + (coef_lane ? 49 : oi * 7) + kb] += mine;
+          if (kick) {
+            const T last = sum_over_wave(cc[7]);
+            if (lane == 63) acc[s * 64 + 56] += last;
+          }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        wave_lds_sync();
 
         // z_bar_in = T^T o_lin (+ direct cavity terms)
 #pragma unroll

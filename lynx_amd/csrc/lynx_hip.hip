@@ -711,11 +711,11 @@ static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const v
   a.n_particles = N;
   a.chunks = (int32_t)chunks;
   a.tiles_per_wg = (int32_t)tpw;
-  const size_t lds = ((size_t)((S + kBwdGroup - 1) / kBwdGroup) * 7 * kTrackThreads + 4 * 22 * kExPitch + (size_t)4 * S * 64) * sizeof(T);
-  if (lds > 160 * 1024)
+  if (S > kBwdGroup * kBwdMaxGroups)
     return fail(ctx, LYNX_ERR_INVALID,
-                "lynx_track_particles_backward: " + std::to_string(S) + " steps need " + std::to_string(lds) +
-                    " B of LDS (limit 160 KiB: about 60 steps in float32, 30 in float64)");
+                "lynx_track_particles_backward: " + std::to_string(S) + " steps; this version parks at most " +
+                    std::to_string(kBwdGroup * kBwdMaxGroups) + " (merge skippable elements or split the lattice)");
+  const size_t lds = ((size_t)4 * kExRows * kExPitch + (size_t)4 * S * 64) * sizeof(T);
   if ((rc = allow_lds(ctx, k_track_bwd<T>, lds))) return rc;
   if ((int64_t)B * chunks > 0x7fffffffLL || (int64_t)B * S > 0x7fffffffLL) return fail(ctx, LYNX_ERR_INVALID, "grid too large");
   if ((rc = ensure_scratch(ctx, &ctx->scratch_grad[0], &ctx->scratch_grad_bytes[0],

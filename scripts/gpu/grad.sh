@@ -1,8 +1,9 @@
 #!/bin/bash
-mkdir -p gpurun_out/grad; rm -f gpurun_out/grad/*
+# reverse pass: wall clock per step (forward + backward) and the kernel trace
+mkdir -p gpurun_out/grad; rm -rf gpurun_out/grad/*
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for wl in c5 c4; do
-  timeout -k 10 200 python bench.py --workload $wl --grad --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/grad/$wl.json 2> gpurun_out/grad/$wl.err
+for wl in c5 c4 c5; do
+  timeout -k 10 200 python bench.py --workload $wl --grad --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/grad/$wl.json 2> gpurun_out/grad/$wl.err
   tail -2 gpurun_out/grad/$wl.err
   python3 -c "
 import json; d=json.loads(open('gpurun_out/grad/$wl.json').read().strip().splitlines()[-1]); print('$wl grad ms/step', d['ms_per_step'])"
