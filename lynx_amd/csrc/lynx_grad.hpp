@@ -29,7 +29,6 @@ namespace lynx {
 
 constexpr int kGradStride = 64;   // per (sample, step): 49 T_bar + 8 coef_bar + padding
 constexpr int kGradParams = 8;    // gradient slots per element (kinds with <= 8 parameters)
-constexpr int kExPitch = 68;
 
 struct BwdArgs {
   int64_t n_particles;
@@ -48,15 +47,17 @@ struct BwdArgs {
 //   every state in LDS (476 B/particle)          1 workgroup/CU   20.7 ms
 //   every 4th state in LDS, exchange pitch 68    2 workgroups/CU  10.0 ms
 //   parked states in scratch, 14-row exchange    4 workgroups/CU   7.2 ms
-//   + k-blocked exchange reads, DPP finishing    (see below)
+//   + k-blocked exchange reads with DPP finishing, coefficient sums on idle lanes  6.9 ms
+//   + two float32 particles per lane (v_pk_fma_f32)                  (see LaneOf below)
 //
-// LDS: exchange [4][21][kExPitch] T | accumulators [4][S][64] T
-// kExPitch = 68: rows stay 16-byte aligned and the 7 rows a 49-lane read touches at the same
-// column fall on different banks (pitch 64 made every such read a 7-way conflict).
+// LDS: exchange [4][21][ExGeom::kPitch] T | accumulators [4][S][64] T
 // ---------------------------------------------------------------------------------------
 constexpr int kBwdGroup = 4;
 constexpr int kBwdMaxGroups = 16;  // => at most 64 steps
-constexpr int kExRows = 21;
+// Rows of the exchange buffer: 14 (o_lin, z_in), or 21 when the first 7 cavity-coefficient
+// cotangents also travel through it (summed by the otherwise idle lanes 56..63).  Packed pairs
+// double the row length; with 21 rows only two workgroups fit a CU, with 14 three.
+template <int W> struct ExRows { static constexpr int value = W == 1 ? 21 : 14; };
 
 // LDS hand-over inside one wave: make this wave's LDS writes visible to its own later reads
 // (and keep the compiler from moving accesses across); no workgroup barrier is involved.
@@ -109,48 +110,101 @@ __device__ __forceinline__ void load_step_map(const T* g_steps, int s, T (&m)[57
   for (int q = 0; q < 57; ++q) m[q] = g_steps[s * LYNX_STEP_STRIDE + q];  // wave-uniform: scalar loads
 }
 
-template <typename T>
+// ---- lane values: one particle per lane (float64) or two as a packed pair (float32) -----
+// The reverse sweep is VALU-bound; with two float32 particles per lane every multiply-add of
+// the step applications, of T^T z_bar and of the exchange products is one v_pk_fma_f32 for
+// both (map entries broadcast from SGPRs), i.e. about 0.6x the instructions per particle.
+template <typename Z> struct LaneOf { static constexpr int W = 1; };
+template <> struct LaneOf<lynx_f32x2> { static constexpr int W = 2; };
+
+__device__ __forceinline__ float zfma(float a, float b, float c) { return t_fma(a, b, c); }
+__device__ __forceinline__ double zfma(double a, double b, double c) { return t_fma(a, b, c); }
+__device__ __forceinline__ lynx_f32x2 zfma(lynx_f32x2 a, float b, lynx_f32x2 c) { return pk_fma(a, b, c); }
+__device__ __forceinline__ lynx_f32x2 zfma(lynx_f32x2 a, lynx_f32x2 b, lynx_f32x2 c) {
+  return __builtin_elementwise_fma(a, b, c);
+}
+__device__ __forceinline__ float zget(float z, int) { return z; }
+__device__ __forceinline__ double zget(double z, int) { return z; }
+__device__ __forceinline__ float zget(lynx_f32x2 z, int w) { return w ? z.y : z.x; }
+__device__ __forceinline__ void zset(float& z, int, float v) { z = v; }
+__device__ __forceinline__ void zset(double& z, int, double v) { z = v; }
+__device__ __forceinline__ void zset(lynx_f32x2& z, int w, float v) {
+  if (w) z.y = v;
+  else z.x = v;
+}
+__device__ __forceinline__ float zhsum(float z) { return z; }
+__device__ __forceinline__ double zhsum(double z) { return z; }
+__device__ __forceinline__ float zhsum(lynx_f32x2 z) { return z.x + z.y; }
+__device__ __forceinline__ void zsincos(float x, float& s, float& c) { t_sincos(x, s, c); }
+__device__ __forceinline__ void zsincos(double x, double& s, double& c) { t_sincos(x, s, c); }
+__device__ __forceinline__ void zsincos(lynx_f32x2 x, lynx_f32x2& s, lynx_f32x2& c) {
+  float s0, c0, s1, c1;
+  t_sincos(x.x, s0, c0);
+  t_sincos(x.y, s1, c1);
+  s = lynx_f32x2{s0, s1};
+  c = lynx_f32x2{c0, c1};
+}
+__device__ __forceinline__ void zapply(const float* m, int kind, int flags, float (&z)[7]) { apply_step<float>(m, kind, flags, z); }
+__device__ __forceinline__ void zapply(const double* m, int kind, int flags, double (&z)[7]) { apply_step<double>(m, kind, flags, z); }
+__device__ __forceinline__ void zapply(const float* m, int kind, int flags, lynx_f32x2 (&z)[7]) { apply_step_pair(m, kind, flags, z); }
+
+// Exchange-buffer geometry: a row holds the 64 W values of one quantity; lane (i, kb) works on
+// the 16-byte pieces l * 32 + kb * 4 (in scalars of 4 bytes; 8-byte scalars: l * 16 + kb * 2)
+// of its rows, so that the 8 lanes of one row group read 128 consecutive bytes per access.
+template <typename T, int W> struct ExGeom {
+  static constexpr int kVW = 16 / (int)sizeof(T);          // scalars per 16-byte access
+  static constexpr int kRow = 64 * W;                      // scalars per row
+  static constexpr int kPitch = kRow + kVW;                // + one access: rows start on different banks
+  static constexpr int kPieces = kRow / (8 * kVW);         // accesses per lane and row
+};
+
+template <typename T, typename Z>
 __global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
     LatticeDev lat, BwdArgs a, const T* __restrict__ p_in, const T* __restrict__ steps,
     const double* __restrict__ moments_fwd, const double* __restrict__ grad_moments,
     T* __restrict__ partials /* [B][chunks][S][64] */, T* __restrict__ grad_p /* [B][N][7] or null */) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int K = kBwdGroup;
+  constexpr int W = LaneOf<Z>::W;
+  using Geo = ExGeom<T, W>;
+  using V = typename VecOf<T, true>::type;  // 16-byte LDS accesses
+  constexpr int VW = Geo::kVW, P = Geo::kPitch;
   const int S = lat.n_steps;
   const int G = (S + K - 1) / K;
-  T* s_ex = reinterpret_cast<T*>(smem_raw);                  // [4][21][kExPitch]
-  T* s_acc = s_ex + 4 * kExRows * kExPitch;                  // [4][S][64]
-  T stack[kBwdMaxGroups * 7];                                // private: state entering step g*K
+  constexpr int kExRows = ExRows<W>::value;
+  constexpr bool kCoefRows = kExRows == 21;
+  T* s_ex = reinterpret_cast<T*>(smem_raw);                  // [4][kExRows][P]
+  T* s_acc = s_ex + 4 * kExRows * P;                         // [4][S][64]
+  Z stack[kBwdMaxGroups * 7];                                // private: state entering step g*K
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t b = blockIdx.x / a.chunks;
   const int chunk = blockIdx.x % a.chunks;
   const int64_t N = a.n_particles;
   const T* g_steps = steps + b * (int64_t)S * LYNX_STEP_STRIDE;
-  T* ex = s_ex + wave * (kExRows * kExPitch);
+  T* ex = s_ex + wave * (kExRows * P);
   T* acc = s_acc + wave * (S * 64);
 
   for (int s = 0; s < S; ++s) acc[s * 64 + lane] = T(0);
 
-  // per-sample constants of the moment cotangent
   const double* rec = moments_fwd + b * LYNX_MOMENT_STRIDE;
   const double* gm = grad_moments + b * LYNX_MOMENT_STRIDE;
-  const T inv_n = (T)(1.0 / rec[35]);
-  T mean[6], mu_bar[7], Gc[21];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) mean[i] = (T)rec[i];
-#pragma unroll
-  for (int i = 0; i < 7; ++i) mu_bar[i] = (T)gm[i];
-#pragma unroll
-  for (int i = 0; i < 21; ++i) Gc[i] = (T)gm[7 + i];
-
   const T* src = p_in + b * N * 7;
+  constexpr int64_t kTile = (int64_t)kTrackThreads * W;
   for (int it = 0; it < a.tiles_per_wg; ++it) {
-    const int64_t i = ((int64_t)chunk * a.tiles_per_wg + it) * kTrackThreads + tid;
-    if (((int64_t)chunk * a.tiles_per_wg + it) * kTrackThreads >= N) break;  // uniform
-    const bool live = i < N;
-    T z[7];
-    load_particle(src + (live ? i : 0) * 7, z);
+    const int64_t base = ((int64_t)chunk * a.tiles_per_wg + it) * kTile;
+    if (base >= N) break;  // uniform
+    bool live[W];
+    Z z[7];
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      const int64_t i = base + (int64_t)w * kTrackThreads + tid;
+      live[w] = i < N;
+      T zw[7];
+      load_particle(src + (live[w] ? i : 0) * 7, zw);
+#pragma unroll
+      for (int c = 0; c < 7; ++c) zset(z[c], w, zw[c]);
+    }
 
     // forward sweep, parking the state that enters every K-th step
     for (int s = 0; s < S; ++s) {
@@ -161,33 +215,39 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
 #pragma unroll
         for (int c = 0; c < 7; ++c) stack[(s / K) * 7 + c] = z[c];
       }
-      apply_step<T>(m, st.kind, st.flags, z);
+      zapply(m, st.kind, st.flags, z);
     }
 
     // cotangent of the outgoing particle: (1/N) (mu_bar + G_hat (z - mean)), G_hat built from
-    // the upper-triangle cotangent (diagonal counted twice)
-    T zb[7];
+    // the upper-triangle cotangent (diagonal counted twice); the per-sample constants are
+    // fetched here, per tile, so that they do not stay live across the sweeps
+    Z zb[7];
     {
-      T d[6];
+      const T inv_n = (T)(1.0 / rec[35]);
+      Z d[6];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) d[k] = z[k] - mean[k];
+      for (int k = 0; k < 6; ++k) d[k] = z[k] - (T)rec[k];
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
-        T accv = mu_bar[k];
+        Z accv = Z((T)gm[k]);
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
           const int r = k < j ? k : j, c = k < j ? j : k;
-          const T g = Gc[r * 6 - (r * (r - 1)) / 2 + (c - r)];
-          accv = t_fma(k == j ? g + g : g, d[j], accv);
+          const T g = (T)gm[7 + r * 6 - (r * (r - 1)) / 2 + (c - r)];
+          accv = zfma(d[j], k == j ? g + g : g, accv);
         }
-        zb[k] = live ? accv * inv_n : T(0);
+        zb[k] = accv * inv_n;
       }
-      zb[6] = live ? mu_bar[6] * inv_n : T(0);
+      zb[6] = Z((T)gm[6] * inv_n);
+#pragma unroll
+      for (int w = 0; w < W; ++w)
+#pragma unroll
+        for (int c = 0; c < 7; ++c) zset(zb[c], w, live[w] ? zget(zb[c], w) : T(0));
     }
 
     for (int grp = G - 1; grp >= 0; --grp) {
       // states entering steps grp*K .. grp*K + K-1
-      T zz[K][7];
+      Z zz[K][7];
 #pragma unroll
       for (int c = 0; c < 7; ++c) zz[0][c] = stack[grp * 7 + c];
 #pragma unroll
@@ -199,7 +259,7 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
           const lynx_step st = lat.steps[sp];
           T m[57];
           load_step_map<T>(g_steps, sp, m);
-          apply_step<T>(m, st.kind, st.flags, zz[j]);
+          zapply(m, st.kind, st.flags, zz[j]);
         }
       }
 
@@ -209,27 +269,27 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
         const lynx_step st = lat.steps[s];
         T m[57];
         load_step_map<T>(g_steps, s, m);
-        T zin[7];
+        Z zin[7];
 #pragma unroll
         for (int c = 0; c < 7; ++c) {
-          T v = zz[0][c];
+          Z v = zz[0][c];
 #pragma unroll
           for (int q = 1; q < K; ++q) v = (j == q) ? zz[q][c] : v;
           zin[c] = v;
         }
 
         const bool kick = st.kind == LYNX_STEP_CAVITY && (st.flags & LYNX_FLAG_CAV_GAIN);
-        T olin[7], cc[8], dir4 = T(0), dir5 = T(0);
+        Z olin[7], cc[8], dir4 = Z(T(0)), dir5 = Z(T(0));
 #pragma unroll
         for (int c = 0; c < 7; ++c) olin[c] = zb[c];
         if (kick) {
           // o5' = z5 c0 + c1 (cos(a) - c4), a = -z4 c2 + c3 ; o4' = o4 + c5 z5^2 + c6 z4 z5 + c7 z4^2
           const T* cf = m + LYNX_COEF_OFFSET;
-          const T z4 = zin[4], z5 = zin[5], o4b = zb[4], o5b = zb[5];
-          const T arg = T(-1) * z4 * cf[LYNX_C_BK] + cf[LYNX_C_PHI];
-          T ca, sa;
-          t_sincos(arg, sa, ca);
-          const T ab = -o5b * cf[LYNX_C_DKICK] * sa;
+          const Z z4 = zin[4], z5 = zin[5], o4b = zb[4], o5b = zb[5];
+          const Z arg = T(-1) * z4 * cf[LYNX_C_BK] + cf[LYNX_C_PHI];
+          Z ca, sa;
+          zsincos(arg, sa, ca);
+          const Z ab = -o5b * cf[LYNX_C_DKICK] * sa;
           cc[LYNX_C_DSCALE] = o5b * z5;
           cc[LYNX_C_DKICK] = o5b * (ca - cf[LYNX_C_COSPHI]);
           cc[LYNX_C_BK] = ab * (-z4);
@@ -240,59 +300,69 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
           cc[LYNX_C_T555] = o4b * (z4 * z4);
           dir4 = ab * (-cf[LYNX_C_BK]) + o4b * (cf[LYNX_C_T556] * z5 + T(2) * cf[LYNX_C_T555] * z4);
           dir5 = o5b * cf[LYNX_C_DSCALE] + o4b * (T(2) * cf[LYNX_C_T566] * z5 + cf[LYNX_C_T556] * z4);
-          olin[5] = T(0);  // the linear delta was overwritten
+          olin[5] = Z(T(0));  // the linear delta was overwritten
         }
 
-        // 64-lane sums through the wave's exchange buffer: rows 0..6 o_lin, 7..13 z_in,
-        // 14..20 the first 7 cavity-coefficient cotangents (kick steps only).
-        // Lane (i, kb) = (lane / 8, lane % 8) owns output row i and the 8 particles
-        // [8 kb, 8 kb + 8): it reads its 8 entries of row i once and the same 8 of all z_in
-        // rows (lanes that share kb read the same addresses: broadcast), forms 7 partial
-        // sums, and an 8-lane DPP butterfly finishes them -- 16 wide LDS reads per step instead
-        // of the 32 a lane-per-output mapping needs.  The 8 lanes with i = 7 run the same
-        // instructions on a row of ones against rows 14..20, which sums 7 of the 8 coefficient
-        // cotangents for free; the 8th takes one DPP wave sum.
+        // Sums over the wave's 64 W particles through its exchange buffer: rows 0..6 o_lin,
+        // 7..13 z_in, 14..20 the first 7 cavity-coefficient cotangents (kick steps only).
+        // Lane (i, kb) = (lane / 8, lane % 8) owns output row i and one eighth of the
+        // particles: it reads its pieces of row i once and the same pieces of all z_in rows
+        // (lanes that share kb read the same addresses: broadcast), forms 7 partial sums, and
+        // an 8-lane DPP butterfly finishes them -- half the wide LDS reads of a
+        // lane-per-output mapping.  The 8 lanes with i = 7 run the same instructions on ones
+        // against rows 14..20, which sums 7 of the 8 coefficient cotangents for free; the 8th
+        // takes one DPP wave sum.
+        Z* exz = reinterpret_cast<Z*>(ex);
 #pragma unroll
-        for (int c = 0; c < 7; ++c) ex[c * kExPitch + lane] = olin[c];
+        for (int c = 0; c < 7; ++c) exz[(c * P) / W + lane] = olin[c];
 #pragma unroll
-        for (int c = 0; c < 7; ++c) ex[(7 + c) * kExPitch + lane] = zin[c];
-        if (kick) {
+        for (int c = 0; c < 7; ++c) exz[((7 + c) * P) / W + lane] = zin[c];
+        if (kCoefRows && kick) {
 #pragma unroll
-          for (int c = 0; c < 7; ++c) ex[(14 + c) * kExPitch + lane] = cc[c];
+          for (int c = 0; c < 7; ++c) exz[((14 + c) * P) / W + lane] = cc[c];
         }
         wave_lds_sync();
         {
-          using V = typename VecOf<T, true>::type;  // 16-byte LDS reads
-          constexpr int VW = VecOf<T, true>::width;
+          constexpr int NP = Geo::kPieces;
           const int oi = lane >> 3, kb = lane & 7;
-          const bool coef_lane = oi == 7;
-          const V* ra = reinterpret_cast<const V*>(ex + (coef_lane ? 0 : oi) * kExPitch + kb * 8);
-          const T* rows = ex + (coef_lane ? 14 : 7) * kExPitch + kb * 8;
-          T av[8];
+          const bool coef_lane = kCoefRows && oi == 7;
+          const T* arow = ex + (coef_lane ? 0 : oi) * P + kb * VW;
+          const T* rows = ex + (coef_lane ? 14 : 7) * P + kb * VW;
+          V av[NP];
 #pragma unroll
-          for (int l = 0; l < 8 / VW; ++l) {
-            const V va = ra[l];
+          for (int l = 0; l < NP; ++l) {
+            const V va = *reinterpret_cast<const V*>(arow + l * 8 * VW);
 #pragma unroll
-            for (int q = 0; q < VW; ++q) av[l * VW + q] = coef_lane ? T(1) : va[q];
+            for (int q = 0; q < VW; ++q) av[l][q] = coef_lane ? T(1) : va[q];
           }
           T mine = T(0);
 #pragma unroll
           for (int j = 0; j < 7; ++j) {
-            const V* rb = reinterpret_cast<const V*>(rows + j * kExPitch);
-            T part = T(0);
+            V part;
 #pragma unroll
-            for (int l = 0; l < 8 / VW; ++l) {
-              const V vb = rb[l];
+            for (int q = 0; q < VW; ++q) part[q] = T(0);
 #pragma unroll
-              for (int q = 0; q < VW; ++q) part = t_fma(av[l * VW + q], vb[q], part);
+            for (int l = 0; l < NP; ++l) {
+              const V vb = *reinterpret_cast<const V*>(rows + j * P + l * 8 * VW);
+              part = __builtin_elementwise_fma(av[l], vb, part);
             }
-            const T total = sum_over_8_lanes(part);
+            T folded = part[0];
+#pragma unroll
+            for (int q = 1; q < VW; ++q) folded += part[q];
+            const T total = sum_over_8_lanes(folded);
             mine = (kb == j) ? total : mine;
           }
-          if (kb < 7 && (!coef_lane || kick)) acc[s * 64 + (coef_lane ? 49 : oi * 7) + kb] += mine;
+          if (kb < 7 && oi < (kCoefRows ? 8 : 7) && (!coef_lane || kick))
+            acc[s * 64 + (coef_lane ? 49 : oi * 7) + kb] += mine;
           if (kick) {
-            const T last = sum_over_wave(cc[7]);
-            if (lane == 63) acc[s * 64 + 56] += last;
+            // coefficient cotangents that did not travel through the buffer: DPP wave sums
+            T rest = T(0);
+#pragma unroll
+            for (int c = kCoefRows ? 7 : 0; c < 8; ++c) {
+              const T total = sum_over_wave(zhsum(cc[c]));
+              rest = (lane == c) ? total : rest;
+            }
+            if (lane >= (kCoefRows ? 7 : 0) && lane < 8) acc[s * 64 + 49 + lane] += rest;
           }
         }
         wave_lds_sync();
@@ -300,9 +370,9 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
         // z_bar_in = T^T o_lin (+ direct cavity terms)
 #pragma unroll
         for (int jj = 0; jj < 7; ++jj) {
-          T v = m[0 * 7 + jj] * olin[0];
+          Z v = olin[0] * m[0 * 7 + jj];
 #pragma unroll
-          for (int r = 1; r < 7; ++r) v = t_fma(m[r * 7 + jj], olin[r], v);
+          for (int r = 1; r < 7; ++r) v = zfma(olin[r], m[r * 7 + jj], v);
           zb[jj] = v;
         }
         zb[4] += dir4;
@@ -310,7 +380,18 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
       }
     }
     // what is left after the last (= first) step is dL/d(incoming particle)
-    if (grad_p != nullptr && live) store_particle(grad_p + (b * N + i) * 7, zb);
+    if (grad_p != nullptr) {
+#pragma unroll
+      for (int w = 0; w < W; ++w) {
+        const int64_t i = base + (int64_t)w * kTrackThreads + tid;
+        if (live[w]) {
+          T zw[7];
+#pragma unroll
+          for (int c = 0; c < 7; ++c) zw[c] = zget(zb[c], w);
+          store_particle(grad_p + (b * N + i) * 7, zw);
+        }
+      }
+    }
   }
 
   __syncthreads();

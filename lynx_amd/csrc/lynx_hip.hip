@@ -690,7 +690,7 @@ int lynx_track_particles(lynx_ctx* ctx, lynx_lattice* lat, int64_t n_particles, 
 
 // ---- reverse pass -----------------------------------------------------------------------
 
-template <typename T>
+template <typename T, typename Z = T>
 static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const void* d_energy_in, const void* d_p_in,
                             const double* d_moments_fwd, const double* d_grad_moments, void* d_grad_params,
                             void* d_grad_energy_in, void* d_grad_p_in) {
@@ -702,9 +702,12 @@ static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const v
   if ((rc = ensure_scratch(ctx, &ctx->scratch_steps, &ctx->scratch_steps_bytes, steps_bytes))) return rc;
   if ((rc = launch_build<T>(ctx, lat, d_energy_in, ctx->scratch_steps, nullptr))) return rc;
 
+  // Z: what a lane carries -- one particle, or (float32) two as a packed pair
+  constexpr int W = LaneOf<Z>::W;
+  using Geo = ExGeom<T, W>;
   const int64_t cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
-  const int64_t ntiles = (N + kTrackThreads - 1) / kTrackThreads;
-  int64_t chunks = std::max<int64_t>(1, std::min<int64_t>(ntiles, (8 * cus + B - 1) / B));
+  const int64_t ntiles = (N + kTrackThreads * W - 1) / (kTrackThreads * W);
+  int64_t chunks = std::max<int64_t>(1, std::min<int64_t>(ntiles, ((int64_t)env_int("LYNX_BWD_WGS_PER_CU", 24) * cus + B - 1) / B));
   const int64_t tpw = (ntiles + chunks - 1) / chunks;
   chunks = (ntiles + tpw - 1) / tpw;
   BwdArgs a;
@@ -715,8 +718,9 @@ static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const v
     return fail(ctx, LYNX_ERR_INVALID,
                 "lynx_track_particles_backward: " + std::to_string(S) + " steps; this version parks at most " +
                     std::to_string(kBwdGroup * kBwdMaxGroups) + " (merge skippable elements or split the lattice)");
-  const size_t lds = ((size_t)4 * kExRows * kExPitch + (size_t)4 * S * 64) * sizeof(T);
-  if ((rc = allow_lds(ctx, k_track_bwd<T>, lds))) return rc;
+  const size_t lds = ((size_t)4 * ExRows<W>::value * Geo::kPitch + (size_t)4 * S * 64) * sizeof(T);
+  if (lds > 160 * 1024) return fail(ctx, LYNX_ERR_INVALID, "lynx_track_particles_backward: LDS budget exceeded");
+  if ((rc = allow_lds(ctx, k_track_bwd<T, Z>, lds))) return rc;
   if ((int64_t)B * chunks > 0x7fffffffLL || (int64_t)B * S > 0x7fffffffLL) return fail(ctx, LYNX_ERR_INVALID, "grid too large");
   if ((rc = ensure_scratch(ctx, &ctx->scratch_grad[0], &ctx->scratch_grad_bytes[0],
                            (size_t)B * chunks * S * kGradStride * sizeof(T))))
@@ -727,7 +731,7 @@ static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const v
                            (size_t)B * (2 * E + S + 1) * 49 * sizeof(T))))
     return rc;
   LatticeDev lv = dev_view(lat);
-  hipLaunchKernelGGL(k_track_bwd<T>, dim3((unsigned)(B * chunks)), dim3(kTrackThreads), lds, ctx->stream, lv, a,
+  hipLaunchKernelGGL((k_track_bwd<T, Z>), dim3((unsigned)(B * chunks)), dim3(kTrackThreads), lds, ctx->stream, lv, a,
                      (const T*)d_p_in, (const T*)ctx->scratch_steps, d_moments_fwd, d_grad_moments,
                      (T*)ctx->scratch_grad[0], (T*)d_grad_p_in);
   HIP_TRY(ctx, hipGetLastError());
@@ -753,6 +757,9 @@ int lynx_track_particles_backward(lynx_ctx* ctx, lynx_lattice* lat, int64_t n_pa
   return lat->dtype == LYNX_F64
              ? track_backward_t<double>(ctx, lat, n_particles, d_energy_in, d_p_in, d_moments_fwd, d_grad_moments,
                                         d_grad_params, d_grad_energy_in, d_grad_p_in)
+         : env_int("LYNX_BWD_PAIRS", 1)
+             ? track_backward_t<float, lynx_f32x2>(ctx, lat, n_particles, d_energy_in, d_p_in, d_moments_fwd,
+                                                   d_grad_moments, d_grad_params, d_grad_energy_in, d_grad_p_in)
              : track_backward_t<float>(ctx, lat, n_particles, d_energy_in, d_p_in, d_moments_fwd, d_grad_moments,
                                        d_grad_params, d_grad_energy_in, d_grad_p_in);
 }
