@@ -25,6 +25,10 @@ from .. import _ffi, engine
 
 _anonymous = itertools.count()
 
+# Bumped by every public attribute write on any element: while it stands still, nothing the
+# packed lattice programs depend on can have changed, and `engine` reuses its plan in O(1).
+EPOCH = [0]
+
 
 def generate_unique_name() -> str:
     """Names of elements constructed without one: unnamed_element_0, _1, ... (lynx/utils.py:1-11)."""
@@ -56,7 +60,7 @@ class Element:
     _row: tuple = ()
     _settings: tuple = ()
     _kept_on_broadcast: tuple = ()  # parameters `broadcast` passes on unrepeated
-    _transient: tuple = ("_lattice_cache",)  # never shared between an element and its copies
+    _transient: tuple = ("_lattice_cache", "_plan")  # never shared between an element and its copies
     _host_barrier = False
     _skippable: Optional[bool] = None
     _version = 0
@@ -70,6 +74,7 @@ class Element:
         object.__setattr__(self, key, value)
         if not key.startswith("_"):
             object.__setattr__(self, "_version", self._version + 1)
+            EPOCH[0] += 1
 
     def _adopt(self, dtype, length, **given) -> None:
         """

@@ -94,6 +94,34 @@ def partition(elements) -> list:
     return out
 
 
+def plan(owner, elements, raw: bool) -> list:
+    """
+    `partition(elements)` remembered on `owner` for as long as no element attribute has been
+    written (global EPOCH) and the element list holds the same objects: the steady state of a
+    tracking loop then costs one C-level pass over the list instead of Python work per element.
+    """
+    from .accelerator.element import EPOCH
+    from .accelerator.segment import Segment
+
+    def identities(items):
+        ids = tuple(map(id, items))
+        if any(issubclass(t, Segment) for t in set(map(type, items))):  # nested lists can change too
+            ids = (ids, tuple(identities(el.elements) for el in items if isinstance(el, Segment)))
+        return ids
+
+    ids = identities(elements)
+    token = (EPOCH[0], raw, ids)
+    remembered = owner.__dict__.get("_plan")
+    if remembered is not None and remembered[0] == token:
+        return remembered[1]
+    items = partition(elements)
+    for item in items:
+        if isinstance(item, Program):
+            item.raw = raw
+    owner.__dict__["_plan"] = (token, items)
+    return items
+
+
 # -------------------------------------------------------------------------------------------
 # packing
 # -------------------------------------------------------------------------------------------
@@ -122,24 +150,14 @@ class PackedLattice:
         self.elems = (_ffi.Elem * max(E, 1))()
         self.steps = (_ffi.Step * max(S, 1))()
         parts, offset = [], 0
+        self.layout = []  # per element: (offset, scalars, batch stride) in the parameter pool
         for e, el in enumerate(leaves):
-            rows = el._param_rows(self.dtype)
-            n = _ffi.PARAMS_OF_KIND[el._kind]
-            assert len(rows) == n, (el, len(rows), n)
-            if n == 0:
-                stride = 0
-            elif all(np.asarray(r).size == 1 for r in rows):
-                parts.append(np.array([np.asarray(r, dtype=self.dtype).reshape(()) for r in rows],
-                                      dtype=self.dtype))
-                stride = 0
-            else:
-                mat = np.stack(
-                    [_broadcast_param(r, self.batch_shape, self.dtype, type(el).__name__).reshape(self.B)
-                     for r in rows], axis=1)
-                parts.append(np.ascontiguousarray(mat).reshape(-1))
-                stride = n
+            block, stride = self._pack_element(el)
             self.elems[e] = _ffi.Elem(el._kind, 0, offset, stride)
-            offset += parts[-1].size if n else 0
+            self.layout.append((offset, block.size, stride))
+            if block.size:
+                parts.append(block)
+                offset += block.size
         self.pool = (np.concatenate(parts) if parts else np.zeros(1, dtype=self.dtype)).astype(self.dtype)
         for s, (kind, first, last) in enumerate(program.steps):
             self.steps[s] = _ffi.Step(kind, first, last, 0)
@@ -151,6 +169,42 @@ class PackedLattice:
         self.rt = None
         self._static = None
         self._has_cavity = False
+        self.versions = tuple(el._version for el in leaves)
+
+    def _pack_element(self, el):
+        """The element's parameter rows as one pool block: (flat array, batch stride)."""
+        rows = el._param_rows(self.dtype)
+        n = _ffi.PARAMS_OF_KIND[el._kind]
+        assert len(rows) == n, (el, len(rows), n)
+        if n == 0:
+            return np.zeros(0, dtype=self.dtype), 0
+        if all(np.asarray(r).size == 1 for r in rows):  # shared by the whole batch
+            return np.array([np.asarray(r, dtype=self.dtype).reshape(()) for r in rows], dtype=self.dtype), 0
+        mat = np.stack([_broadcast_param(r, self.batch_shape, self.dtype, type(el).__name__).reshape(self.B)
+                        for r in rows], axis=1)
+        return np.ascontiguousarray(mat).reshape(-1), n
+
+    def refresh(self, versions) -> bool:
+        """
+        Element parameters changed (`quad.k1 = ...`) but not the structure: rewrite the pool
+        blocks of the changed elements in place (`lynx_lattice_update_params`).  False if a
+        block changed its size or stride -- the caller then packs from scratch.
+        """
+        for e, (el, old, new) in enumerate(zip(self.program.leaves, self.versions, versions)):
+            if old == new:
+                continue
+            block, stride = self._pack_element(el)
+            offset, size, old_stride = self.layout[e]
+            if block.size != size or stride != old_stride:
+                return False
+            if size:
+                self.pool[offset:offset + size] = block
+                if self.handle is not None:
+                    self.rt.check(self.rt.lib.lynx_lattice_update_params(
+                        self.handle, offset, size, self.pool[offset:offset + size].ctypes.data))
+        self.versions = tuple(versions)
+        self._static = None
+        return True
 
     # whole-batch predicates -----------------------------------------------------------------
     def evaluate_flags(self, energy_host):
@@ -227,21 +281,37 @@ class PackedLattice:
 
 
 class LatticeCache:
-    """Packed programs of one owner (a Segment or an Element), keyed by element versions."""
+    """
+    Packed programs of one owner (a Segment or an Element).  Keyed by structure (which element
+    objects, which steps, batch shape, dtype); a parameter change only rewrites the changed
+    elements' blocks of the device-resident pool.
+    """
 
     def __init__(self, capacity: int = 4):
         self.capacity = capacity
         self.entries: dict = {}
+        self._last = None
 
     def get(self, program: Program, batch_shape, dtype) -> PackedLattice:
-        key = (tuple((id(el), el._version) for el in program.leaves),
-               tuple(tuple(s) for s in program.steps), tuple(batch_shape), np.dtype(dtype).str, program.raw)
+        from .accelerator.element import EPOCH
+
+        shape_key = (tuple(batch_shape), np.dtype(dtype).str, program.raw)
+        last = self._last
+        if last is not None and last[0] is program and last[1] == EPOCH[0] and last[2] == shape_key:
+            return last[3]
+        leaves = program.leaves
+        key = (tuple(map(id, leaves)), tuple(tuple(s) for s in program.steps), shape_key)
+        versions = tuple(el._version for el in leaves)
         hit = self.entries.get(key)
+        if hit is not None and hit.versions != versions and not hit.refresh(versions):
+            self.entries.pop(key).release()
+            hit = None
         if hit is None:
             if len(self.entries) >= self.capacity:
                 self.entries.pop(next(iter(self.entries))).release()
             hit = PackedLattice(program, batch_shape, dtype)
             self.entries[key] = hit
+        self._last = (program, EPOCH[0], shape_key, hit)
         return hit
 
 
@@ -324,9 +394,8 @@ def track(owner, elements, incoming, raw: bool = False):
         raise TypeError(f"Parameter incoming is of invalid type {type(incoming)}")
     cache = owner.__dict__.setdefault("_lattice_cache", LatticeCache())
     beam = incoming
-    for item in partition(elements):
+    for item in plan(owner, elements, raw):
         if isinstance(item, Program):
-            item.raw = raw
             if isinstance(beam, ParticleBeam):
                 beam = run_program_particles(cache, item, beam)
             else:
@@ -354,7 +423,7 @@ def transfer_map(owner, elements, energy, dtype, raw: bool = False) -> np.ndarra
     dtype = np.dtype(dtype)
     energy = np.asarray(energy, dtype=dtype)
     batch_shape = energy.shape
-    items = partition(elements)
+    items = plan(owner, elements, raw)
     if not items:
         out = np.zeros((*batch_shape, 7, 7), dtype=dtype)
         out[..., range(7), range(7)] = 1
@@ -362,7 +431,6 @@ def transfer_map(owner, elements, energy, dtype, raw: bool = False) -> np.ndarra
     assert len(items) == 1 and isinstance(items[0], Program) and len(items[0].steps) == 1, (
         "transfer_map needs a skippable element list")
     program = items[0]
-    program.raw = raw
     cache = owner.__dict__.setdefault("_lattice_cache", LatticeCache())
     lat = _ready(cache, program, batch_shape, dtype, energy)
     e_in = rt.to_device(np.ascontiguousarray(energy))

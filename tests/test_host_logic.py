@@ -134,7 +134,7 @@ def test_shape_mismatch_is_an_assertion_error():
         engine.PackedLattice(prog, (3,), np.float32)
 
 
-def test_parameter_changes_invalidate_the_cache_key():
+def test_parameter_changes_refresh_the_packed_lattice():
     q = lx.Quadrupole(np.array([0.2], np.float32), k1=np.array([1.0], np.float32), name="Q")
     seg = lx.Segment([lx.Drift(np.array([1.0], np.float32)), q])
     v0 = q._version
@@ -143,9 +143,45 @@ def test_parameter_changes_invalidate_the_cache_key():
     cache = engine.LatticeCache()
     a = cache.get(engine.partition(seg.elements)[0], (1,), np.float32)
     assert cache.get(engine.partition(seg.elements)[0], (1,), np.float32) is a
+    # same structure, new value: the changed element's pool block is rewritten in place
     q.k1 = np.array([5.0], np.float32)
     b = cache.get(engine.partition(seg.elements)[0], (1,), np.float32)
-    assert b is not a and b.pool[2] == 5.0
+    assert b is a and b.pool[2] == 5.0 and b.versions[1] == q._version
+    q.tilt = np.array([0.3], np.float32)  # static flags depend on the parameters: re-evaluated
+    c = cache.get(engine.partition(seg.elements)[0], (1,), np.float32)
+    assert c is a and c.evaluate_flags(np.array([1e8], np.float32))[0][1] & _ffi.FLAG_TILT
+    # a parameter that stops being shared by the batch changes the block size: packed afresh
+    cache2 = engine.LatticeCache()
+    a2 = cache2.get(engine.partition(seg.elements)[0], (3,), np.float32)
+    q.k1 = np.array([1.0, 2.0, 3.0], np.float32)
+    seg.elements[0].length = np.ones(3, np.float32)
+    q.length, q.tilt, q.misalignment = np.full(3, 0.2, np.float32), np.zeros(3, np.float32), np.zeros((3, 2), np.float32)
+    b2 = cache2.get(engine.partition(seg.elements)[0], (3,), np.float32)
+    assert b2 is not a2 and b2.layout[1][2] == 5 and np.array_equal(b2.pool[b2.layout[1][0] + 1::5][:3], [1.0, 2.0, 3.0])
+
+
+def test_plan_is_reused_until_an_attribute_is_written():
+    f = lambda v: np.array([v], dtype=np.float32)  # noqa: E731
+    bpm = lx.BPM(name="B")
+    seg = lx.Segment([lx.Drift(f(1.0)), lx.Quadrupole(f(0.2), k1=f(1.0), name="Q"), bpm, lx.Drift(f(1.0))])
+    first = engine.plan(seg, seg.elements, False)
+    assert engine.plan(seg, seg.elements, False) is first and len(first) == 1
+    cache = engine.LatticeCache()
+    lat = cache.get(first[0], (1,), np.float32)
+    assert cache.get(first[0], (1,), np.float32) is lat  # O(1) path: same program object, same epoch
+    seg.Q.k1 = f(2.0)
+    second = engine.plan(seg, seg.elements, False)
+    assert second is not first and cache.get(second[0], (1,), np.float32) is lat and lat.pool[lat.layout[1][0] + 1] == 2.0
+    bpm.is_active = True  # structure changes: the BPM becomes a host-side barrier
+    third = engine.plan(seg, seg.elements, False)
+    assert [type(i).__name__ for i in third] == ["Program", "BPM", "Program"]
+    seg.elements.append(lx.Drift(f(0.5)))  # in-place list mutation, no attribute write
+    assert len(engine.plan(seg, seg.elements, False)[-1].leaves) == 2
+    inner = lx.Segment([lx.Drift(f(0.1))])
+    outer = lx.Segment([inner, lx.Drift(f(0.2))])
+    assert len(engine.plan(outer, outer.elements, False)[0].leaves) == 2
+    inner.elements.append(lx.Drift(f(0.3)))  # nested list mutated in place
+    assert len(engine.plan(outer, outer.elements, False)[0].leaves) == 3
 
 
 def test_segment_container_api():
