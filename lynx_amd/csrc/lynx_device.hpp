@@ -887,11 +887,13 @@ __global__ __launch_bounds__(64) void k_finalize_moments_small(const double* __r
 }
 
 // ---------------------------------------------------------------------------------------
-// k_track_moments: ParameterBeam path, one wave per sample (element.py:71-82,
-// cavity.py:134-140, 202-218).
+// k_track_moments: ParameterBeam path, one workgroup per sample (element.py:71-82,
+// cavity.py:134-140, 202-218): one wave when the batch is large (hundreds of thousands of
+// settings), four when it is small, where the build of a long lattice is the whole cost and
+// parallelises over elements.  The moment propagation itself uses 49 lanes.
 // ---------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(64) void k_track_moments(LatticeDev lat, const T* __restrict__ energy_in,
+__global__ __launch_bounds__(256) void k_track_moments(LatticeDev lat, const T* __restrict__ energy_in,
                                                        const T* mu_in, const T* cov_in, T* mu_out,
                                                        T* cov_out, T* __restrict__ energy_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];

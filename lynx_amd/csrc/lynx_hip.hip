@@ -788,7 +788,8 @@ static int launch_track_moments(lynx_ctx* ctx, lynx_lattice* lat, const void* d_
       ((size_t)kBuildScratch + (size_t)lat->n_steps * LYNX_STEP_STRIDE + lat->n_steps + 1 + 8 + 49 + 49 + 16) * sizeof(T);
   int rc = allow_lds(ctx, k_track_moments<T>, lds);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_track_moments<T>, dim3((unsigned)lat->batch), dim3(64), lds, ctx->stream, dev_view(lat),
+  const unsigned threads = lat->batch <= 4096 ? 256u : 64u;
+  hipLaunchKernelGGL(k_track_moments<T>, dim3((unsigned)lat->batch), dim3(threads), lds, ctx->stream, dev_view(lat),
                      (const T*)d_energy_in, (const T*)d_mu_in, (const T*)d_cov_in, (T*)d_mu_out, (T*)d_cov_out,
                      (T*)d_energy_out);
   HIP_TRY(ctx, hipGetLastError());
