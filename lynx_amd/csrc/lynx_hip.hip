@@ -664,7 +664,7 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
       hipLaunchKernelGGL(k_finalize_moments_small, dim3((unsigned)B), dim3(64), 0, ctx->stream, d_partials,
                          p.a.chunks, d_moments_out);
     else
-      hipLaunchKernelGGL(k_finalize_moments, dim3((unsigned)B), dim3(256), 0, ctx->stream, d_partials, p.a.chunks,
+      hipLaunchKernelGGL(k_finalize_moments, dim3((unsigned)B), dim3(1024), 0, ctx->stream, d_partials, p.a.chunks,
                          d_moments_out);
     HIP_TRY(ctx, hipGetLastError());
   }
