@@ -163,7 +163,7 @@ def main():
     beam = lx.ParticleBeam.synthetic((batch,), particles, sigma=[1e-4, 1e-5, 1e-4, 1e-5, 1e-5, 1e-3],
                                      energy=6e6 if args.workload == "c5" else 1e8, seed=2 + rank, dtype=dtype)
 
-    comm, gather_kind = None, "none"
+    comm, gather_kind, abandon_comm = None, "none", False
     force_comm = os.environ.get("LYNX_FORCE_COMM") == "1"  # exercise the RCCL path at world_size 1
     if world > 1 or force_comm:
         def exchange(uid):
@@ -173,12 +173,34 @@ def main():
             dist.broadcast_object_list(box, src=0)
             return box[0]
 
-        try:
-            comm = RcclCommunicator(world, rank, exchange, rt)
+        # The id travels over gloo on this thread; the blocking ncclCommInitRank runs under a
+        # watchdog, so that a communicator that cannot be brought up (error or no answer within
+        # LYNX_COMM_TIMEOUT_S) costs the transport, not the run.
+        import threading
+
+        from lynx_amd.parallel import rccl_unique_id
+
+        uid = exchange(rccl_unique_id(rt) if rank == 0 else None)
+        attempt: dict = {}
+
+        def bring_up():
+            try:
+                attempt["comm"] = RcclCommunicator(world, rank, lambda _: uid, rt)
+            except Exception as exc:
+                attempt["error"] = exc
+
+        worker = threading.Thread(target=bring_up, daemon=True)
+        worker.start()
+        worker.join(timeout=float(os.environ.get("LYNX_COMM_TIMEOUT_S", "180")))
+        if worker.is_alive():
+            attempt["error"] = TimeoutError("ncclCommInitRank did not return")
+            abandon_comm = True
+        comm = attempt.get("comm")
+        if comm is not None:
             gather_kind = "rccl-allgather"
-        except Exception as exc:  # the run must still produce its line; say loudly what happened
-            print(f"[rank {rank}] RCCL communicator failed ({exc}); moment records will be gathered through "
-                  "the host with gloo", file=sys.stderr, flush=True)
+        else:  # the run must still produce its line; say loudly what happened
+            print(f"[rank {rank}] RCCL communicator failed ({attempt.get('error')}); moment records will be gathered "
+                  "through the host with gloo", file=sys.stderr, flush=True)
             gather_kind = "gloo-host-fallback"
         if dist is not None:
             # every rank must use the same transport
@@ -187,8 +209,8 @@ def main():
             ok = torch.tensor([1 if comm is not None else 0])
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 0 and comm is not None:
-                comm.close()
-                comm, gather_kind = None, "gloo-host-fallback"
+                # a peer has no communicator: tearing ours down could wait for it forever
+                comm, gather_kind, abandon_comm = None, "gloo-host-fallback", True
 
     grad_cov_bar = None
     if args.grad:
@@ -317,6 +339,10 @@ def main():
         comm.close()
     if dist is not None:
         dist.destroy_process_group()
+    if abandon_comm:  # a half-built RCCL communicator may block interpreter shutdown
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

@@ -82,6 +82,14 @@ def merge_records(gathered: np.ndarray) -> np.ndarray:
     return out
 
 
+def rccl_unique_id(rt: Runtime | None = None) -> bytes:
+    """A fresh 128-byte RCCL unique id (rank 0 makes it, every rank needs it: `lynx_comm_unique_id`)."""
+    rt = rt or get_runtime()
+    buf = C.create_string_buffer(_ffi.UNIQUE_ID_BYTES)
+    _ffi.check(rt.lib.lynx_comm_unique_id(buf))
+    return buf.raw
+
+
 class RcclCommunicator:
     """RCCL communicator of this process' GPU (C ABI: lynx_comm_*, lynx_gather_moments)."""
 
@@ -93,12 +101,7 @@ class RcclCommunicator:
         """
         self.rt = rt or get_runtime()
         self.n_ranks, self.rank = n_ranks, rank
-        uid = None
-        if rank == 0:
-            buf = C.create_string_buffer(_ffi.UNIQUE_ID_BYTES)
-            _ffi.check(self.rt.lib.lynx_comm_unique_id(buf))
-            uid = buf.raw
-        uid = exchange(uid)
+        uid = exchange(rccl_unique_id(self.rt) if rank == 0 else None)
         assert isinstance(uid, (bytes, bytearray)) and len(uid) == _ffi.UNIQUE_ID_BYTES
         self.rt.check(self.rt.lib.lynx_comm_init(self.rt.ctx, n_ranks, rank, bytes(uid)))
 
