@@ -7,6 +7,7 @@ there is no `jax.grad` call to mirror, so the API is an explicit vector-Jacobian
     vjp = lynx_amd.grad.track_vjp(segment, beam)     # forward pass, fused moments
     out = vjp.outgoing                                # the tracked ParticleBeam
     g = vjp(mu_bar=..., cov_bar=...)                  # cotangents of mean (.., 6) and cov (.., 6, 6)
+    g = vjp(mu_x=..., sigma_x=..., sigma_y=...)       # or of the beam properties a loss is written in
     g[segment.Q1]["k1"], g.energy                     # dL/dk1 (shape of k1), dL/dE_in
 
 All arithmetic runs in the HIP kernels of `lynx_amd/csrc/lynx_grad.hpp`
@@ -101,6 +102,37 @@ class Gradients:
         return total
 
 
+_COORDINATES = ("x", "xp", "y", "yp", "s", "p")
+
+
+def property_cotangents(outgoing: ParticleBeam, named: dict):
+    """
+    Cotangents of named beam properties -> (mu_bar, cov_bar).  `mu_<c>`: the mean itself;
+    `sigma_<c>` = sqrt(cov_cc n / (n - ddof)) (particle_beam.py:736-823, `config.std_ddof`), so
+    d sigma / d cov_cc = n / (n - ddof) / (2 sigma); `sigma_xxp`, `sigma_yyp`: cov_01, cov_23.
+    """
+    from . import config
+
+    batch = outgoing.batch_shape
+    mu_bar, cov_bar = np.zeros((*batch, 6)), np.zeros((*batch, 6, 6))
+    n = float(outgoing.num_particles)
+    for name, bar in named.items():
+        bar = np.broadcast_to(np.asarray(bar, dtype=np.float64), batch)
+        kind, _, coord = name.partition("_")
+        if kind == "mu" and coord in _COORDINATES:
+            mu_bar[..., _COORDINATES.index(coord)] += bar
+        elif kind == "sigma" and coord in _COORDINATES:
+            c = _COORDINATES.index(coord)
+            sigma = np.asarray(getattr(outgoing, name), dtype=np.float64)
+            cov_bar[..., c, c] += bar * (n / (n - config.std_ddof)) / (2.0 * sigma)
+        elif name in ("sigma_xxp", "sigma_yyp"):
+            c = 0 if name == "sigma_xxp" else 2
+            cov_bar[..., c, c + 1] += bar
+        else:
+            raise KeyError(f"no cotangent rule for beam property {name!r}")
+    return mu_bar, cov_bar
+
+
 class TrackVJP:
     def __init__(self, segment, beam: ParticleBeam):
         if not isinstance(beam, ParticleBeam):
@@ -113,11 +145,15 @@ class TrackVJP:
         self.cache = segment.__dict__.setdefault("_lattice_cache", engine.LatticeCache())
         self.outgoing = engine.run_program_particles(self.cache, self.program, beam, moments=True)
 
-    def __call__(self, mu_bar=None, cov_bar=None, wrt_particles: bool = False) -> Gradients:
+    def __call__(self, mu_bar=None, cov_bar=None, wrt_particles: bool = False, **properties) -> Gradients:
         rt = get_runtime()
         beam, program = self.beam, self.program
         batch_shape, dtype = beam.batch_shape, beam.dtype
         B = int(np.prod(batch_shape, dtype=np.int64))
+        if properties:
+            extra_mu, extra_cov = property_cotangents(self.outgoing, properties)
+            mu_bar = extra_mu if mu_bar is None else extra_mu + np.asarray(mu_bar, dtype=np.float64).reshape(extra_mu.shape)
+            cov_bar = extra_cov if cov_bar is None else extra_cov + np.asarray(cov_bar, dtype=np.float64).reshape(extra_cov.shape)
         rec = np.zeros((B, _ffi.MOMENT_STRIDE), dtype=np.float64)
         if mu_bar is not None:
             mu_bar = np.asarray(mu_bar, dtype=np.float64).reshape(B, -1)

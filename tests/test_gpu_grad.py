@@ -190,3 +190,40 @@ def test_ea_magnets_gradients_fp32(lx):
         ref = (loss({**settings, key: settings[key] + h}) - loss({**settings, key: settings[key] - h})) / (2 * h)
         got = g[elements[index]][name][0]
         assert abs(got - ref) <= 1e-3 * abs(ref) + 1e-7, (key, got, ref)  # float32 kernels: 1e-3
+
+
+def test_gradient_based_tuning_example_converges(lx):
+    """
+    The scenario of the reference's docs/examples/gradientbased.ipynb (examples/
+    gradient_based_tuning.py): Adam on three quadrupoles and two correctors of the ARES EA
+    section, loss = mse of (mu_x, sigma_x, mu_y, sigma_y) on the screen.  Also checks the
+    property cotangents (sigma = sqrt of the unbiased variance) against finite differences.
+    """
+    import importlib.util
+    import pathlib
+
+    spec = importlib.util.spec_from_file_location(
+        "gradient_based_tuning", pathlib.Path(__file__).resolve().parents[1] / "examples" / "gradient_based_tuning.py")
+    example = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(example)
+    f = example.f
+    segment = example.ares_ea()
+    segment.AREAMQZM1.k1, segment.AREAMQZM2.k1, segment.AREAMQZM3.k1 = f(5.0), f(-5.0), f(5.0)
+    segment.AREAMCVM1.angle, segment.AREAMCHM1.angle = f(1e-3), f(-1e-3)
+    beam = lx.ParticleBeam.from_parameters(num_particles=20_000, sigma_x=f(1.75e-4), sigma_xp=f(3.7e-6),
+                                           sigma_y=f(1.75e-4), sigma_yp=f(3.7e-6), energy=f(1.07e8), seed=0)
+
+    # d sigma_x / d k1 of the first quadrupole: VJP vs central difference of the tracked sigma_x
+    g = lx.grad.track_vjp(segment, beam)(sigma_x=1.0)
+    got = float(g[segment.AREAMQZM1]["k1"][0])
+    h = 0.05
+    segment.AREAMQZM1.k1 = f(5.0 + h)
+    up = float(segment.track(beam).sigma_x[0])
+    segment.AREAMQZM1.k1 = f(5.0 - h)
+    down = float(segment.track(beam).sigma_x[0])
+    segment.AREAMQZM1.k1 = f(5.0)
+    assert np.isclose(got, (up - down) / (2 * h), rtol=2e-2), (got, (up - down) / (2 * h))
+
+    history = example.tune(segment, beam, steps=60)
+    assert history[-1] < 0.05 * history[0], (history[0], history[-1])
+    assert abs(float(segment.track(beam).mu_x[0])) < 2e-4
