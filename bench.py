@@ -132,6 +132,9 @@ def main():
     ap.add_argument("--particles", type=int, default=None)
     ap.add_argument("--no-moments", action="store_true", help="track without the fused moment epilogue")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shared-input", action="store_true",
+                    help="variant (SURVEY.md section 8d): ONE incoming beam broadcast lazily over the batch instead of "
+                         "one physical beam per sample; reported with its own algorithmic bytes, never the default")
     ap.add_argument("--grad", action="store_true",
                     help="step = forward + reverse pass (gradient of sum of var(x) w.r.t. every element parameter)")
     args = ap.parse_args()
@@ -160,8 +163,12 @@ def main():
 
     segment = build_segment(lx, args.workload, batch, cells, dtype, rank, world)
     n_elements = len(segment.elements)
-    beam = lx.ParticleBeam.synthetic((batch,), particles, sigma=[1e-4, 1e-5, 1e-4, 1e-5, 1e-5, 1e-3],
+    beam = lx.ParticleBeam.synthetic((1,) if args.shared_input else (batch,), particles,
+                                     sigma=[1e-4, 1e-5, 1e-4, 1e-5, 1e-5, 1e-3],
                                      energy=6e6 if args.workload == "c5" else 1e8, seed=2 + rank, dtype=dtype)
+    if args.shared_input:
+        beam = beam.broadcast((batch,))
+        assert beam.is_shared
 
     comm, gather_kind, abandon_comm = None, "none", False
     force_comm = os.environ.get("LYNX_FORCE_COMM") == "1"  # exercise the RCCL path at world_size 1
@@ -305,6 +312,8 @@ def main():
         itemsize = np.dtype(dtype).itemsize
         steps_per_pass = batch * world * particles * n_elements
         alg_bytes = 2 * batch * particles * 7 * itemsize  # per launch of the streaming kernel, per GPU
+        if args.shared_input:  # the incoming beam is read once, every sample's outgoing beam is written
+            alg_bytes = (1 + batch) * particles * 7 * itemsize
         kern_s = kern_ms / 1e3 / max(launches, 1)
         achieved = alg_bytes / kern_s / 1e9 if launches else None
         result = {
@@ -322,6 +331,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {descr}", "batch_per_gpu": batch, "global_batch": batch * world,
                        "particles": particles, "elements": n_elements, "fused_moments": not args.no_moments, "reverse_pass": bool(args.grad),
+                       "incoming_beam": "one beam shared by the batch (lazy broadcast)" if args.shared_input else "one physical beam per sample",
                        "gather": gather_kind, "parallelism": f"{'particle' if batch == 1 else 'batch'}-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": "k_track_direct", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,

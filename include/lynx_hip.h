@@ -92,6 +92,11 @@ typedef struct lynx_step {
 /* flags of lynx_track_particles */
 #define LYNX_TRACK_MOMENTS 1     /* also accumulate the output-beam moments (fused epilogue) */
 #define LYNX_TRACK_TWO_KERNEL 2  /* build+compose in its own launch instead of the fused prologue */
+/* d_p_in is [N][7]: one incoming beam shared by every sample of the lattice batch.  The
+ * reference's `ParticleBeam.broadcast` repeats the particles physically
+ * (particle_beam.py:838-843) before a parameter scan; a beam broadcast lazily is read once
+ * per sample out of the caches instead, which halves the HBM traffic of the pass. */
+#define LYNX_TRACK_SHARED_INPUT 4
 
 /* Layout of one sample's moment record (float64 regardless of the particle dtype):
  * [0..6] mean of the 7 coordinates, [7..27] upper triangle (row-major, i<=j<6) of the
@@ -161,7 +166,7 @@ int lynx_build_compose(lynx_ctx* ctx, lynx_lattice* lat, const void* d_energy_in
 
 /* Segment.track on a ParticleBeam (reference: segment.py:340-356 -> element.py:83-92
  * `particles @ tm^T`, cavity.py:141-161,219-226).
- *   d_p_in / d_p_out [B][N][7]  (may alias)
+ *   d_p_in / d_p_out [B][N][7]  (may alias; d_p_in [N][7] with LYNX_TRACK_SHARED_INPUT)
  *   d_moments_out    [B][36] float64 or NULL (needs LYNX_TRACK_MOMENTS)                    */
 int lynx_track_particles(lynx_ctx* ctx, lynx_lattice* lat, int64_t n_particles,
                          const void* d_energy_in, const void* d_p_in, void* d_p_out,

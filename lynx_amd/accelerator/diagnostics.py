@@ -199,10 +199,11 @@ class Screen(Element):
             else:
                 # the reference subtracts the y misalignment from coordinate 1 (x'), not from
                 # y (screen.py:134-135); kept as it is
-                host = np.array(incoming._particles.host())
+                host = np.array(incoming.particles)
                 host[..., 0] -= mis[..., None, 0]
                 host[..., 1] -= mis[..., None, 1]
                 copy._particles = Dual(host)
+                copy._batch = None
                 copy._moments = None
         self.set_read_beam(copy)
 
@@ -226,6 +227,8 @@ class Screen(Element):
             return self._cached_reading
         Beam, ParameterBeam, ParticleBeam = _beam_types()
         beam = self.get_read_beam()
+        if isinstance(beam, ParticleBeam):
+            beam = beam.materialized()
         nx, ny = int(self.effective_resolution[0]), int(self.effective_resolution[1])
         if beam is Beam.empty or beam is None:
             image = np.zeros((*self.misalignment.shape[:-1], ny, nx), dtype=self.resolution.dtype)

@@ -12,3 +12,8 @@ two_kernel = os.environ.get("LYNX_TWO_KERNEL", "0") == "1"
 # Delta degrees of freedom of ParticleBeam.sigma_*.  The reference spells it
 # `xs.std(dim=-1)` (lynx/particles/particle_beam.py:742), i.e. the torch default: unbiased.
 std_ddof = int(os.environ.get("LYNX_STD_DDOF", "1"))
+
+# `ParticleBeam.broadcast` of a single beam: keep one stored copy and let the tracking kernel
+# read it once per sample (LYNX_TRACK_SHARED_INPUT) instead of repeating it physically like
+# the reference does (particle_beam.py:838-843).  Same values and shapes either way.
+lazy_broadcast = os.environ.get("LYNX_LAZY_BROADCAST", "1") != "0"

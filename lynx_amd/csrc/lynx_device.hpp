@@ -297,6 +297,7 @@ struct TrackArgs {
   int32_t store;         // 1: write p_out
   int32_t lds_tile_scalars;  // size of the tile/scratch region in scalars
   int32_t interleave;    // direct kernel: 1 = a workgroup takes every `chunks`-th tile
+  int64_t in_stride;     // scalars between the samples of p_in: N*7, or 0 for one shared incoming beam
 };
 
 __device__ __forceinline__ float uniform_value(float v) {
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(kTrackThreads) void k_track(
   {
     const int64_t tile_start = first_tile * TILE;
     const int cnt = (int)((N - tile_start) < TILE ? (N - tile_start) : TILE);
-    const V* src = reinterpret_cast<const V*>(p_in + (b * N + tile_start) * 7);
+    const V* src = reinterpret_cast<const V*>(p_in + b * a.in_stride + tile_start * 7);
     const int nvec = cnt * 7 / VW;
     // clamped index instead of a guarded load: keeps `pre` in registers (a guarded
     // element-wise assignment sends the array to scratch and serialises the prefetch)
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(kTrackThreads) void k_track(
   T shift[7];
   if (MOMENTS) {
     acc.clear();
-    const T* p0 = p_in + b * N * 7;
+    const T* p0 = p_in + b * a.in_stride;
 #pragma unroll
     for (int i = 0; i < 7; ++i) shift[i] = p0[i];
     apply_program<T>(lat, s_steps, shift);
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(kTrackThreads) void k_track(
       const int64_t next_start = tile_start + TILE;
       if (t + 1 < a.tiles_per_wg && next_start < N) {
         const int ncnt = (int)((N - next_start) < TILE ? (N - next_start) : TILE);
-        const V* src = reinterpret_cast<const V*>(p_in + (b * N + next_start) * 7);
+        const V* src = reinterpret_cast<const V*>(p_in + b * a.in_stride + next_start * 7);
         const int nnvec = ncnt * 7 / VW;
 #pragma unroll
         for (int r = 0; r < NV; ++r) {
@@ -568,7 +569,7 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_direct(
   // Software pipeline: the loads of a tile are issued one iteration ahead (the first ones
   // right here, before the step table is fetched), so a workgroup always has a tile of HBM
   // reads in flight while it computes and stores the previous one.
-  const T* src = p_in + b * N * 7;
+  const T* src = p_in + b * a.in_stride;
   T* dst = p_out + b * N * 7;
   T zn[UNROLL][7];
   {
@@ -618,7 +619,7 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_direct(
 #pragma unroll
       for (int i = 0; i < 7; ++i) shift[i] = s_steps[LYNX_SHIFT_OFFSET + i];  // from k_build
     } else {
-      const T* p0 = p_in + b * N * 7;
+      const T* p0 = p_in + b * a.in_stride;
 #pragma unroll
       for (int i = 0; i < 7; ++i) shift[i] = p0[i];
       apply_program<T>(lat, s_steps, shift);

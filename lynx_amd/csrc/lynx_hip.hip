@@ -635,13 +635,15 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
   TrackPlan p = plan_track<T>(ctx, B, N, S, true, d_p_in, d_p_out, moments);
   bool fused = S > 0 && !(flags & LYNX_TRACK_TWO_KERNEL) && p.a.chunks <= env_int("LYNX_FUSE_MAX_CHUNKS", 0);
   if (!fused) p = plan_track<T>(ctx, B, N, S, false, d_p_in, d_p_out, moments);
+  const bool shared_in = (flags & LYNX_TRACK_SHARED_INPUT) != 0;
+  p.a.in_stride = shared_in ? 0 : N * 7;
   const void* d_steps = nullptr;
   int rc;
   if (S > 0 && !fused) {
     const size_t need = (size_t)B * S * LYNX_STEP_STRIDE * sizeof(T);
     if ((rc = ensure_scratch(ctx, &ctx->scratch_steps, &ctx->scratch_steps_bytes, need))) return rc;
     if ((rc = launch_build<T>(ctx, lat, d_energy_in, ctx->scratch_steps, d_energy_out, moments ? d_p_in : nullptr,
-                              N * 7)))
+                              p.a.in_stride)))
       return rc;
     d_steps = ctx->scratch_steps;
   }
@@ -679,6 +681,8 @@ int lynx_track_particles(lynx_ctx* ctx, lynx_lattice* lat, int64_t n_particles, 
   if (lat->n_steps > 0 && !d_energy_in) return fail(ctx, LYNX_ERR_INVALID, "energy_in required");
   if ((flags & LYNX_TRACK_MOMENTS) && !d_moments_out)
     return fail(ctx, LYNX_ERR_INVALID, "LYNX_TRACK_MOMENTS needs d_moments_out");
+  if ((flags & LYNX_TRACK_SHARED_INPUT) && d_p_in == d_p_out)
+    return fail(ctx, LYNX_ERR_INVALID, "a shared incoming beam cannot be tracked in place");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   LatticeDev lv = dev_view(lat);
   return lat->dtype == LYNX_F64

@@ -342,18 +342,22 @@ def run_program_particles(cache, program: Program, beam, moments: bool | None = 
     dtype = beam.dtype
     batch_shape = beam.batch_shape
     lat = _ready(cache, program, batch_shape, dtype, beam._energy.host())
-    p_in = beam._particles.device(rt)
-    p_out = rt.empty(p_in.shape, dtype)
+    p_in = beam._particles.device(rt)  # (N, 7)-like storage when the beam is shared by the batch
+    p_out = rt.empty((*batch_shape, beam.num_particles, 7), dtype)
     e_in = beam._energy.broadcast_device(rt, batch_shape)
     e_out = rt.empty(batch_shape, dtype) if lat.has_cavity_step else None
     want_moments = config.fused_moments if moments is None else moments
     mom = rt.empty((*batch_shape, _ffi.MOMENT_STRIDE), np.float64) if want_moments else None
-    flags = (_ffi.TRACK_MOMENTS if want_moments else 0) | (_ffi.TRACK_TWO_KERNEL if config.two_kernel else 0)
+    flags = ((_ffi.TRACK_MOMENTS if want_moments else 0) | (_ffi.TRACK_TWO_KERNEL if config.two_kernel else 0)
+             | (_ffi.TRACK_SHARED_INPUT if beam.is_shared else 0))
     rt.check(rt.lib.lynx_track_particles(rt.ctx, lat.handle, beam.num_particles, _ptr(e_in), _ptr(p_in),
                                          _ptr(p_out), _ptr(e_out), _ptr(mom), flags))
     out = ParticleBeam.__new__(ParticleBeam)
+    charges = beam._charges
+    if beam.is_shared and charges is not None:
+        charges = np.ascontiguousarray(beam.particle_charges)
     out._init_raw(Dual(dev=p_out), Dual(dev=e_out) if e_out is not None else beam._energy,
-                  beam._charges, dtype, moments=Dual(dev=mom) if mom is not None else None)
+                  charges, dtype, moments=Dual(dev=mom) if mom is not None else None)
     return out
 
 

