@@ -197,6 +197,18 @@ int lynx_track_particles_backward(lynx_ctx* ctx, lynx_lattice* lat, int64_t n_pa
                                   const double* d_moments_fwd, const double* d_grad_moments,
                                   void* d_grad_params, void* d_grad_energy_in, void* d_grad_p_in);
 
+/* Reverse pass of lynx_track_moments (ParameterBeam): gradient of a scalar function of the
+ * outgoing (mu, cov) with respect to every element parameter, the incoming energy and the
+ * incoming mu and cov (the reference's tests/test_differentiable.py:54-72 makes those the
+ * leaves).
+ *   d_mu_bar [B][7], d_cov_bar [B][7][7]   dL/d(outgoing mu), dL/d(outgoing cov), entry by entry
+ *   d_grad_params [B][E][8], d_grad_energy_in [B]   as for lynx_track_particles_backward
+ *   d_grad_mu_in [B][7], d_grad_cov_in [B][7][7]    dL/d(incoming mu), dL/d(incoming cov)      */
+int lynx_track_moments_backward(lynx_ctx* ctx, lynx_lattice* lat, const void* d_energy_in,
+                                const void* d_mu_in, const void* d_cov_in, const void* d_mu_bar,
+                                const void* d_cov_bar, void* d_grad_params, void* d_grad_energy_in,
+                                void* d_grad_mu_in, void* d_grad_cov_in);
+
 /* Moment read-out of an existing ParticleBeam (reference: particle_beam.py:736-836,
  * one fused pass instead of 14 separate reductions).  d_moments_out [B][36] float64.       */
 int lynx_moments(lynx_ctx* ctx, int dtype, int64_t batch, int64_t n_particles, const void* d_p,

@@ -84,6 +84,7 @@ SIGNATURES = {
     "lynx_track_particles": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i]),
     "lynx_track_moments": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "lynx_track_particles_backward": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "lynx_track_moments_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "lynx_moments": (_i, [_vp, _i, _i64, _i64, _vp, _vp]),
     "lynx_histogram2d": (_i, [_vp, _i, _i64, _i64, _vp, _vp, _vp, C.c_int32, C.c_int32, _vp]),
     "lynx_gaussian_image": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _vp, C.c_int32, C.c_int32, _vp]),

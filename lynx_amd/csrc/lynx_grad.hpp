@@ -401,6 +401,160 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// k_moments_bwd: reverse pass of k_track_moments (ParameterBeam), one wave per sample.
+//   forward per step:  mu' = M mu,  C' = M C M^T,  then for an active cavity
+//                      mu'[4] += T566 d^2 + T556 s d + T555 s^2,  mu'[5] = d c0 + c1 (cos a - c4),
+//                      C'[5][5] = c55,  C'[4][4] = C'[4][5] = C'[5][4] = T566 c55^2 + T556 c45 c55 + T555 c44^2
+//                      with s, d, c44, c45, c55 of the INCOMING beam (cavity.py:134-140, 202-218)
+//   reverse per step:  G = C'_bar without the overwritten entries, m = mu'_bar without [5]
+//                      T_bar = m (x) mu + (G M) C^T + (G^T M) C,   mu_bar = M^T m,   C_bar = M^T G M
+//                      plus the cavity's direct terms and its 8 coefficient cotangents.
+// The states entering every step are parked in HBM by the forward sweep ([B][S+1][56]).
+// T_bar and the coefficient cotangents leave in the layout k_build_bwd consumes.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(64) void k_moments_bwd(LatticeDev lat, const T* __restrict__ steps,
+                                                    const T* __restrict__ mu_in, const T* __restrict__ cov_in,
+                                                    const T* __restrict__ mu_bar_out, const T* __restrict__ cov_bar_out,
+                                                    T* __restrict__ states, T* __restrict__ tbar,
+                                                    T* __restrict__ grad_mu_in, T* __restrict__ grad_cov_in) {
+  __shared__ T s_mu[8], s_c[49], s_x[49], s_y[49], s_g[49], s_mb[8], s_m[64], s_k[16];
+  const int64_t b = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int cl = lane < 49 ? lane : 48;
+  const int i = cl / 7, j = cl % 7;
+  const int S = lat.n_steps;
+  const T* g_steps = steps + b * (int64_t)S * LYNX_STEP_STRIDE;
+  T* st = states + b * (int64_t)(S + 1) * 56;
+
+  if (lane < 7) s_mu[lane] = mu_in[b * 7 + lane];
+  if (lane < 49) s_c[lane] = cov_in[b * 49 + lane];
+  __syncthreads();
+  for (int s = 0; s < S; ++s) {
+    const lynx_step stp = lat.steps[s];
+    if (lane < 7) st[s * 56 + lane] = s_mu[lane];
+    if (lane < 49) st[s * 56 + 7 + lane] = s_c[lane];
+    s_m[lane] = g_steps[s * LYNX_STEP_STRIDE + lane];
+    __syncthreads();
+    T mu_new = T(0);
+    if (lane < 7) {
+      mu_new = s_m[lane * 7] * s_mu[0];
+#pragma unroll
+      for (int k = 1; k < 7; ++k) mu_new = t_fma(s_m[lane * 7 + k], s_mu[k], mu_new);
+    }
+    T x = s_c[i * 7] * s_m[j * 7];
+#pragma unroll
+    for (int k = 1; k < 7; ++k) x = t_fma(s_c[i * 7 + k], s_m[j * 7 + k], x);
+    const T s_i = s_mu[4], d_i = s_mu[5], c44 = s_c[32], c45 = s_c[33], c55 = s_c[40];
+    __syncthreads();
+    if (lane < 49) s_x[lane] = x;
+    if (lane < 7) s_mu[lane] = mu_new;
+    __syncthreads();
+    T c = s_m[i * 7] * s_x[j];
+#pragma unroll
+    for (int k = 1; k < 7; ++k) c = t_fma(s_m[i * 7 + k], s_x[k * 7 + j], c);
+    if (lane < 49) s_c[lane] = c;
+    __syncthreads();
+    if (stp.kind == LYNX_STEP_CAVITY && (stp.flags & LYNX_FLAG_CAV_GAIN) && lane == 0) {
+      const T* coef = s_m + LYNX_COEF_OFFSET;
+      T s_o = s_mu[4], d_o;
+      cavity_kick<T>(coef, s_i, d_i, s_o, d_o);
+      s_mu[4] = s_o;
+      s_mu[5] = d_o;
+      const T v = coef[LYNX_C_T566] * (c55 * c55) + coef[LYNX_C_T556] * c45 * c55 + coef[LYNX_C_T555] * (c44 * c44);
+      s_c[40] = c55;
+      s_c[32] = v;
+      s_c[33] = v;
+      s_c[39] = v;
+    }
+    __syncthreads();
+  }
+
+  if (lane < 7) s_mb[lane] = mu_bar_out[b * 7 + lane];
+  if (lane < 49) s_g[lane] = cov_bar_out[b * 49 + lane];
+  __syncthreads();
+  for (int s = S - 1; s >= 0; --s) {
+    const lynx_step stp = lat.steps[s];
+    if (lane < 7) s_mu[lane] = st[s * 56 + lane];
+    if (lane < 49) s_c[lane] = st[s * 56 + 7 + lane];
+    s_m[lane] = g_steps[s * LYNX_STEP_STRIDE + lane];
+    if (lane < 16) s_k[lane] = T(0);
+    __syncthreads();
+    const bool kick = stp.kind == LYNX_STEP_CAVITY && (stp.flags & LYNX_FLAG_CAV_GAIN);
+    if (kick && lane == 0) {
+      const T* cf = s_m + LYNX_COEF_OFFSET;
+      const T z4 = s_mu[4], z5 = s_mu[5], c44 = s_c[32], c45 = s_c[33], c55 = s_c[40];
+      const T m4 = s_mb[4], m5 = s_mb[5];
+      const T vb = s_g[32] + s_g[33] + s_g[39];
+      const T arg = T(-1) * z4 * cf[LYNX_C_BK] + cf[LYNX_C_PHI];
+      T sa, ca;
+      t_sincos(arg, sa, ca);
+      const T ab = -m5 * cf[LYNX_C_DKICK] * sa;
+      s_k[LYNX_C_DSCALE] = m5 * z5;
+      s_k[LYNX_C_DKICK] = m5 * (ca - cf[LYNX_C_COSPHI]);
+      s_k[LYNX_C_BK] = ab * (-z4);
+      s_k[LYNX_C_PHI] = ab;
+      s_k[LYNX_C_COSPHI] = -m5 * cf[LYNX_C_DKICK];
+      s_k[LYNX_C_T566] = vb * (c55 * c55) + m4 * (z5 * z5);
+      s_k[LYNX_C_T556] = vb * (c45 * c55) + m4 * (z4 * z5);
+      s_k[LYNX_C_T555] = vb * (c44 * c44) + m4 * (z4 * z4);
+      s_k[8] = ab * (-cf[LYNX_C_BK]) + m4 * (cf[LYNX_C_T556] * z5 + T(2) * cf[LYNX_C_T555] * z4);   // d/d mu_in[4]
+      s_k[9] = m5 * cf[LYNX_C_DSCALE] + m4 * (T(2) * cf[LYNX_C_T566] * z5 + cf[LYNX_C_T556] * z4);  // d/d mu_in[5]
+      s_k[10] = vb * T(2) * cf[LYNX_C_T555] * c44;                                                   // d/d c44
+      s_k[11] = vb * cf[LYNX_C_T556] * c55;                                                          // d/d c45
+      s_k[12] = s_g[40] + vb * (T(2) * cf[LYNX_C_T566] * c55 + cf[LYNX_C_T556] * c45);               // d/d c55
+      s_mb[5] = T(0);  // these outputs were overwritten by the kick
+      s_g[32] = T(0);
+      s_g[33] = T(0);
+      s_g[39] = T(0);
+      s_g[40] = T(0);
+    }
+    __syncthreads();
+    // P = G M, Q = G^T M
+    T pv = s_g[i * 7] * s_m[j], qv = s_g[i] * s_m[j];
+#pragma unroll
+    for (int k = 1; k < 7; ++k) {
+      pv = t_fma(s_g[i * 7 + k], s_m[k * 7 + j], pv);
+      qv = t_fma(s_g[k * 7 + i], s_m[k * 7 + j], qv);
+    }
+    if (lane < 49) {
+      s_x[lane] = pv;
+      s_y[lane] = qv;
+    }
+    __syncthreads();
+    T tb = s_mb[i] * s_mu[j], cb = T(0), mbn = T(0);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      tb = t_fma(s_x[i * 7 + k], s_c[j * 7 + k], tb);
+      tb = t_fma(s_y[i * 7 + k], s_c[k * 7 + j], tb);
+      cb = t_fma(s_m[k * 7 + i], s_x[k * 7 + j], cb);
+    }
+    if (lane < 7) {
+#pragma unroll
+      for (int k = 0; k < 7; ++k) mbn = t_fma(s_m[k * 7 + lane], s_mb[k], mbn);
+    }
+    T* tb_out = tbar + (b * S + s) * (int64_t)kGradStride;
+    if (lane < 49) tb_out[lane] = tb;
+    else if (lane < 57) tb_out[lane] = s_k[lane - 49];
+    else tb_out[lane] = T(0);
+    __syncthreads();
+    if (lane < 49) s_g[lane] = cb;
+    if (lane < 7) s_mb[lane] = mbn;
+    __syncthreads();
+    if (kick && lane == 0) {
+      s_mb[4] += s_k[8];
+      s_mb[5] += s_k[9];
+      s_g[32] += s_k[10];
+      s_g[33] += s_k[11];
+      s_g[40] += s_k[12];
+    }
+    __syncthreads();
+  }
+  if (lane < 7) grad_mu_in[b * 7 + lane] = s_mb[lane];
+  if (lane < 49) grad_cov_in[b * 49 + lane] = s_g[lane];
+}
+
 // partials [B][chunks][S][64] -> tbar [B][S][64]; one 64-thread workgroup per (sample, step)
 template <typename T>
 __global__ __launch_bounds__(64) void k_reduce_tbar(const T* __restrict__ partials, int chunks, int S,

@@ -768,6 +768,54 @@ int lynx_track_particles_backward(lynx_ctx* ctx, lynx_lattice* lat, int64_t n_pa
                                        d_grad_params, d_grad_energy_in, d_grad_p_in);
 }
 
+template <typename T>
+static int moments_backward_t(lynx_ctx* ctx, lynx_lattice* lat, const void* d_energy_in, const void* d_mu_in,
+                              const void* d_cov_in, const void* d_mu_bar, const void* d_cov_bar, void* d_grad_params,
+                              void* d_grad_energy_in, void* d_grad_mu_in, void* d_grad_cov_in) {
+  const int64_t B = lat->batch;
+  const int32_t S = lat->n_steps, E = lat->n_elems;
+  int rc;
+  if ((rc = ensure_scratch(ctx, &ctx->scratch_steps, &ctx->scratch_steps_bytes, (size_t)B * S * LYNX_STEP_STRIDE * sizeof(T))))
+    return rc;
+  if ((rc = launch_build<T>(ctx, lat, d_energy_in, ctx->scratch_steps, nullptr))) return rc;
+  if ((rc = ensure_scratch(ctx, &ctx->scratch_grad[0], &ctx->scratch_grad_bytes[0], (size_t)B * (S + 1) * 56 * sizeof(T))))
+    return rc;
+  if ((rc = ensure_scratch(ctx, &ctx->scratch_grad[1], &ctx->scratch_grad_bytes[1], (size_t)B * S * kGradStride * sizeof(T))))
+    return rc;
+  if ((rc = ensure_scratch(ctx, &ctx->scratch_grad[2], &ctx->scratch_grad_bytes[2],
+                           (size_t)B * (2 * E + S + 1) * 49 * sizeof(T))))
+    return rc;
+  LatticeDev lv = dev_view(lat);
+  hipLaunchKernelGGL(k_moments_bwd<T>, dim3((unsigned)B), dim3(64), 0, ctx->stream, lv, (const T*)ctx->scratch_steps,
+                     (const T*)d_mu_in, (const T*)d_cov_in, (const T*)d_mu_bar, (const T*)d_cov_bar,
+                     (T*)ctx->scratch_grad[0], (T*)ctx->scratch_grad[1], (T*)d_grad_mu_in, (T*)d_grad_cov_in);
+  HIP_TRY(ctx, hipGetLastError());
+  const size_t lds2 = ((size_t)2 * (S + 1) + E + 49 + 49) * sizeof(T);
+  if ((rc = allow_lds(ctx, k_build_bwd<T>, lds2))) return rc;
+  HIP_TRY(ctx, hipMemsetAsync(d_grad_params, 0, (size_t)B * E * kGradParams * sizeof(T), ctx->stream));
+  hipLaunchKernelGGL(k_build_bwd<T>, dim3((unsigned)B), dim3(256), lds2, ctx->stream, lv, (const T*)d_energy_in,
+                     (const T*)ctx->scratch_grad[1], (T*)ctx->scratch_grad[2], (T*)d_grad_params, (T*)d_grad_energy_in);
+  HIP_TRY(ctx, hipGetLastError());
+  return LYNX_OK;
+}
+
+int lynx_track_moments_backward(lynx_ctx* ctx, lynx_lattice* lat, const void* d_energy_in, const void* d_mu_in,
+                                const void* d_cov_in, const void* d_mu_bar, const void* d_cov_bar,
+                                void* d_grad_params, void* d_grad_energy_in, void* d_grad_mu_in,
+                                void* d_grad_cov_in) {
+  if (!ctx || !lat || !d_energy_in || !d_mu_in || !d_cov_in || !d_mu_bar || !d_cov_bar || !d_grad_params ||
+      !d_grad_energy_in || !d_grad_mu_in || !d_grad_cov_in)
+    return fail(ctx, LYNX_ERR_INVALID, "null argument");
+  if (lat->n_steps <= 0) return fail(ctx, LYNX_ERR_INVALID, "empty program");
+  if (lat->batch > 0x7fffffffLL) return fail(ctx, LYNX_ERR_INVALID, "batch too large");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  return lat->dtype == LYNX_F64
+             ? moments_backward_t<double>(ctx, lat, d_energy_in, d_mu_in, d_cov_in, d_mu_bar, d_cov_bar, d_grad_params,
+                                          d_grad_energy_in, d_grad_mu_in, d_grad_cov_in)
+             : moments_backward_t<float>(ctx, lat, d_energy_in, d_mu_in, d_cov_in, d_mu_bar, d_cov_bar, d_grad_params,
+                                         d_grad_energy_in, d_grad_mu_in, d_grad_cov_in);
+}
+
 int lynx_moments(lynx_ctx* ctx, int dtype, int64_t batch, int64_t n_particles, const void* d_p,
                  double* d_moments_out) {
   if (!ctx || !d_p || !d_moments_out) return fail(ctx, LYNX_ERR_INVALID, "null argument");

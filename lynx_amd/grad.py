@@ -49,9 +49,11 @@ class Gradients:
     first access.
     """
 
-    def __init__(self, program, raw_dev, energy_dev, batch_shape, energy_shape, particles_dev=None):
+    def __init__(self, program, raw_dev, energy_dev, batch_shape, energy_shape, particles_dev=None,
+                 mu_dev=None, cov_dev=None):
         self._program, self._raw_dev, self._energy_dev = program, raw_dev, energy_dev
         self._particles_dev = particles_dev
+        self._mu_dev, self._cov_dev = mu_dev, cov_dev
         self._batch_shape, self._energy_shape = tuple(batch_shape), tuple(energy_shape)
         self._raw = None
         self._cache = {}
@@ -72,6 +74,20 @@ class Gradients:
         if self._particles_dev is None:
             raise KeyError("call the VJP with wrt_particles=True to get the gradient w.r.t. the incoming particles")
         return self._particles_dev
+
+    @property
+    def mu(self) -> np.ndarray:
+        """dL/d(incoming mu), (*batch, 7) -- ParameterBeam VJPs only."""
+        if self._mu_dev is None:
+            raise KeyError("the gradient w.r.t. mu exists for ParameterBeam VJPs only")
+        return self._mu_dev.numpy()
+
+    @property
+    def cov(self) -> np.ndarray:
+        """dL/d(incoming cov), (*batch, 7, 7), entry by entry -- ParameterBeam VJPs only."""
+        if self._cov_dev is None:
+            raise KeyError("the gradient w.r.t. cov exists for ParameterBeam VJPs only")
+        return self._cov_dev.numpy()
 
     def __contains__(self, element) -> bool:
         return any(el is element and el._kind in DIFFERENTIABLE_KINDS for el in self._program.leaves)
@@ -180,6 +196,74 @@ class TrackVJP:
         return Gradients(program, g_par, g_en, batch_shape, np.asarray(beam.energy).shape, g_p)
 
 
-def track_vjp(segment, beam: ParticleBeam) -> TrackVJP:
+class MomentsVJP:
+    """Vector-Jacobian product of `Segment.track` on a `ParameterBeam` (lynx_track_moments_backward)."""
+
+    def __init__(self, segment, beam):
+        items = engine.partition(segment.elements if hasattr(segment, "elements") else [segment])
+        if len(items) != 1 or not isinstance(items[0], engine.Program):
+            raise NotImplementedError("track_vjp: lattices with active BPMs are not supported yet")
+        self.program = items[0]
+        self.beam = beam
+        self.cache = segment.__dict__.setdefault("_lattice_cache", engine.LatticeCache())
+        self.outgoing = engine.run_program_parameters(self.cache, self.program, beam)
+
+    def _property_cotangents(self, named: dict):
+        """`mu_<c>`: mu[c]; `sigma_<c>` = sqrt(max(cov_cc, 1e-20)) (parameter_beam.py:371-417); `sigma_xxp/yyp`: cov_01, cov_23."""
+        out = self.outgoing
+        batch = out.batch_shape
+        mu_bar, cov_bar = np.zeros((*batch, 7)), np.zeros((*batch, 7, 7))
+        for name, bar in named.items():
+            bar = np.broadcast_to(np.asarray(bar, dtype=np.float64), batch)
+            kind, _, coord = name.partition("_")
+            if kind == "mu" and coord in _COORDINATES:
+                mu_bar[..., _COORDINATES.index(coord)] += bar
+            elif kind == "sigma" and coord in _COORDINATES:
+                c = _COORDINATES.index(coord)
+                var = np.asarray(out._cov, dtype=np.float64)[..., c, c]
+                cov_bar[..., c, c] += np.where(var > 1e-20, bar / (2.0 * np.sqrt(np.maximum(var, 1e-20))), 0.0)
+            elif name in ("sigma_xxp", "sigma_yyp"):
+                c = 0 if name == "sigma_xxp" else 2
+                cov_bar[..., c, c + 1] += bar
+            else:
+                raise KeyError(f"no cotangent rule for beam property {name!r}")
+        return mu_bar, cov_bar
+
+    def __call__(self, mu_bar=None, cov_bar=None, **properties) -> Gradients:
+        """`mu_bar` (*batch, <=7), `cov_bar` (*batch, 6|7, 6|7): cotangents entry by entry."""
+        rt = get_runtime()
+        beam, program = self.beam, self.program
+        batch_shape, dtype = beam.batch_shape, beam.dtype
+        B = int(np.prod(batch_shape, dtype=np.int64))
+        mb, cb = np.zeros((B, 7)), np.zeros((B, 7, 7))
+        if properties:
+            pm, pc = self._property_cotangents(properties)
+            mb += pm.reshape(B, 7)
+            cb += pc.reshape(B, 7, 7)
+        if mu_bar is not None:
+            mu_bar = np.asarray(mu_bar, dtype=np.float64).reshape(B, -1)
+            mb[:, : mu_bar.shape[1]] += mu_bar
+        if cov_bar is not None:
+            cov_bar = np.asarray(cov_bar, dtype=np.float64)
+            k = cov_bar.shape[-1]
+            cb[:, :k, :k] += cov_bar.reshape(B, k, k)
+        lat = engine._ready(self.cache, program, batch_shape, dtype, beam._energy.host())
+        g_par = rt.empty((B, max(lat.E, 1), 8), dtype)
+        g_en = rt.empty((B,), dtype)
+        g_mu = rt.empty((*batch_shape, 7), dtype)
+        g_cov = rt.empty((*batch_shape, 7, 7), dtype)
+        e_in = beam._energy.broadcast_device(rt, batch_shape)
+        p = lambda a: C.c_void_p(a.ptr)  # noqa: E731
+        rt.check(rt.lib.lynx_track_moments_backward(
+            rt.ctx, lat.handle, p(e_in), p(beam._mu_d.device(rt)), p(beam._cov_d.device(rt)),
+            p(rt.to_device(mb.astype(dtype))), p(rt.to_device(cb.astype(dtype))), p(g_par), p(g_en), p(g_mu), p(g_cov)))
+        return Gradients(program, g_par, g_en, batch_shape, np.asarray(beam.energy).shape, mu_dev=g_mu, cov_dev=g_cov)
+
+
+def track_vjp(segment, beam):
     """Forward pass through `segment`; returns the callable vector-Jacobian product."""
+    from .particles.parameter_beam import ParameterBeam
+
+    if isinstance(beam, ParameterBeam):
+        return MomentsVJP(segment, beam)
     return TrackVJP(segment, beam)

@@ -227,3 +227,96 @@ def test_gradient_based_tuning_example_converges(lx):
     history = example.tune(segment, beam, steps=60)
     assert history[-1] < 0.05 * history[0], (history[0], history[-1])
     assert abs(float(segment.track(beam).mu_x[0])) < 2e-4
+
+
+def test_parameter_beam_gradients_match_finite_differences_fp64(lx):
+    """
+    Reverse pass of the ParameterBeam path (lynx_track_moments_backward): every element
+    parameter of the cavity lattice, the incoming energy, and the incoming mu and cov (the leaves
+    of the reference's tests/test_differentiable.py:54-72) against central differences of the
+    oracle's ParameterBeam tracking in float64.
+    """
+    rng = np.random.default_rng(11)
+    B = 2
+    desc = _desc(B, rng)
+    elements, specs = make_lattice(desc, np.float64, lx)
+    A = rng.normal(size=(B, 6, 6)) * [1e-4, 1e-5, 1e-4, 1e-5, 1e-4, 1e-3]
+    cov = np.zeros((B, 7, 7))
+    cov[:, :6, :6] = A @ np.swapaxes(A, -1, -2)
+    mu = np.concatenate([rng.normal(size=(B, 6)) * [1e-3, 1e-4, 1e-3, 1e-4, 1e-4, 1e-3], np.ones((B, 1))], axis=-1)
+    energy = np.array([6e6, 8e6])
+    w_mu = rng.normal(size=(B, 7)) * [1, 1, 1, 1, 1, 1, 0]
+    w_cov = np.zeros((B, 7, 7))
+    w_cov[:, :6, :6] = rng.normal(size=(B, 6, 6)) * 1e3
+
+    def loss(mu_, cov_, energy_):
+        out = o.segment_track(specs, o.parameter_beam(mu_, cov_, energy_, np.float64), np.float64)
+        return np.sum(w_mu * out["mu"], axis=-1) + np.sum(w_cov * out["cov"], axis=(-1, -2))
+
+    beam = lx.ParameterBeam(mu, cov, energy, dtype=np.float64)
+    g = lx.grad.track_vjp(lx.Segment(elements), beam)(mu_bar=w_mu, cov_bar=w_cov)
+
+    def central(apply, x0):
+        h = 1e-6 * max(abs(x0), 1e-2)
+        apply(x0 + h)
+        up = loss(mu, cov, energy)
+        apply(x0 - h)
+        down = loss(mu, cov, energy)
+        apply(x0)
+        return (up - down) / (2 * h)
+
+    checked = 0
+    for e, (kind, _) in enumerate(desc):
+        for name in PARAMS_TO_CHECK.get(kind, []):
+            arr = specs[e][name]
+            if arr is None:
+                continue
+            got = g[elements[e]][name]
+            for idx in np.ndindex(arr.shape):
+                def apply(x, arr=arr, idx=idx):
+                    arr[idx] = x
+                ref = central(apply, arr[idx])[idx[0]]
+                scale = max(abs(ref), 1e-9 * np.max(np.abs(w_cov)))
+                assert abs(got[idx] - ref) <= 2e-4 * scale + 1e-7 * np.max(np.abs(got)), (kind, e, name, idx, got[idx], ref)
+                checked += 1
+    assert checked > 50
+    # incoming energy, mu and cov
+    for bidx in range(B):
+        h = 1e-6 * energy[bidx]
+        ep, em = energy.copy(), energy.copy()
+        ep[bidx] += h
+        em[bidx] -= h
+        ref = (loss(mu, cov, ep)[bidx] - loss(mu, cov, em)[bidx]) / (2 * h)
+        assert abs(g.energy[bidx] - ref) <= 2e-4 * abs(ref) + 1e-12, (bidx, g.energy[bidx], ref)
+        for c in range(6):
+            h = 1e-7
+            mp, mm = mu.copy(), mu.copy()
+            mp[bidx, c] += h
+            mm[bidx, c] -= h
+            ref = (loss(mp, cov, energy)[bidx] - loss(mm, cov, energy)[bidx]) / (2 * h)
+            assert abs(g.mu[bidx, c] - ref) <= 1e-5 * abs(ref) + 1e-9 * np.max(np.abs(g.mu[bidx])), (bidx, c, g.mu[bidx, c], ref)
+        for (r, c) in [(0, 0), (0, 1), (1, 0), (2, 3), (4, 4), (4, 5), (5, 4), (5, 5), (3, 5)]:
+            h = 1e-12
+            cp, cm = cov.copy(), cov.copy()
+            cp[bidx, r, c] += h
+            cm[bidx, r, c] -= h
+            ref = (loss(mu, cp, energy)[bidx] - loss(mu, cm, energy)[bidx]) / (2 * h)
+            assert abs(g.cov[bidx, r, c] - ref) <= 1e-4 * abs(ref) + 1e-7 * np.max(np.abs(g.cov[bidx])), (bidx, r, c, g.cov[bidx, r, c], ref)
+
+
+def test_parameter_beam_property_cotangents_and_batches(lx):
+    """sigma_x cotangent of a ParameterBeam against a central difference of the tracked sigma_x, fp32, batch of 1000."""
+    f = lambda v: np.full(1000, v, np.float32)  # noqa: E731
+    k1 = np.linspace(-8, 8, 1000).astype(np.float32)
+    seg = lx.Segment([lx.Drift(f(0.2)), lx.Quadrupole(f(0.122), k1=k1, name="Q"), lx.Drift(f(1.0))])
+    beam = lx.ParameterBeam.from_parameters(sigma_x=f(1.75e-4), sigma_xp=f(3.7e-6), energy=f(1.07e8))
+    g = lx.grad.track_vjp(seg, beam)(sigma_x=np.ones(1000))
+    got = g[seg.Q]["k1"]
+    assert got.shape == (1000,)
+    h = 0.05
+    seg.Q.k1 = k1 + np.float32(h)
+    up = seg.track(beam).sigma_x.astype(np.float64)
+    seg.Q.k1 = k1 - np.float32(h)
+    down = seg.track(beam).sigma_x.astype(np.float64)
+    ref = (up - down) / (2 * h)
+    assert np.allclose(got, ref, rtol=5e-2, atol=2e-3 * np.max(np.abs(ref)))
