@@ -228,6 +228,19 @@ int lynx_histogram2d(lynx_ctx* ctx, int dtype, int64_t batch, int64_t n_particle
 int lynx_gaussian_image(lynx_ctx* ctx, int dtype, int64_t batch, const void* d_mu, const void* d_cov,
                         const void* d_xs, const void* d_ys, int32_t nx, int32_t ny, void* d_image);
 
+/* Aperture (reference: aperture.py:69-108): particles with |x| < x_max and |y| < y_max
+ * (rectangular) or x^2/x_max^2 + y^2/y_max^2 <= 1 (elliptical) survive.
+ *   d_x_max, d_y_max [B] (param_stride 1) or one value for all samples (param_stride 0)
+ *   d_mask [B][N] uint8, d_counts / d_offsets [B][ceil(N/1024)], d_totals [B] survivors     */
+int lynx_aperture_mask(lynx_ctx* ctx, int dtype, int64_t batch, int64_t n_particles, const void* d_p,
+                       const void* d_x_max, const void* d_y_max, int32_t param_stride, int32_t elliptical,
+                       unsigned char* d_mask, int32_t* d_counts, int64_t* d_offsets, int64_t* d_totals);
+/* One sample: d_kept [total][7] survivors and d_lost [N - total][7] lost particles, each in
+ * their original order (what `particles[mask]` returns), from the mask and offsets above.    */
+int lynx_aperture_compact(lynx_ctx* ctx, int dtype, int64_t n_particles, const void* d_p,
+                          const unsigned char* d_mask, const int64_t* d_offsets, void* d_kept,
+                          void* d_lost);
+
 /* Seeded synthetic beam, generated in HBM: uncorrelated 6-D Gaussian per sample, 7th
  * coordinate 1 (shape of ParticleBeam.from_parameters, particle_beam.py:144-170; not the
  * same random stream).  mu[6], sigma[6] are host arrays.                                   */

@@ -85,10 +85,15 @@ class BPM(Element):
 
 class Aperture(Element):
     """
-    Physical aperture, kept as a parameter holder so that lattices containing one load.  An
-    inactive aperture is an identity element; an active one drops particles, which changes N
-    per batch sample -- out of scope of the fixed-shape streaming path
-    and refused loudly.
+    Physical aperture (lynx/accelerator/aperture.py:23-153).  An active aperture removes the
+    particles of a `ParticleBeam` outside |x| < x_max, |y| < y_max (or the ellipse); a
+    `ParameterBeam` passes unchanged.  The mask, the survivor count and the order-preserving
+    compaction run on the GPU (`lynx_aperture_mask`, `lynx_aperture_compact`).
+
+    Particle loss makes the particle count depend on the sample, so a batch is accepted as long
+    as no sample loses a particle (the ARES lattice's three apertures are infinite) and a single
+    sample may lose any number; the reference's boolean-mask indexing flattens the batch
+    dimension in that case (aperture.py:87), here the leading batch dimension of size 1 stays.
 
     :param x_max: half size horizontal offset in [m]
     :param y_max: half size vertical offset in [m]
@@ -98,6 +103,9 @@ class Aperture(Element):
 
     _batched = (("x_max", 0), ("y_max", 0))
     _settings = ("shape", "is_active")
+    _transient = Element._transient + ("lost_particles", "lost_particle_charges")
+    lost_particles = None
+    lost_particle_charges = None
 
     def __init__(self, x_max=None, y_max=None, shape: str = "rectangular", is_active: bool = True,
                  name: Optional[str] = None, device=None, dtype=np.float32) -> None:
@@ -106,17 +114,70 @@ class Aperture(Element):
         self.y_max = np.asarray(np.inf if y_max is None else y_max, dtype=dtype)
         self.shape = shape
         self.is_active = is_active
-        self.lost_particles = None
 
     @property
     def is_skippable(self) -> bool:
         return not self.is_active
 
+    @property
+    def _host_barrier(self) -> bool:
+        return bool(self.is_active)
+
+    def _observe(self, incoming) -> None:
+        pass
+
+    def _transform(self, incoming):
+        """What an active aperture does to the beam (aperture.py:69-108)."""
+        Beam, _, ParticleBeam = _beam_types()
+        if not isinstance(incoming, ParticleBeam):
+            return incoming  # only particle beams are clipped (aperture.py:70-72)
+        assert np.all(self.x_max >= 0) and np.all(self.y_max >= 0)
+        assert self.shape in ["rectangular", "elliptical"], f"Unknown aperture shape {self.shape}"
+        beam = incoming.materialized()
+        rt = get_runtime()
+        dtype, batch, n = beam.dtype, beam.batch_shape, beam.num_particles
+        B = int(np.prod(batch, dtype=np.int64))
+        limits = []
+        for value in (self.x_max, self.y_max):
+            value = np.asarray(value, dtype=dtype)
+            limits.append(value.reshape(1) if value.size == 1 else np.ascontiguousarray(np.broadcast_to(value, batch)).reshape(B))
+        stride = 0 if limits[0].size == 1 and limits[1].size == 1 else 1
+        if stride:
+            limits = [np.ascontiguousarray(np.broadcast_to(v, (B,))) for v in limits]
+        chunks = (n + 1023) // 1024
+        mask = rt.empty((*batch, n), np.uint8)
+        counts = rt.empty((B, chunks), np.int32)
+        offsets = rt.empty((B, chunks), np.int64)
+        totals = rt.empty((B,), np.int64)
+        particles = beam._particles.device(rt)
+        ptr = lambda a: C.c_void_p(a.ptr)  # noqa: E731
+        x_dev, y_dev = rt.to_device(limits[0]), rt.to_device(limits[1])  # named: alive until the call is enqueued
+        rt.check(rt.lib.lynx_aperture_mask(rt.ctx, dtype_code(dtype), B, n, ptr(particles), ptr(x_dev),
+                                           ptr(y_dev), stride, int(self.shape == "elliptical"),
+                                           ptr(mask), ptr(counts), ptr(offsets), ptr(totals)))
+        survivors = totals.numpy()
+        if np.all(survivors == n):  # nothing lost: the beam goes on as it is
+            self.lost_particles = np.zeros((0, 7), dtype=dtype)
+            self.lost_particle_charges = np.zeros((0,), dtype=dtype)
+            return beam._shallow_copy()
+        if B != 1:
+            raise NotImplementedError(
+                f"Aperture {self.name!r}: {int(np.sum(n - survivors))} particles lost in a batch of {B} samples; the "
+                "particle count would differ between samples (the reference's mask indexing flattens the batch here)")
+        k = int(survivors[0])
+        keep = mask.numpy().reshape(-1).astype(bool)
+        charges = np.asarray(beam.particle_charges).reshape(-1)
+        if k == 0:
+            self.lost_particles, self.lost_particle_charges = np.asarray(beam.particles).reshape(n, 7), charges
+            return Beam.empty  # aperture.py:106-107
+        kept, lost = rt.empty((*batch, k, 7), dtype), rt.empty((n - k, 7), dtype)
+        rt.check(rt.lib.lynx_aperture_compact(rt.ctx, dtype_code(dtype), n, ptr(particles), ptr(mask), ptr(offsets),
+                                              ptr(kept), ptr(lost)))
+        self.lost_particles, self.lost_particle_charges = lost, charges[~keep]
+        return ParticleBeam(kept, beam.energy, particle_charges=charges[keep].reshape(*batch, k), dtype=dtype)
+
     def track(self, incoming):
-        if self.is_active:
-            raise NotImplementedError("an active Aperture changes the particle count per sample; "
-                                      "lynx_amd does not build ragged particle loss")
-        return incoming
+        return self._transform(incoming) if self.is_active else incoming
 
 
 class Screen(Element):
@@ -251,9 +312,10 @@ class Screen(Element):
             xs = np.arange(e[0], e[1], step[0], dtype=dtype)
             ys = np.arange(e[2], e[3], step[1], dtype=dtype)
             out = rt.empty((*beam.batch_shape, len(xs), len(ys)), dtype)
+            xs_dev, ys_dev = rt.to_device(xs), rt.to_device(ys)  # named: alive until the call is enqueued
             rt.check(rt.lib.lynx_gaussian_image(rt.ctx, dtype_code(dtype), B, C.c_void_p(beam._mu_d.device(rt).ptr),
                                                 C.c_void_p(beam._cov_d.device(rt).ptr),
-                                                C.c_void_p(rt.to_device(xs).ptr), C.c_void_p(rt.to_device(ys).ptr),
+                                                C.c_void_p(xs_dev.ptr), C.c_void_p(ys_dev.ptr),
                                                 len(xs), len(ys), C.c_void_p(out.ptr)))
             image = out.numpy()
         else:

@@ -1016,6 +1016,95 @@ __global__ __launch_bounds__(256) void k_gaussian_image(const T* __restrict__ mu
 }
 
 // ---------------------------------------------------------------------------------------
+// Aperture (lynx/accelerator/aperture.py:69-108): which particles survive, and the stable
+// compaction of one sample's survivors / lost particles.
+//   k_aperture_mask     mask[b][n] and the survivor count of every 1024-particle chunk
+//   k_aperture_scan     per sample: exclusive scan of the chunk counts, total survivors
+//   k_aperture_compact  one sample: survivors to `kept` in their original order, the rest to
+//                       `lost` in their original order (what boolean-mask indexing returns)
+// ---------------------------------------------------------------------------------------
+constexpr int kApertureChunk = 1024;  // 256 threads x 4 consecutive particles
+
+template <typename T>
+__device__ __forceinline__ bool aperture_survives(T x, T y, T xm, T ym, int elliptical) {
+  if (elliptical) return (x * x) / (xm * xm) + (y * y) / (ym * ym) <= T(1);  // aperture.py:83-86
+  return (x > -xm && x < xm) && (y > -ym && y < ym);                         // aperture.py:78-82
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_aperture_mask(const T* __restrict__ p, int64_t N, int chunks,
+                                                        const T* __restrict__ x_max, const T* __restrict__ y_max,
+                                                        int param_stride, int elliptical,
+                                                        unsigned char* __restrict__ mask, int32_t* __restrict__ counts) {
+  __shared__ int s_count;
+  const int64_t b = blockIdx.x / chunks;
+  const int chunk = blockIdx.x % chunks;
+  const T xm = x_max[b * param_stride], ym = y_max[b * param_stride];
+  if (threadIdx.x == 0) s_count = 0;
+  __syncthreads();
+  int mine = 0;
+  for (int q = 0; q < 4; ++q) {
+    const int64_t n = (int64_t)chunk * kApertureChunk + threadIdx.x * 4 + q;
+    if (n < N) {
+      const T* z = p + (b * N + n) * 7;
+      const bool ok = aperture_survives<T>(z[0], z[2], xm, ym, elliptical);
+      mask[b * N + n] = ok ? 1 : 0;
+      mine += ok ? 1 : 0;
+    }
+  }
+  atomicAdd(&s_count, mine);  // integer: exact and order-independent
+  __syncthreads();
+  if (threadIdx.x == 0) counts[b * chunks + chunk] = s_count;
+}
+
+__global__ __launch_bounds__(256) void k_aperture_scan(const int32_t* __restrict__ counts, int chunks,
+                                                        int64_t* __restrict__ offsets, int64_t* __restrict__ totals) {
+  // one workgroup per sample; thread 0 walks the chunk counts (chunks = N / 1024: short)
+  const int64_t b = blockIdx.x;
+  if (threadIdx.x == 0) {
+    int64_t run = 0;
+    for (int c = 0; c < chunks; ++c) {
+      offsets[b * chunks + c] = run;
+      run += counts[b * chunks + c];
+    }
+    totals[b] = run;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_aperture_compact(const T* __restrict__ p, int64_t N,
+                                                           const unsigned char* __restrict__ mask,
+                                                           const int64_t* __restrict__ offsets, T* __restrict__ kept,
+                                                           T* __restrict__ lost) {
+  __shared__ int s_scan[256];
+  const int chunk = blockIdx.x, tid = threadIdx.x;
+  const int64_t first = (int64_t)chunk * kApertureChunk + tid * 4;
+  bool ok[4];
+  int mine = 0;
+  for (int q = 0; q < 4; ++q) {
+    ok[q] = first + q < N && mask[first + q] != 0;
+    mine += ok[q] ? 1 : 0;
+  }
+  s_scan[tid] = mine;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {  // inclusive scan of the 256 per-thread counts
+    const int add = tid >= off ? s_scan[tid - off] : 0;
+    __syncthreads();
+    s_scan[tid] += add;
+    __syncthreads();
+  }
+  int64_t k = offsets[chunk] + (s_scan[tid] - mine);  // survivors before this thread's particles
+  for (int q = 0; q < 4; ++q) {
+    const int64_t n = first + q;
+    if (n >= N) break;
+    T* dst = ok[q] ? kept + k * 7 : lost + (n - k) * 7;  // n - k = lost particles before n
+#pragma unroll
+    for (int c = 0; c < 7; ++c) dst[c] = p[n * 7 + c];
+    k += ok[q] ? 1 : 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // k_diag_copy: plain 16-byte grid-stride copy.  Calibration only: what this box sustains for
 // a read+write stream of the same size as a tracking pass (the practical HBM ceiling).
 // ---------------------------------------------------------------------------------------

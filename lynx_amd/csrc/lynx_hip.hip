@@ -885,6 +885,48 @@ int lynx_histogram2d(lynx_ctx* ctx, int dtype, int64_t batch, int64_t n_particle
   return LYNX_OK;
 }
 
+// ---- aperture ----------------------------------------------------------------------------
+
+int lynx_aperture_mask(lynx_ctx* ctx, int dtype, int64_t batch, int64_t n_particles, const void* d_p,
+                       const void* d_x_max, const void* d_y_max, int32_t param_stride, int32_t elliptical,
+                       unsigned char* d_mask, int32_t* d_counts, int64_t* d_offsets, int64_t* d_totals) {
+  if (!ctx || !d_p || !d_x_max || !d_y_max || !d_mask || !d_counts || !d_offsets || !d_totals || batch <= 0 ||
+      n_particles <= 0 || (param_stride != 0 && param_stride != 1))
+    return fail(ctx, LYNX_ERR_INVALID, "bad argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int64_t chunks = (n_particles + kApertureChunk - 1) / kApertureChunk;
+  if (batch * chunks > 0x7fffffffLL) return fail(ctx, LYNX_ERR_INVALID, "grid too large");
+  if (dtype == LYNX_F64)
+    hipLaunchKernelGGL(k_aperture_mask<double>, dim3((unsigned)(batch * chunks)), dim3(256), 0, ctx->stream,
+                       (const double*)d_p, n_particles, (int)chunks, (const double*)d_x_max, (const double*)d_y_max,
+                       (int)param_stride, (int)elliptical, d_mask, d_counts);
+  else
+    hipLaunchKernelGGL(k_aperture_mask<float>, dim3((unsigned)(batch * chunks)), dim3(256), 0, ctx->stream,
+                       (const float*)d_p, n_particles, (int)chunks, (const float*)d_x_max, (const float*)d_y_max,
+                       (int)param_stride, (int)elliptical, d_mask, d_counts);
+  HIP_TRY(ctx, hipGetLastError());
+  hipLaunchKernelGGL(k_aperture_scan, dim3((unsigned)batch), dim3(256), 0, ctx->stream, d_counts, (int)chunks, d_offsets,
+                     d_totals);
+  HIP_TRY(ctx, hipGetLastError());
+  return LYNX_OK;
+}
+
+int lynx_aperture_compact(lynx_ctx* ctx, int dtype, int64_t n_particles, const void* d_p, const unsigned char* d_mask,
+                          const int64_t* d_offsets, void* d_kept, void* d_lost) {
+  if (!ctx || !d_p || !d_mask || !d_offsets || !d_kept || !d_lost || n_particles <= 0)
+    return fail(ctx, LYNX_ERR_INVALID, "bad argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int64_t chunks = (n_particles + kApertureChunk - 1) / kApertureChunk;
+  if (dtype == LYNX_F64)
+    hipLaunchKernelGGL(k_aperture_compact<double>, dim3((unsigned)chunks), dim3(256), 0, ctx->stream, (const double*)d_p,
+                       n_particles, d_mask, d_offsets, (double*)d_kept, (double*)d_lost);
+  else
+    hipLaunchKernelGGL(k_aperture_compact<float>, dim3((unsigned)chunks), dim3(256), 0, ctx->stream, (const float*)d_p,
+                       n_particles, d_mask, d_offsets, (float*)d_kept, (float*)d_lost);
+  HIP_TRY(ctx, hipGetLastError());
+  return LYNX_OK;
+}
+
 int lynx_gaussian_image(lynx_ctx* ctx, int dtype, int64_t batch, const void* d_mu, const void* d_cov,
                         const void* d_xs, const void* d_ys, int32_t nx, int32_t ny, void* d_image) {
   if (!ctx || !d_mu || !d_cov || !d_xs || !d_ys || !d_image || batch <= 0 || nx <= 0 || ny <= 0 || batch > 65535)

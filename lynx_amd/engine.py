@@ -408,6 +408,8 @@ def track(owner, elements, incoming, raw: bool = False):
             item._observe(beam)
             if getattr(item, "_swallows_beam", False):
                 beam = Beam.empty
+            elif hasattr(item, "_transform"):  # active Aperture (aperture.py:69-108)
+                beam = item._transform(beam)
             elif beam is not Beam.empty:
                 beam = beam._shallow_copy()
         if beam is Beam.empty:  # everything behind an active screen sees the empty beam

@@ -254,9 +254,11 @@ class MomentsVJP:
         g_cov = rt.empty((*batch_shape, 7, 7), dtype)
         e_in = beam._energy.broadcast_device(rt, batch_shape)
         p = lambda a: C.c_void_p(a.ptr)  # noqa: E731
+        # named, so that both uploads stay allocated until the call has been enqueued
+        mb_dev, cb_dev = rt.to_device(mb.astype(dtype)), rt.to_device(cb.astype(dtype))
         rt.check(rt.lib.lynx_track_moments_backward(
             rt.ctx, lat.handle, p(e_in), p(beam._mu_d.device(rt)), p(beam._cov_d.device(rt)),
-            p(rt.to_device(mb.astype(dtype))), p(rt.to_device(cb.astype(dtype))), p(g_par), p(g_en), p(g_mu), p(g_cov)))
+            p(mb_dev), p(cb_dev), p(g_par), p(g_en), p(g_mu), p(g_cov)))
         return Gradients(program, g_par, g_en, batch_shape, np.asarray(beam.energy).shape, mu_dev=g_mu, cov_dev=g_cov)
 
 

@@ -916,3 +916,20 @@ def screen_reading_parameters(mu, cov, resolution, pixel_size, binning, dtype=np
         img = np.exp(-0.5 * maha - np.log(2 * np.pi) - 0.5 * np.log(det))
         out.append(img[::-1])  # flip(dims=[1]) of the stacked (B, nx, ny) image
     return np.stack(out).reshape(*mu.shape[:-1], len(xs), len(ys))
+
+
+# ---------------------------------------------------------------------------------
+# Aperture (lynx/accelerator/aperture.py:69-108)
+# ---------------------------------------------------------------------------------
+
+
+def aperture_mask(particles, x_max, y_max, shape="rectangular"):
+    """aperture.py:78-86: which particles survive (x_max, y_max broadcast over the particle axis)."""
+    xs, ys = particles[..., 0], particles[..., 2]
+    x_max = np.asarray(x_max, dtype=particles.dtype)[..., None]
+    y_max = np.asarray(y_max, dtype=particles.dtype)[..., None]
+    if shape == "rectangular":
+        return np.logical_and(np.logical_and(xs > -x_max, xs < x_max), np.logical_and(ys > -y_max, ys < y_max))
+    assert shape == "elliptical", f"Unknown aperture shape {shape}"
+    with np.errstate(all="ignore"):
+        return xs ** 2 / x_max ** 2 + ys ** 2 / y_max ** 2 <= 1.0
