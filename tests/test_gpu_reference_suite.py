@@ -342,3 +342,91 @@ def test_split_drift_and_quadrupole_lengths(lx):
         # a split drift / quadrupole is the same linear map up to rounding
         beam = lx.ParameterBeam.from_parameters(sigma_x=f32(1e-4), sigma_xp=f32(1e-5))
         assert np.allclose(lx.Segment(pieces).track(beam).sigma_x, element.track(beam).sigma_x, rtol=1e-4)
+
+
+# -- a whole machine: the element mix of docs/examples/ARESlatticeStage3v1_9.json --------------------
+
+
+def _ares_like_machine(lx, dtype, seed=0):
+    """
+    183 elements with the class counts of the ARES lattice file's element table (78 drifts, 26 markers, 15 + 15
+    correctors, 14 screens, 13 quadrupoles, 8 BPMs, 5 dipoles, 4 cavities, 3 apertures, 2
+    solenoids), shuffled with a fixed seed; screens and BPMs inactive, apertures active and
+    infinitely wide as in the file.  The cavities are switched ON: the file has them at zero
+    voltage, for which the reference's cavity map is NaN (cavity.py:72-78, guard removed) and
+    every particle is then lost in the next aperture -- here as there; that case is covered by
+    test_cavity_mixed_zero_voltage_batch_matches_reference_nan.  Returns (lynx elements,
+    oracle specs of the elements that have a map).
+    """
+    rng = np.random.default_rng(seed)
+    a = lambda v: np.array([v], dtype=dtype)  # noqa: E731
+    kinds = (["drift"] * 78 + ["marker"] * 26 + ["hcor"] * 15 + ["vcor"] * 15 + ["screen"] * 14 + ["quad"] * 13
+             + ["bpm"] * 8 + ["dipole"] * 5 + ["cavity"] * 4 + ["aperture"] * 3 + ["solenoid"] * 2)
+    rng.shuffle(kinds)
+    elements, specs = [], []
+    for kind in kinds:
+        if kind == "drift":
+            L = a(rng.uniform(0.05, 0.5))
+            elements.append(lx.Drift(L, dtype=dtype)); specs.append(o.Drift(L))
+        elif kind == "marker":
+            elements.append(lx.Marker())
+        elif kind in ("hcor", "vcor"):
+            L, ang = a(rng.uniform(0.01, 0.05)), a(rng.normal(0, 2e-4))
+            cls_x, cls_o = (lx.HorizontalCorrector, o.HorizontalCorrector) if kind == "hcor" else (lx.VerticalCorrector, o.VerticalCorrector)
+            elements.append(cls_x(L, angle=ang, dtype=dtype)); specs.append(cls_o(L, angle=ang))
+        elif kind == "screen":
+            elements.append(lx.Screen(resolution=(2448, 2040), pixel_size=(3.5488e-06, 2.5003e-06), is_active=False, dtype=dtype))
+        elif kind == "quad":
+            L, k1 = a(0.122), a(rng.uniform(-8, 8))
+            elements.append(lx.Quadrupole(L, k1=k1, dtype=dtype)); specs.append(o.Quadrupole(L, k1=k1))
+        elif kind == "bpm":
+            elements.append(lx.BPM())
+        elif kind == "dipole":
+            kw = dict(angle=a(rng.uniform(-0.1, 0.1)), e1=a(0.02), e2=a(0.03), fringe_integral=a(0.3), gap=a(0.02))
+            L = a(0.22)
+            elements.append(lx.Dipole(L, dtype=dtype, **kw)); specs.append(o.Dipole(L, **kw))
+        elif kind == "cavity":
+            kw = dict(voltage=a(rng.uniform(1e7, 2e7)), phase=a(rng.uniform(-5, 5)), frequency=a(2.998e9))
+            L = a(4.139)
+            elements.append(lx.Cavity(L, dtype=dtype, **kw)); specs.append(o.Cavity(L, **kw))
+        elif kind == "aperture":
+            elements.append(lx.Aperture(x_max=a(np.inf), y_max=a(np.inf), dtype=dtype))
+        else:
+            L, k = a(0.09), a(rng.uniform(0, 2))
+            elements.append(lx.Solenoid(L, k=k, dtype=dtype)); specs.append(o.Solenoid(L, k=k))
+    return elements, specs
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_a_whole_ares_like_machine(lx, dtype):
+    elements, specs = _ares_like_machine(lx, dtype)
+    segment = lx.Segment(elements)
+    assert len(segment.elements) == 183 and not segment.is_skippable  # the three active apertures
+    energy = np.array([1.07e8], dtype)
+    P = o.gaussian_particles((1,), 30_000, seed=8, dtype=dtype, sigma=[1.75e-4, 3.7e-6, 1.75e-4, 3.7e-6, 8e-6, 2.3e-3])
+    out = segment.track(lx.ParticleBeam(P, energy, dtype=dtype))
+    ref = o.segment_track(specs, o.particle_beam(P, energy, dtype), dtype)
+    got = np.asarray(out.particles)
+    tol = 2e-3 if dtype == np.float32 else 1e-9  # ~170 maps composed in float32
+    for c in range(6):
+        scale = np.max(np.abs(ref["particles"][..., c]))
+        assert np.max(np.abs(got[..., c] - ref["particles"][..., c])) < tol * scale, c
+    mom = o.beam_moments(ref)
+    for name in ("sigma_x", "sigma_y", "sigma_xp", "sigma_yp"):
+        assert np.allclose(getattr(out, name), mom[name], rtol=tol), name
+    # the moments-only beam through the same machine
+    pout = segment.track(lx.ParameterBeam.from_parameters(sigma_x=np.array([1.75e-4], dtype), sigma_xp=np.array([3.7e-6], dtype),
+                                                         energy=energy, dtype=dtype))
+    pref = o.segment_track(specs, o.parameter_beam_from_parameters(dtype=dtype, sigma_x=np.array([1.75e-4], dtype),
+                                                                    sigma_xp=np.array([3.7e-6], dtype), energy=energy), dtype)
+    assert np.allclose(pout.sigma_x, o.beam_moments(pref)["sigma_x"], rtol=tol)
+    # and the file round trip of the whole machine (latticejson.py:69-189)
+    import os
+    import tempfile
+
+    path = os.path.join(tempfile.mkdtemp(), "machine.json")
+    segment.to_lattice_json(path)
+    again = lx.Segment.from_lattice_json(path)
+    assert [type(e).__name__ for e in again.elements] == [type(e).__name__ for e in segment.elements]
+    if dtype == np.float32:  # the file format is float32 (latticejson.py:129-138)
+        assert np.array_equal(np.asarray(again.track(lx.ParticleBeam(P, energy)).particles), got)
