@@ -260,3 +260,27 @@ def test_gradient_host_helpers():
     idx = sorted(_tri(i, j) for i in range(6) for j in range(i, 6))
     assert idx == list(range(7, 28))  # the 21 upper-triangle slots of a moment record
     assert _tri(0, 0) == 7 and _tri(0, 5) == 12 and _tri(1, 1) == 13 and _tri(5, 5) == 27
+
+
+def test_header_is_plain_c(tmp_path):
+    """The drop-in boundary is a C ABI: include/lynx_hip.h must compile as C99 and link from a C client."""
+    import shutil
+    import subprocess
+
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    header = ROOT / "include" / "lynx_hip.h"
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", str(header)], check=True)
+    client = tmp_path / "client.c"
+    client.write_text(
+        '#include "lynx_hip.h"\n#include <stdio.h>\n'
+        'int main(void) { int n = -1; printf("%s %d\\n", lynx_version(), lynx_device_count(&n)); '
+        'lynx_elem e = {LYNX_KIND_QUADRUPOLE, LYNX_FLAG_TILT, 0, 5}; lynx_step s = {LYNX_STEP_RUN, 0, 1, 0}; '
+        'return (int)(sizeof e + sizeof s) == 32 ? 0 : 1; }\n')
+    lib = ROOT / "lynx_amd" / "_lib"
+    exe = tmp_path / "client"
+    subprocess.run([gcc, "-std=c99", f"-I{ROOT / 'include'}", str(client), f"-L{lib}", "-llynxhip", f"-Wl,-rpath,{lib}",
+                    "-o", str(exe)], check=True)
+    done = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert done.returncode == 0 and done.stdout.startswith("lynx"), (done.returncode, done.stdout, done.stderr)
