@@ -262,7 +262,7 @@ def test_gradient_host_helpers():
     assert _tri(0, 0) == 7 and _tri(0, 5) == 12 and _tri(1, 1) == 13 and _tri(5, 5) == 27
 
 
-def test_header_is_plain_c(tmp_path):
+def test_header_is_plain_c(tmp_path, built_library):
     """The drop-in boundary is a C ABI: include/lynx_hip.h must compile as C99 and link from a C client."""
     import shutil
     import subprocess
