@@ -5,9 +5,10 @@ included, on synthetic lattices/beams of the shapes BASELINE.json names.
 
     python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torchrun)
 
-A "step" is one `segment.track(beam)` over the whole per-GPU batch: one fused launch that
-builds + composes every sample's element maps and streams the particles through them,
-the moment finalisation, and (N > 1) the RCCL all-gather of the per-sample moment records.
+A "step" is one `segment.track(beam)` over the whole per-GPU batch: the launch that builds +
+composes every sample's element maps, the launch that streams the particles through them
+(moments accumulated in its epilogue), the moment finalisation, and (N > 1) the RCCL
+all-gather of the per-sample moment records.
 Particles, lattice parameters and outputs are resident in HBM when the timed region starts.
 
 Workload (default `c4`): BASELINE.json config 4, the configuration the metric's target is

@@ -5,13 +5,15 @@
 //               (lynx/particles/particle_beam.py:24-45); scalar type T = float | double.
 //   lattice     elems[E], steps[S], elem_step[E] (int32) + parameter pool (T), see
 //               include/lynx_hip.h.
-//   step table  [B][S][64] T: per sample and step the composed 7x7 map (49) and the
-//               cavity coefficients (8).  In the fused kernel it only ever lives in LDS.
+//   step table  [B][S][64] T: per sample and step the composed 7x7 map (49), the cavity
+//               coefficients (8) and, in step 0, the moment reference point (7).  Written by
+//               k_build, read with scalar loads by the streaming kernel (in the optional
+//               fused variant it only ever lives in LDS).
 //   partials    [B][chunks][36] double: per-workgroup moment sums (deterministic
 //               two-stage reduction; no float atomics).
 //
-// Wavefront = 64 everywhere; workgroups are 256 threads (4 waves) for the streaming
-// kernel and 64 threads (1 wave) for the per-sample kernels.
+// Wavefront = 64 everywhere; workgroups are 256 threads (4 waves) for the streaming and build
+// kernels, 64 or 256 threads for the per-sample moment kernels.
 #pragma once
 
 #include <hip/hip_runtime.h>
