@@ -313,7 +313,7 @@ class ParticleBeam(Beam):
             batch = tuple(a * b for a, b in zip((1,) * (d - len(stored)) + tuple(stored),
                                                 (1,) * (d - len(shape)) + tuple(shape)))
             out = self.__class__.__new__(self.__class__)
-            out._init_raw(self._particles, Dual(np.tile(self.energy, shape)), self._charges, self.dtype, None, batch)
+            out._init_raw(self._particles, Dual(np.tile(self.energy, shape)), self._charges, self.dtype, self._moments, batch)
             return out
         if self.is_shared:
             return self.materialized().broadcast(shape)
