@@ -228,6 +228,11 @@ int lynx_histogram2d(lynx_ctx* ctx, int dtype, int64_t batch, int64_t n_particle
 int lynx_gaussian_image(lynx_ctx* ctx, int dtype, int64_t batch, const void* d_mu, const void* d_cov,
                         const void* d_xs, const void* d_ys, int32_t nx, int32_t ny, void* d_image);
 
+/* Test hook: the float32 sine / cosine the cavity kick uses on the device (cavity.py:141-161
+ * calls cos per particle), scalar (packed = 0) or two-per-lane (packed = 1) code path.        */
+int lynx_diag_phase_trig(lynx_ctx* ctx, int64_t n, const float* d_x, int32_t packed, float* d_sin,
+                         float* d_cos);
+
 /* Aperture (reference: aperture.py:69-108): particles with |x| < x_max and |y| < y_max
  * (rectangular) or x^2/x_max^2 + y^2/y_max^2 <= 1 (elliptical) survive.
  *   d_x_max, d_y_max [B] (param_stride 1) or one value for all samples (param_stride 0)

@@ -88,6 +88,7 @@ SIGNATURES = {
     "lynx_moments": (_i, [_vp, _i, _i64, _i64, _vp, _vp]),
     "lynx_histogram2d": (_i, [_vp, _i, _i64, _i64, _vp, _vp, _vp, C.c_int32, C.c_int32, _vp]),
     "lynx_gaussian_image": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _vp, C.c_int32, C.c_int32, _vp]),
+    "lynx_diag_phase_trig": (_i, [_vp, _i64, _vp, C.c_int32, _vp, _vp]),
     "lynx_aperture_mask": (_i, [_vp, _i, _i64, _i64, _vp, _vp, _vp, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp]),
     "lynx_aperture_compact": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _vp, _vp]),
     "lynx_fill_gaussian": (_i, [_vp, _i, _i64, _i64, C.POINTER(C.c_double), C.POINTER(C.c_double),

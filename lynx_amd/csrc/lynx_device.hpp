@@ -171,6 +171,97 @@ __device__ void load_steps_sample(const T* g_steps, int S, T* s_steps) {
   __syncthreads();
 }
 
+// ---------------------------------------------------------------------------------------
+// Phase trigonometry of the cavity kick, float32.  The kick is cos(-s beta0 k + phi) - cos(phi)
+// per particle and cavity (cavity.py:141-161); with 8 cavities it is ~40 % of the VALU work of
+// BASELINE config 5.  The library's cosf/sincosf spend ~45 instructions on the common path
+// because they must be ready for any argument (Payne-Hanek behind a branch).  For |x| <= 1000:
+// 3-term Cody-Waite reduction by pi/2 with FMAs and the Cephes minimax polynomials on
+// [-pi/4, pi/4] -- about 22 instructions, half of that per particle when two are packed.
+// Measured on 2 M random arguments per range: max error 1.55 ulp up to |x| = 1000 (NumPy's
+// float32 cos, the oracle's: 1.49), max absolute error 9.2e-8 (6e-8).  Larger arguments (a
+// reference test sets phase = 48198468 degrees) and NaN/Inf take the library path.
+// ---------------------------------------------------------------------------------------
+constexpr float kFastTrigLimit = 1000.0f;
+typedef float lynx_f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float vfma(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ lynx_f32x2 vfma(lynx_f32x2 a, lynx_f32x2 b, lynx_f32x2 c) {
+  return __builtin_elementwise_fma(a, b, c);
+}
+__device__ __forceinline__ float vrint(float a) { return __builtin_rintf(a); }
+__device__ __forceinline__ lynx_f32x2 vrint(lynx_f32x2 a) {
+  return lynx_f32x2{__builtin_rintf(a.x), __builtin_rintf(a.y)};
+}
+
+// quadrant q (as a float) of x, |x| <= kFastTrigLimit, and sin / cos of the reduced argument
+template <typename V>
+__device__ __forceinline__ void sincos_reduced(V x, V& q, V& sr, V& cr) {
+  q = vrint(x * 0.636619772f);
+  V r = vfma(q, V(-1.5707963705062866f), x);
+  r = vfma(q, V(4.3711388286737929e-08f), r);
+  r = vfma(q, V(1.7151245100059975e-15f), r);
+  const V z = r * r;
+  V ps = vfma(z, V(-1.9515295891e-4f), V(8.3321608736e-3f));
+  ps = vfma(ps, z, V(-1.6666654611e-1f));
+  sr = vfma(ps * z, r, r);
+  V pc = vfma(z, V(2.443315711809948e-5f), V(-1.388731625493765e-3f));
+  pc = vfma(pc, z, V(4.166664568298827e-2f));
+  cr = vfma(pc * z, z, vfma(z, V(-0.5f), V(1.0f)));
+}
+
+__device__ __forceinline__ void quadrant_select(float q, float sr, float cr, float& s, float& c) {
+  const int m = (int)q & 3;
+  const float ss = (m & 1) ? cr : sr, cc = (m & 1) ? sr : cr;
+  s = (m & 2) ? -ss : ss;
+  c = ((m + 1) & 2) ? -cc : cc;
+}
+
+__device__ __forceinline__ void phase_sincos(float x, float& s, float& c) {
+  if (__builtin_expect(!(__builtin_fabsf(x) <= kFastTrigLimit), 0)) {
+    s = t_sin(x);
+    c = t_cos(x);
+    return;
+  }
+  float q, sr, cr;
+  sincos_reduced<float>(x, q, sr, cr);
+  quadrant_select(q, sr, cr, s, c);
+}
+__device__ __forceinline__ void phase_sincos(double x, double& s, double& c) {
+  s = t_sin(x);
+  c = t_cos(x);
+}
+__device__ __forceinline__ void phase_sincos(lynx_f32x2 x, lynx_f32x2& s, lynx_f32x2& c) {
+  float s0, c0, s1, c1;
+  const float big = __builtin_fmaxf(__builtin_fabsf(x.x), __builtin_fabsf(x.y));
+  if (__builtin_expect(!(big <= kFastTrigLimit), 0)) {
+    phase_sincos(x.x, s0, c0);
+    phase_sincos(x.y, s1, c1);
+  } else {
+    lynx_f32x2 q, sr, cr;
+    sincos_reduced<lynx_f32x2>(x, q, sr, cr);
+    quadrant_select(q.x, sr.x, cr.x, s0, c0);
+    quadrant_select(q.y, sr.y, cr.y, s1, c1);
+  }
+  s = lynx_f32x2{s0, s1};
+  c = lynx_f32x2{c0, c1};
+}
+template <typename V> __device__ __forceinline__ V phase_cos(V x) {
+  V s, c;
+  phase_sincos(x, s, c);
+  return c;
+}
+
+// Non-linear cavity step on the device: the expression of cavity_kick<T> (lynx_maps.hpp, the
+// one the host harness checks against the oracle) with phase_cos.
+template <typename T>
+__device__ __forceinline__ void device_cavity_kick(const T* coef, T s_in, T d_in, T& s_out, T& d_out) {
+  d_out = d_in * coef[LYNX_C_DSCALE] +
+          coef[LYNX_C_DKICK] * (phase_cos<T>(T(-1) * s_in * coef[LYNX_C_BK] + coef[LYNX_C_PHI]) - coef[LYNX_C_COSPHI]);
+  s_out = s_out + (coef[LYNX_C_T566] * (d_in * d_in) + coef[LYNX_C_T556] * s_in * d_in +
+                   coef[LYNX_C_T555] * (s_in * s_in));
+}
+
 // Apply one step of the program to one particle held in registers.
 //   run:    z <- T z                                  (element.py:85, `particles @ tm^T`)
 //   cavity: z <- T z, then the non-linear delta / s update from the INCOMING s, delta
@@ -187,7 +278,7 @@ __device__ __forceinline__ void apply_step(const T* M /*49 + coef*/, int step_ki
     o[i] = acc;
   }
   if (step_kind == LYNX_STEP_CAVITY && (step_flags & LYNX_FLAG_CAV_GAIN)) {
-    cavity_kick<T>(M + LYNX_COEF_OFFSET, z[4], z[5], o[4], o[5]);
+    device_cavity_kick<T>(M + LYNX_COEF_OFFSET, z[4], z[5], o[4], o[5]);
   }
 #pragma unroll
   for (int i = 0; i < 7; ++i) z[i] = o[i];
@@ -199,7 +290,6 @@ __device__ __forceinline__ void apply_step(const T* M /*49 + coef*/, int step_ki
 // VALU-bound (BASELINE config 5: 16 maps + 8 cosines per particle), whereas the single-map
 // stream is HBM-bound and measured 10 % slower with packed math.  Same operations in the same
 // order per component as apply_step<float>, so the results are bit-identical.
-typedef float lynx_f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ lynx_f32x2 pk_fma(lynx_f32x2 a, float b, lynx_f32x2 c) {
   return __builtin_elementwise_fma(a, (lynx_f32x2)(b), c);
@@ -219,7 +309,7 @@ __device__ __forceinline__ void apply_step_pair(const float* M /*49 + coef*/, in
     const float* coef = M + LYNX_COEF_OFFSET;
     const lynx_f32x2 s_in = z[4], d_in = z[5];
     const lynx_f32x2 arg = -1.0f * s_in * coef[LYNX_C_BK] + coef[LYNX_C_PHI];
-    const lynx_f32x2 ca = {t_cos(arg.x), t_cos(arg.y)};
+    const lynx_f32x2 ca = phase_cos<lynx_f32x2>(arg);
     o[5] = d_in * coef[LYNX_C_DSCALE] + coef[LYNX_C_DKICK] * (ca - coef[LYNX_C_COSPHI]);
     o[4] = o[4] + (coef[LYNX_C_T566] * (d_in * d_in) + coef[LYNX_C_T556] * s_in * d_in +
                    coef[LYNX_C_T555] * (s_in * s_in));
@@ -939,7 +1029,7 @@ __global__ __launch_bounds__(256) void k_track_moments(LatticeDev lat, const T* 
     if (st.kind == LYNX_STEP_CAVITY && (st.flags & LYNX_FLAG_CAV_GAIN) && lane == 0) {
       const T* coef = M + LYNX_COEF_OFFSET;
       T s_o = s_mu[4], d_o;
-      cavity_kick<T>(coef, s_in[4], s_in[5], s_o, d_o);  // cavity.py:134-140, 202-206
+      device_cavity_kick<T>(coef, s_in[4], s_in[5], s_o, d_o);  // cavity.py:134-140, 202-206
       s_mu[4] = s_o;
       s_mu[5] = d_o;
       const T c44 = s_in[7], c45 = s_in[8], c55 = s_in[9];
@@ -1103,6 +1193,27 @@ __global__ __launch_bounds__(256) void k_aperture_compact(const T* __restrict__ 
 #pragma unroll
     for (int c = 0; c < 7; ++c) dst[c] = p[n * 7 + c];
     k += ok[q] ? 1 : 0;
+  }
+}
+
+// k_diag_phase_trig: phase_sincos on an array, scalar and packed-pair code paths (test hook for
+// the accuracy statement above).
+__global__ __launch_bounds__(256) void k_diag_phase_trig(const float* __restrict__ x, int64_t n, int packed,
+                                                          float* __restrict__ s_out, float* __restrict__ c_out) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+  if (i >= n) return;
+  const int64_t j = i + 1 < n ? i + 1 : i;
+  if (packed) {
+    lynx_f32x2 s, c;
+    phase_sincos(lynx_f32x2{x[i], x[j]}, s, c);
+    s_out[i] = s.x; c_out[i] = c.x;
+    s_out[j] = s.y; c_out[j] = c.y;
+  } else {
+    float s, c;
+    phase_sincos(x[i], s, c);
+    s_out[i] = s; c_out[i] = c;
+    phase_sincos(x[j], s, c);
+    s_out[j] = s; c_out[j] = c;
   }
 }
 

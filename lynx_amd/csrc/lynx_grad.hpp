@@ -100,10 +100,6 @@ template <typename T> __device__ __forceinline__ T sum_over_wave(T v) {
   return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
 }
 
-// sine and cosine of the cavity phase share one range reduction
-__device__ __noinline__ void t_sincos(float x, float& s, float& c) { sincosf(x, &s, &c); }
-__device__ __noinline__ void t_sincos(double x, double& s, double& c) { sincos(x, &s, &c); }
-
 template <typename T>
 __device__ __forceinline__ void load_step_map(const T* g_steps, int s, T (&m)[57]) {
 #pragma unroll
@@ -135,15 +131,8 @@ __device__ __forceinline__ void zset(lynx_f32x2& z, int w, float v) {
 __device__ __forceinline__ float zhsum(float z) { return z; }
 __device__ __forceinline__ double zhsum(double z) { return z; }
 __device__ __forceinline__ float zhsum(lynx_f32x2 z) { return z.x + z.y; }
-__device__ __forceinline__ void zsincos(float x, float& s, float& c) { t_sincos(x, s, c); }
-__device__ __forceinline__ void zsincos(double x, double& s, double& c) { t_sincos(x, s, c); }
-__device__ __forceinline__ void zsincos(lynx_f32x2 x, lynx_f32x2& s, lynx_f32x2& c) {
-  float s0, c0, s1, c1;
-  t_sincos(x.x, s0, c0);
-  t_sincos(x.y, s1, c1);
-  s = lynx_f32x2{s0, s1};
-  c = lynx_f32x2{c0, c1};
-}
+// sine and cosine of the cavity phase: phase_sincos of lynx_device.hpp (the forward kernels' cos)
+template <typename Z> __device__ __forceinline__ void zsincos(Z x, Z& s, Z& c) { phase_sincos(x, s, c); }
 __device__ __forceinline__ void zapply(const float* m, int kind, int flags, float (&z)[7]) { apply_step<float>(m, kind, flags, z); }
 __device__ __forceinline__ void zapply(const double* m, int kind, int flags, double (&z)[7]) { apply_step<double>(m, kind, flags, z); }
 __device__ __forceinline__ void zapply(const float* m, int kind, int flags, lynx_f32x2 (&z)[7]) { apply_step_pair(m, kind, flags, z); }
@@ -459,7 +448,7 @@ __global__ __launch_bounds__(64) void k_moments_bwd(LatticeDev lat, const T* __r
     if (stp.kind == LYNX_STEP_CAVITY && (stp.flags & LYNX_FLAG_CAV_GAIN) && lane == 0) {
       const T* coef = s_m + LYNX_COEF_OFFSET;
       T s_o = s_mu[4], d_o;
-      cavity_kick<T>(coef, s_i, d_i, s_o, d_o);
+      device_cavity_kick<T>(coef, s_i, d_i, s_o, d_o);
       s_mu[4] = s_o;
       s_mu[5] = d_o;
       const T v = coef[LYNX_C_T566] * (c55 * c55) + coef[LYNX_C_T556] * c45 * c55 + coef[LYNX_C_T555] * (c44 * c44);
@@ -489,7 +478,7 @@ __global__ __launch_bounds__(64) void k_moments_bwd(LatticeDev lat, const T* __r
       const T vb = s_g[32] + s_g[33] + s_g[39];
       const T arg = T(-1) * z4 * cf[LYNX_C_BK] + cf[LYNX_C_PHI];
       T sa, ca;
-      t_sincos(arg, sa, ca);
+      phase_sincos(arg, sa, ca);
       const T ab = -m5 * cf[LYNX_C_DKICK] * sa;
       s_k[LYNX_C_DSCALE] = m5 * z5;
       s_k[LYNX_C_DKICK] = m5 * (ca - cf[LYNX_C_COSPHI]);

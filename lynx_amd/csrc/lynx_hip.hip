@@ -885,6 +885,16 @@ int lynx_histogram2d(lynx_ctx* ctx, int dtype, int64_t batch, int64_t n_particle
   return LYNX_OK;
 }
 
+int lynx_diag_phase_trig(lynx_ctx* ctx, int64_t n, const float* d_x, int32_t packed, float* d_sin, float* d_cos) {
+  if (!ctx || !d_x || !d_sin || !d_cos || n <= 0) return fail(ctx, LYNX_ERR_INVALID, "bad argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int64_t threads = (n + 1) / 2;
+  hipLaunchKernelGGL(k_diag_phase_trig, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, d_x, n,
+                     (int)packed, d_sin, d_cos);
+  HIP_TRY(ctx, hipGetLastError());
+  return LYNX_OK;
+}
+
 // ---- aperture ----------------------------------------------------------------------------
 
 int lynx_aperture_mask(lynx_ctx* ctx, int dtype, int64_t batch, int64_t n_particles, const void* d_p,

@@ -656,3 +656,34 @@ def test_lazily_broadcast_beam_tracks_like_the_repeated_one(lx, dtype):
     w.xs = np.asarray(w.xs) * 2
     assert not w.is_shared and np.array_equal(np.asarray(w.particles)[..., 0], 2 * np.asarray(repeated.particles)[..., 0])
     assert shared.is_shared  # the copy was written to, not the original
+
+
+@pytest.mark.parametrize("packed", [0, 1])
+def test_device_phase_trig_accuracy(lx, packed):
+    """
+    The cavity kick's float32 cos/sin on the device (lynx_device.hpp: Cody-Waite + minimax up to
+    |x| = 1000, library path beyond) against float64: within 2 ulp of the correctly rounded
+    value and 1.2e-7 absolute -- the class of NumPy's float32 cos (the oracle's), so the choice of
+    implementation does not show in the 1e-4 moment tolerance; special values as the library's.
+    """
+    import ctypes as C
+
+    from lynx_amd.device import get_runtime
+
+    rt = get_runtime()
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.uniform(-1, 1, 200_000), rng.uniform(-30, 30, 200_000), rng.uniform(-1000, 1000, 200_000),
+                        rng.uniform(-2e6, 2e6, 100_000), np.array([0.0, -0.0, 1000.0, -1000.0, 1000.0001, 841226.0]),
+                        np.arange(-40, 41) * (np.pi / 4)]).astype(np.float32)
+    special = np.array([np.nan, np.inf, -np.inf], dtype=np.float32)
+    xs = np.concatenate([x, special, special[:1]])  # odd length too
+    d_x, d_s, d_c = rt.to_device(xs), rt.empty(xs.shape, np.float32), rt.empty(xs.shape, np.float32)
+    rt.check(rt.lib.lynx_diag_phase_trig(rt.ctx, xs.size, C.c_void_p(d_x.ptr), packed, C.c_void_p(d_s.ptr), C.c_void_p(d_c.ptr)))
+    s, c = d_s.numpy(), d_c.numpy()
+    assert np.all(np.isnan(s[x.size:])) and np.all(np.isnan(c[x.size:]))
+    x64 = x.astype(np.float64)
+    for got, ref in ((c[: x.size], np.cos(x64)), (s[: x.size], np.sin(x64))):
+        err = np.abs(got.astype(np.float64) - ref)
+        assert err.max() < 1.2e-7, err.max()
+        ulp = np.spacing(np.maximum(np.abs(ref), 1e-3).astype(np.float32)).astype(np.float64)  # relative, away from zeros
+        assert (err / ulp).max() < 2.0, (err / ulp).max()
