@@ -25,9 +25,14 @@ from .. import _ffi, engine
 
 _anonymous = itertools.count()
 
-# Bumped by every public attribute write on any element: while it stands still, nothing the
-# packed lattice programs depend on can have changed, and `engine` reuses its plan in O(1).
+# EPOCH is bumped by every public attribute write on any element: while it stands still,
+# nothing the packed lattice programs depend on can have changed, and `engine` reuses them in
+# O(1).  STRUCTURE is bumped only by writes that can change how a lattice is partitioned into
+# kernel launches -- attributes of elements whose skippability is not a class constant (cavity
+# voltage, `is_active` of BPM / Screen / Aperture) and anything set on a Segment -- so that the
+# optimisation-loop pattern (write a magnet strength, track, repeat) keeps its plan.
 EPOCH = [0]
+STRUCTURE = [0]
 
 
 def generate_unique_name() -> str:
@@ -75,6 +80,8 @@ class Element:
         if not key.startswith("_"):
             object.__setattr__(self, "_version", self._version + 1)
             EPOCH[0] += 1
+            if self._skippable is None:
+                STRUCTURE[0] += 1
 
     def _adopt(self, dtype, length, **given) -> None:
         """

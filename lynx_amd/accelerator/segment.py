@@ -13,7 +13,7 @@ import numpy as np
 from .. import engine
 from .diagnostics import Marker
 from .magnets import CustomTransferMap, Drift
-from .element import EPOCH, Element
+from .element import EPOCH, STRUCTURE, Element
 
 
 class Segment(Element):
@@ -41,6 +41,7 @@ class Segment(Element):
     def __setattr__(self, key, value):
         object.__setattr__(self, key, value)
         EPOCH[0] += 1
+        STRUCTURE[0] += 1
 
     @property
     def _version(self):  # a segment's version is the version of what it contains

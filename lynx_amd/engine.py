@@ -96,11 +96,12 @@ def partition(elements) -> list:
 
 def plan(owner, elements, raw: bool) -> list:
     """
-    `partition(elements)` remembered on `owner` for as long as no element attribute has been
-    written (global EPOCH) and the element list holds the same objects: the steady state of a
-    tracking loop then costs one C-level pass over the list instead of Python work per element.
+    `partition(elements)` remembered on `owner` for as long as no attribute that can change the
+    partition has been written (global STRUCTURE counter) and the element list holds the same
+    objects: a tracking loop then costs one C-level pass over the list instead of Python work
+    per element, also when magnet strengths are rewritten between the calls.
     """
-    from .accelerator.element import EPOCH
+    from .accelerator.element import STRUCTURE
     from .accelerator.segment import Segment
 
     def identities(items):
@@ -110,7 +111,7 @@ def plan(owner, elements, raw: bool) -> list:
         return ids
 
     ids = identities(elements)
-    token = (EPOCH[0], raw, ids)
+    token = (STRUCTURE[0], raw, ids)
     remembered = owner.__dict__.get("_plan")
     if remembered is not None and remembered[0] == token:
         return remembered[1]

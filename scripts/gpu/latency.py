@@ -51,7 +51,6 @@ k = [0.0]
 
 def retune_and_track(b):
     k[0] += 0.01
-    seg.H2 = None  # (no such element: plain attribute on the segment, leaves the elements alone)
     seg.elements[4].angle = f(3e-3 + 1e-6 * k[0])
     return seg.track(b)
 

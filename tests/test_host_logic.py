@@ -169,9 +169,15 @@ def test_plan_is_reused_until_an_attribute_is_written():
     cache = engine.LatticeCache()
     lat = cache.get(first[0], (1,), np.float32)
     assert cache.get(first[0], (1,), np.float32) is lat  # O(1) path: same program object, same epoch
-    seg.Q.k1 = f(2.0)
+    seg.Q.k1 = f(2.0)  # a magnet strength cannot change the partition: same plan, refreshed pool block
     second = engine.plan(seg, seg.elements, False)
-    assert second is not first and cache.get(second[0], (1,), np.float32) is lat and lat.pool[lat.layout[1][0] + 1] == 2.0
+    assert second is first and cache.get(second[0], (1,), np.float32) is lat and lat.pool[lat.layout[1][0] + 1] == 2.0
+    cav = lx.Cavity(f(1.0), voltage=f(0.0), name="C")
+    with_cavity = lx.Segment([lx.Drift(f(1.0)), cav])
+    off = engine.plan(with_cavity, with_cavity.elements, False)
+    assert off[0].steps == [[_ffi.STEP_RUN, 0, 2]]
+    cav.voltage = f(1e6)  # ... a cavity voltage can: the cavity becomes a step of its own
+    assert engine.plan(with_cavity, with_cavity.elements, False)[0].steps == [[_ffi.STEP_RUN, 0, 1], [_ffi.STEP_CAVITY, 1, 2]]
     bpm.is_active = True  # structure changes: the BPM becomes a host-side barrier
     third = engine.plan(seg, seg.elements, False)
     assert [type(i).__name__ for i in third] == ["Program", "BPM", "Program"]
