@@ -203,8 +203,10 @@ class PackedLattice:
                 if self.handle is not None:
                     self.rt.check(self.rt.lib.lynx_lattice_update_params(
                         self.handle, offset, size, self.pool[offset:offset + size].ctypes.data))
+            if self._static is not None:  # whole-batch predicates of this element (tilt, misalignment, ...)
+                self._static = list(self._static)
+                self._static[e] = el._static_flags()
         self.versions = tuple(versions)
-        self._static = None
         return True
 
     # whole-batch predicates -----------------------------------------------------------------
