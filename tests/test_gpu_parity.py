@@ -687,3 +687,43 @@ def test_device_phase_trig_accuracy(lx, packed):
         assert err.max() < 1.2e-7, err.max()
         ulp = np.spacing(np.maximum(np.abs(ref), 1e-3).astype(np.float32)).astype(np.float64)  # relative, away from zeros
         assert (err / ulp).max() < 2.0, (err / ulp).max()
+
+
+def test_attribute_writes_between_tracks_take_effect(lx):
+    """
+    README.md:60 pattern (`segment.AREAMQZM2.k1 = ...`): values, whole-batch predicates (tilt,
+    misalignment: LYNX_FLAG_*) and structure (cavity switched on, BPM activated) written between
+    two `track` calls of the same Segment must all reach the device-resident lattice program.
+    """
+    f = lambda v: np.array([v], dtype=np.float64)  # noqa: E731
+    quad = lx.Quadrupole(f(0.2), k1=f(1.0), dtype=np.float64, name="Q")
+    cav = lx.Cavity(f(1.0), voltage=f(0.0), phase=f(0.0), frequency=f(1.3e9), dtype=np.float64, name="C")
+    seg = lx.Segment([lx.Drift(f(0.5), dtype=np.float64), quad, lx.Drift(f(0.3), dtype=np.float64)])
+    P = o.gaussian_particles((1,), 3000, seed=5, dtype=np.float64, sigma=[1e-4, 1e-5, 1e-4, 1e-5, 1e-5, 1e-3])
+    beam = lx.ParticleBeam(P, f(6e6), dtype=np.float64)
+
+    def reference(**kw):
+        specs = [o.Drift(f(0.5)), o.Quadrupole(f(0.2), **kw), o.Drift(f(0.3))]
+        return o.segment_track(specs, o.particle_beam(P, f(6e6), np.float64), np.float64)["particles"]
+
+    assert np.allclose(np.asarray(seg.track(beam).particles), reference(k1=f(1.0)), rtol=1e-12, atol=1e-18)
+    seg.Q.k1 = f(-3.0)  # value
+    assert np.allclose(np.asarray(seg.track(beam).particles), reference(k1=f(-3.0)), rtol=1e-12, atol=1e-18)
+    seg.Q.tilt = f(0.4)  # predicate: any(tilt != 0) switches the rotation on
+    assert np.allclose(np.asarray(seg.track(beam).particles), reference(k1=f(-3.0), tilt=f(0.4)), rtol=1e-11, atol=1e-17)
+    seg.Q.misalignment = np.array([[1e-4, -2e-4]])
+    got = np.asarray(seg.track(beam).particles)
+    assert np.allclose(got, reference(k1=f(-3.0), tilt=f(0.4), misalignment=np.array([[1e-4, -2e-4]])), rtol=1e-11, atol=1e-17)
+    seg.Q.tilt = f(0.0)  # and off again
+    seg.Q.misalignment = np.zeros((1, 2))
+    assert np.allclose(np.asarray(seg.track(beam).particles), reference(k1=f(-3.0)), rtol=1e-12, atol=1e-18)
+    # structure: a cavity that is switched on becomes a step of its own
+    seg2 = lx.Segment([lx.Drift(f(0.5), dtype=np.float64), cav, lx.Drift(f(0.3), dtype=np.float64)])
+    cav.voltage = f(1e6)
+    on_first = np.asarray(seg2.track(beam).particles)
+    cav.voltage = f(2e6)
+    specs = [o.Drift(f(0.5)), o.Cavity(f(1.0), voltage=f(2e6), phase=f(0.0), frequency=f(1.3e9)), o.Drift(f(0.3))]
+    ref = o.segment_track(specs, o.particle_beam(P, f(6e6), np.float64), np.float64)
+    out = seg2.track(beam)
+    assert np.allclose(np.asarray(out.particles), ref["particles"], rtol=1e-9, atol=1e-15) and not np.allclose(on_first, ref["particles"])
+    assert np.allclose(out.energy, ref["energy"])
