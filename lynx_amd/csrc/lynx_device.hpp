@@ -272,6 +272,9 @@ __device__ __forceinline__ void apply_step(const T* M /*49 + coef*/, int step_ki
   T o[7];
 #pragma unroll
   for (int i = 0; i < 7; ++i) {
+    // float64: the map stays in LDS; fetch it row by row instead of letting the compiler hoist
+    // all 49 entries into 98 VGPRs (that alone cost one of the three waves per SIMD)
+    if (sizeof(T) == 8) LYNX_FORGET();
     T acc = z[0] * M[i * 7 + 0];
 #pragma unroll
     for (int j = 1; j < 7; ++j) acc = t_fma(z[j], M[i * 7 + j], acc);
