@@ -928,8 +928,19 @@ __global__ __launch_bounds__(1024) void k_finalize_moments(const double* __restr
   const double* src = partials + b * (int64_t)chunks * kPartialStride;
   if (g < kFinalGroups) {
     double v = 0.0;
-    if (j < 28 || j == 35)
-      for (int c = g; c < chunks; c += kFinalGroups) v += src[(int64_t)c * kPartialStride + j];
+    if (j < 28 || j == 35) {
+      // 8 independent loads in flight, added in chunk order (a B = 1 beam of 8 M particles has
+      // ~8000 chunks: one load per latency made this kernel as long as half the streaming pass)
+      int c = g;
+      for (; c + 7 * kFinalGroups < chunks; c += 8 * kFinalGroups) {
+        double t[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] = src[(int64_t)(c + q * kFinalGroups) * kPartialStride + j];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v += t[q];
+      }
+      for (; c < chunks; c += kFinalGroups) v += src[(int64_t)c * kPartialStride + j];
+    }
     s_g[g][j] = v;
   }
   __syncthreads();
