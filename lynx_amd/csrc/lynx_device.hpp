@@ -973,7 +973,15 @@ __global__ __launch_bounds__(64) void k_finalize_moments_small(const double* __r
       v = src[tid];
     } else {
       v = 0.0;
-      for (int c = 0; c < chunks; ++c) v += src[(int64_t)c * kPartialStride + tid];
+      int c = 0;
+      for (; c + 8 <= chunks; c += 8) {  // 8 loads in flight, added in chunk order
+        double t[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] = src[(int64_t)(c + q) * kPartialStride + tid];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v += t[q];
+      }
+      for (; c < chunks; ++c) v += src[(int64_t)c * kPartialStride + tid];
     }
     s[tid] = v;
   }
