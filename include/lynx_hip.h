@@ -97,6 +97,11 @@ typedef struct lynx_step {
  * (particle_beam.py:838-843) before a parameter scan; a beam broadcast lazily is read once
  * per sample out of the caches instead, which halves the HBM traffic of the pass. */
 #define LYNX_TRACK_SHARED_INPUT 4
+/* Apply every step on its own.  By default a run that is followed by an active cavity is applied
+ * together with it: one 7x7 application with T_cav . T_run (composed per sample, like the maps
+ * of a run are) plus the two rows of T_run that give the s and delta entering the cavity --
+ * the same algebra as segment.py:344-354 / cavity.py:113-161, rounded differently. */
+#define LYNX_TRACK_SEQUENTIAL_STEPS 8
 
 /* Layout of one sample's moment record (float64 regardless of the particle dtype):
  * [0..6] mean of the 7 coordinates, [7..27] upper triangle (row-major, i<=j<6) of the

@@ -30,7 +30,7 @@ FLAG_CAV_BETA, FLAG_CAV_GAIN, FLAG_CAV_T5XX = 8, 16, 32
 STEP_RUN, STEP_CAVITY = 0, 1
 STEP_FLAG_RAW = 64
 
-TRACK_MOMENTS, TRACK_TWO_KERNEL, TRACK_SHARED_INPUT = 1, 2, 4
+TRACK_MOMENTS, TRACK_TWO_KERNEL, TRACK_SHARED_INPUT, TRACK_SEQUENTIAL_STEPS = 1, 2, 4, 8
 
 
 class LynxError(RuntimeError):

@@ -17,3 +17,7 @@ std_ddof = int(os.environ.get("LYNX_STD_DDOF", "1"))
 # read it once per sample (LYNX_TRACK_SHARED_INPUT) instead of repeating it physically like
 # the reference does (particle_beam.py:838-843).  Same values and shapes either way.
 lazy_broadcast = os.environ.get("LYNX_LAZY_BROADCAST", "1") != "0"
+
+# A run that is followed by an active cavity is applied together with it (one 7x7 application with
+# T_cav . T_run per particle instead of two; LYNX_TRACK_SEQUENTIAL_STEPS when False).
+merge_steps = os.environ.get("LYNX_MERGE_STEPS", "1") != "0"

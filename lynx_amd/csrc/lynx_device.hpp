@@ -299,7 +299,12 @@ __device__ __forceinline__ lynx_f32x2 pk_fma(lynx_f32x2 a, float b, lynx_f32x2 c
 }
 
 __device__ __forceinline__ void apply_step_pair(const float* M /*49 + coef*/, int step_kind, int step_flags,
-                                                lynx_f32x2 (&z)[7]) {
+                                                lynx_f32x2 (&z)[7], bool merged = false,
+                                                lynx_f32x2 s_entry = lynx_f32x2{0.f, 0.f},
+                                                lynx_f32x2 d_entry = lynx_f32x2{0.f, 0.f}) {
+  // merged [run, cavity] pair: M = T_cav . T_run and the kick is driven by the s and delta that
+  // enter the cavity (s_entry, d_entry = rows 4 and 5 of T_run applied to z), see k_build
+  const lynx_f32x2 s_in = merged ? s_entry : z[4], d_in = merged ? d_entry : z[5];
   lynx_f32x2 o[7];
 #pragma unroll
   for (int i = 0; i < 7; ++i) {
@@ -310,7 +315,6 @@ __device__ __forceinline__ void apply_step_pair(const float* M /*49 + coef*/, in
   }
   if (step_kind == LYNX_STEP_CAVITY && (step_flags & LYNX_FLAG_CAV_GAIN)) {
     const float* coef = M + LYNX_COEF_OFFSET;
-    const lynx_f32x2 s_in = z[4], d_in = z[5];
     const lynx_f32x2 arg = -1.0f * s_in * coef[LYNX_C_BK] + coef[LYNX_C_PHI];
     const lynx_f32x2 ca = phase_cos<lynx_f32x2>(arg);
     o[5] = d_in * coef[LYNX_C_DSCALE] + coef[LYNX_C_DKICK] * (ca - coef[LYNX_C_COSPHI]);
@@ -319,6 +323,22 @@ __device__ __forceinline__ void apply_step_pair(const float* M /*49 + coef*/, in
   }
 #pragma unroll
   for (int i = 0; i < 7; ++i) z[i] = o[i];
+}
+
+// [run, cavity] pair in merged form: `pre` = rows 4 and 5 of the run's map, `M` = T_cav . T_run
+// with the cavity's coefficients.  One 7x7 application + two rows instead of two applications:
+//   z_cav_in[4], z_cav_in[5] = pre . z (merged_pair_entry);  o = M z;  kick from those two.
+// Same algebra as the two steps one after the other; the product is rounded once more in
+// k_build and once less per particle.
+__device__ __forceinline__ void merged_pair_entry(const float* pre /*14*/, const lynx_f32x2 (&z)[7],
+                                                  lynx_f32x2& s_in, lynx_f32x2& d_in) {
+  s_in = z[0] * pre[0];
+  d_in = z[0] * pre[7];
+#pragma unroll
+  for (int j = 1; j < 7; ++j) {
+    s_in = pk_fma(z[j], pre[j], s_in);
+    d_in = pk_fma(z[j], pre[7 + j], d_in);
+  }
 }
 
 // Whole program on one particle, step data read from LDS.
@@ -336,7 +356,8 @@ __device__ __forceinline__ void apply_program(const LatticeDev& lat, const T* s_
 template <typename T>
 __global__ __launch_bounds__(256) void k_build(LatticeDev lat, const T* __restrict__ energy_in,
                                                T* __restrict__ steps_out, T* __restrict__ energy_out,
-                                               const T* __restrict__ p_first, int64_t sample_stride) {
+                                               const T* __restrict__ p_first, int64_t sample_stride,
+                                               int merge_pairs) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* s_scratch = reinterpret_cast<T*>(smem_raw);
   T* s_steps = s_scratch + kBuildScratch;
@@ -356,6 +377,22 @@ __global__ __launch_bounds__(256) void k_build(LatticeDev lat, const T* __restri
     for (int i = 0; i < 7; ++i) s_steps[LYNX_SHIFT_OFFSET + i] = z[i];
   }
   __syncthreads();
+  if (merge_pairs) {
+    // [run, cavity] pairs for the streaming kernel: slot of the cavity <- T_cav . T_run (one
+    // 7x7 application per pair instead of two), slot of the run <- rows 4 and 5 of T_run, which
+    // give the s and delta that ENTER the cavity and drive its non-linear kick
+    for (int s = 1; s < lat.n_steps; ++s) {
+      if (lat.steps[s].kind != LYNX_STEP_CAVITY || lat.steps[s - 1].kind != LYNX_STEP_RUN) continue;  // uniform
+      T* run = s_steps + (s - 1) * LYNX_STEP_STRIDE;
+      T* cav = s_steps + s * LYNX_STEP_STRIDE;
+      T v = T(0);
+      if (threadIdx.x < 49) v = mat_product_entry<T>(cav, run, threadIdx.x);
+      __syncthreads();
+      if (threadIdx.x < 49) cav[threadIdx.x] = v;
+      if (threadIdx.x >= 64 && threadIdx.x < 78) run[threadIdx.x - 64] = run[28 + (threadIdx.x - 64)];
+      __syncthreads();
+    }
+  }
   T* dst = steps_out + b * (int64_t)lat.n_steps * LYNX_STEP_STRIDE;
   for (int i = threadIdx.x; i < lat.n_steps * LYNX_STEP_STRIDE; i += blockDim.x) dst[i] = s_steps[i];
   if (energy_out && threadIdx.x == 0) energy_out[b] = s_energy[lat.n_steps];
@@ -393,6 +430,7 @@ struct TrackArgs {
   int32_t lds_tile_scalars;  // size of the tile/scratch region in scalars
   int32_t interleave;    // direct kernel: 1 = a workgroup takes every `chunks`-th tile
   int64_t in_stride;     // scalars between the samples of p_in: N*7, or 0 for one shared incoming beam
+  int32_t merged_pairs;  // the step table holds [run, cavity] pairs in merged form (see k_build)
 };
 
 __device__ __forceinline__ float uniform_value(float v) {
@@ -767,7 +805,28 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_direct(
           for (int c = 0; c < 7; ++c) zp[u / 2][c] = lynx_f32x2{(float)z[u][c], (float)z[u + 1][c]};
       }
       for (int sidx = 0; sidx < S; ++sidx) {
-        const lynx_step st = lat.steps[sidx];
+        // merged [run, cavity] pair (see k_build): the run's slot holds the two rows that give the
+        // s and delta entering the cavity; they are formed first (their 14 scalars are dead before
+        // the 57 of the pair's map arrive: SGPRs are the scarce resource), then the loop moves on
+        // to the cavity's slot, which holds T_cav . T_run
+        bool merged = false;
+        lynx_f32x2 s_entry[kPairs ? UNROLL / 2 : 1], d_entry[kPairs ? UNROLL / 2 : 1];
+        lynx_step st = lat.steps[sidx];
+        if constexpr (kPairs && kScalarTable) {
+          if (a.merged_pairs && st.kind == LYNX_STEP_RUN && sidx + 1 < S &&
+              lat.steps[sidx + 1].kind == LYNX_STEP_CAVITY) {  // uniform
+            const float* tab = reinterpret_cast<const float*>(g_steps) + sidx * LYNX_STEP_STRIDE;
+            float pre[14];
+#pragma unroll
+            for (int q = 0; q < 14; ++q) pre[q] = uniform_value(tab[q]);
+#pragma unroll
+            for (int h = 0; h < UNROLL / 2; ++h) merged_pair_entry(pre, zp[h], s_entry[h], d_entry[h]);
+            merged = true;
+            ++sidx;
+            st = lat.steps[sidx];
+            LYNX_FORGET();
+          }
+        }
         if constexpr (kMapInRegs) {
           float m[57];
           if (kScalarTable) {
@@ -781,7 +840,8 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_direct(
           }
           if constexpr (kPairs) {
 #pragma unroll
-            for (int h = 0; h < UNROLL / 2; ++h) apply_step_pair(m, st.kind, st.flags, zp[h]);
+            for (int h = 0; h < UNROLL / 2; ++h)
+              apply_step_pair(m, st.kind, st.flags, zp[h], merged, s_entry[h], d_entry[h]);
           } else {
             float(&zf)[UNROLL][7] = reinterpret_cast<float(&)[UNROLL][7]>(z);
 #pragma unroll

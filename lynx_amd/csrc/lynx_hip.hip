@@ -424,12 +424,14 @@ static int allow_lds(lynx_ctx* ctx, K kernel, size_t bytes) {
 
 template <typename T>
 static int launch_build(lynx_ctx* ctx, lynx_lattice* lat, const void* d_energy_in, void* d_steps_out,
-                        void* d_energy_out, const void* d_p_first = nullptr, int64_t sample_stride = 0) {
+                        void* d_energy_out, const void* d_p_first = nullptr, int64_t sample_stride = 0,
+                        int merge_pairs = 0) {
   const size_t lds = ((size_t)kBuildScratch + (size_t)lat->n_steps * LYNX_STEP_STRIDE + lat->n_steps + 1) * sizeof(T);
   int rc = allow_lds(ctx, k_build<T>, lds);
   if (rc) return rc;
   hipLaunchKernelGGL(k_build<T>, dim3((unsigned)lat->batch), dim3(256), lds, ctx->stream, dev_view(lat),
-                     (const T*)d_energy_in, (T*)d_steps_out, (T*)d_energy_out, (const T*)d_p_first, sample_stride);
+                     (const T*)d_energy_in, (T*)d_steps_out, (T*)d_energy_out, (const T*)d_p_first, sample_stride,
+                     merge_pairs);
   HIP_TRY(ctx, hipGetLastError());
   return LYNX_OK;
 }
@@ -637,13 +639,21 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
   if (!fused) p = plan_track<T>(ctx, B, N, S, false, d_p_in, d_p_out, moments);
   const bool shared_in = (flags & LYNX_TRACK_SHARED_INPUT) != 0;
   p.a.in_stride = shared_in ? 0 : N * 7;
+  p.a.merged_pairs = 0;
   const void* d_steps = nullptr;
   int rc;
   if (S > 0 && !fused) {
     const size_t need = (size_t)B * S * LYNX_STEP_STRIDE * sizeof(T);
     if ((rc = ensure_scratch(ctx, &ctx->scratch_steps, &ctx->scratch_steps_bytes, need))) return rc;
+    // [run, cavity] pairs in merged form for the packed float32 step loop (one 7x7 application
+    // per pair); LYNX_TRACK_SEQUENTIAL_STEPS keeps every step on its own
+    bool has_pair = false;
+    for (int32_t s = 1; s < S; ++s)
+      has_pair |= lat->h_steps[s].kind == LYNX_STEP_CAVITY && lat->h_steps[s - 1].kind == LYNX_STEP_RUN;
+    p.a.merged_pairs = has_pair && p.direct && sizeof(T) == 4 && p.unroll % 2 == 0 &&
+                       !(flags & LYNX_TRACK_SEQUENTIAL_STEPS) && env_int("LYNX_MERGE_STEPS", 1);
     if ((rc = launch_build<T>(ctx, lat, d_energy_in, ctx->scratch_steps, d_energy_out, moments ? d_p_in : nullptr,
-                              p.a.in_stride)))
+                              p.a.in_stride, p.a.merged_pairs)))
       return rc;
     d_steps = ctx->scratch_steps;
   }
