@@ -117,3 +117,18 @@ def test_astra_reader_on_a_synthetic_distribution(tmp_path):
     assert np.isclose(beam.total_charge[0], charges.sum(), rtol=1e-5)
     pbeam = lx.ParticleBeam.from_astra(str(path))
     assert pbeam.particles.shape == (1, n - 1, 7) and np.all(pbeam.particles[..., 6] == 1)
+
+
+def test_reference_import_paths_exist(tmp_path):
+    """`lynx.converters.astra.from_astrabeam`, `lynx.latticejson.save/load_cheetah_model` by their names."""
+    import lynx_amd.latticejson as lj
+    from lynx_amd.converters.astra import from_astrabeam
+    from lynx_amd.io.astra import read_astra
+
+    assert from_astrabeam.__doc__ and read_astra is not None
+    f = lambda v: np.array([v], dtype=np.float32)  # noqa: E731
+    seg = lx.Segment([lx.Drift(f(0.5), name="D1"), lx.Quadrupole(f(0.2), k1=f(4.2), name="Q1")], name="cell")
+    path = str(tmp_path / "cell.json")
+    lj.save_cheetah_model(seg, path, title="t")
+    again = lj.load_cheetah_model(path)
+    assert [e.name for e in again.elements] == ["D1", "Q1"] and np.allclose(again.Q1.k1, 4.2)
