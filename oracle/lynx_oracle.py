@@ -611,6 +611,8 @@ def beam_moments(beam, ddof=1):
         pos = np.abs(gamma) > 0
         rb[pos] = np.sqrt(1 - 1 / gamma[pos] ** 2)
         out["relativistic_beta"] = rb
+        for pl in ("x", "y"):  # beam.py:272-275, 297-300
+            out["normalized_emittance_" + pl] = out["emittance_" + pl] * rb * gamma
     out["energy"] = beam["energy"]
     return out
 

@@ -430,3 +430,34 @@ def test_a_whole_ares_like_machine(lx, dtype):
     assert [type(e).__name__ for e in again.elements] == [type(e).__name__ for e in segment.elements]
     if dtype == np.float32:  # the file format is float32 (latticejson.py:129-138)
         assert np.array_equal(np.asarray(again.track(lx.ParticleBeam(P, energy)).particles), got)
+
+
+# -- try_batched.ipynb: what the notebook prints, reproduced by the product ---------------------------
+
+
+def test_printed_beam_properties_of_try_batched(lx):
+    """ParameterBeam.from_twiss properties (cells 1, 14-41), transformed_to (43), make_linspaced (46), Drift (50)."""
+    beam = lx.ParameterBeam.from_twiss(beta_x=f32(61.47503078, 99.0), alpha_x=f32(-1.21242463, -0.9),
+                                       emittance_x=f32(7.1971891e-13, 5e-13), beta_y=f32(35.41897281, 60.0),
+                                       alpha_y=f32(0.66554622, 0.5), emittance_y=f32(3.5866484e-15, 1e-15),
+                                       energy=f32(150e6, 14.6e9))
+    printed = dict(sigma_x=[6.6517e-06, 7.0356e-06], sigma_xp=[1.7005e-07, 9.5611e-08], sigma_y=[3.5642e-07, 2.4495e-07],
+                   sigma_yp=[1.2088e-08, 4.5644e-09], emittance_x=[7.1972e-13, 5.0000e-13], emittance_y=[3.5866e-15, 1.0000e-15],
+                   normalized_emittance_x=[2.1127e-10, 1.4286e-08], normalized_emittance_y=[1.0528e-12, 2.8571e-11],
+                   relativistic_gamma=[293.5427, 28571.4863], beta_x=[61.4750, 99.0000], alpha_x=[-1.2124, -0.9000],
+                   beta_y=[35.4190, 60.0000], alpha_y=[0.6655, 0.5000], sigma_xxp=[8.7260e-13, 4.5000e-13],
+                   sigma_yyp=[-2.3871e-15, -5.0000e-16])
+    for key, value in printed.items():
+        assert np.allclose(getattr(beam, key), value, rtol=1e-4), key
+    moved = beam.transformed_to(mu_x=f32(0.0, 1e-6), sigma_x=f32(175e-9, 42e-8))
+    assert np.allclose(moved.mu_x, [0.0, 1e-6]) and np.allclose(moved.sigma_x, [1.75e-07, 4.2e-07], rtol=1e-5)
+    assert np.allclose(moved.sigma_xp, printed["sigma_xp"], rtol=1e-4)
+    after = lx.Drift(length=f32(1.0, 2.0)).track(beam)
+    assert np.allclose(after.sigma_x, [6.7837e-06, 7.1650e-06], rtol=1e-4)
+    assert np.allclose(after.sigma_y, [3.4987e-07, 2.4100e-07], rtol=1e-4)
+    linspaced = lx.ParticleBeam.make_linspaced(num_particles=10, mu_x=f32(0.0, 1e-6), sigma_x=f32(175e-9, 42e-8))
+    assert linspaced.num_particles == 10
+    assert np.allclose(linspaced.mu_x, [0.0, 1e-6], atol=1e-12)
+    assert np.allclose(linspaced.sigma_x, [1.1774e-07, 2.8258e-07], rtol=1e-4)
+    assert np.allclose(linspaced.sigma_xp, [1.3456e-07, 1.3456e-07], rtol=1e-4)
+    assert np.allclose(linspaced.sigma_y, [1.1774e-07, 1.1774e-07], rtol=1e-4)

@@ -19,6 +19,14 @@ def test_kat1_parameter_beam_twiss_and_drift():
     assert np.allclose(m["sigma_x"], [6.6517e-06, 7.0356e-06], rtol=1e-4)
     assert np.allclose(m["sigma_xxp"], [8.7260e-13, 4.5e-13], rtol=1e-4)
     assert np.allclose(m["relativistic_gamma"], [293.5427, 28571.4863], rtol=1e-6)
+    # the rest of what the notebook prints for this beam (try_batched.ipynb cells 1, 14-41)
+    printed = dict(sigma_xp=[1.7005e-07, 9.5611e-08], sigma_y=[3.5642e-07, 2.4495e-07], sigma_yp=[1.2088e-08, 4.5644e-09],
+                   emittance_x=[7.1972e-13, 5.0000e-13], emittance_y=[3.5866e-15, 1.0000e-15],
+                   normalized_emittance_x=[2.1127e-10, 1.4286e-08], normalized_emittance_y=[1.0528e-12, 2.8571e-11],
+                   beta_x=[61.4750, 99.0000], alpha_x=[-1.2124, -0.9000], beta_y=[35.4190, 60.0000],
+                   alpha_y=[0.6655, 0.5000], sigma_yyp=[-2.3871e-15, -5.0000e-16], relativistic_beta=[1.0, 1.0])
+    for key, value in printed.items():
+        assert np.allclose(m[key], value, rtol=1e-4), key
     out = o.element_track(o.Drift(np.array([1.0, 2.0], dtype=np.float32)), b)
     m2 = o.beam_moments(out)
     assert np.allclose(m2["sigma_x"], [6.7837e-06, 7.1650e-06], rtol=1e-4)
