@@ -57,9 +57,18 @@ template <typename T> __device__ __forceinline__ T shfl_t(T v, int src) { return
 //
 // LDS scratch: kBuildChunk*49 (maps) + kBuildTree*49 (two ping-pong levels + running map).
 // ---------------------------------------------------------------------------------------
-constexpr int kBuildTreeB = kBuildChunk / 2 + 1;  // level buffers
-constexpr int kBuildTreeC = kBuildChunk / 4 + 1;
-constexpr int kBuildScratch = (kBuildChunk + kBuildTreeB + kBuildTreeC + 1) * 49;  // scalars
+// Scratch of a chunk of `c` elements: c maps + two tree levels (c/2+1, c/4+1) + the running map.
+// The ParameterBeam kernel sizes its chunk to the lattice (a 13-element lattice needs 4.9 KB
+// instead of 22.5 KB, so 4x as many of its one-wave workgroups fit a CU); k_build keeps the
+// full chunk (more resident 256-thread workgroups only slowed each other down: 135 -> 162 us
+// on BASELINE config 5).
+__host__ __device__ inline int build_chunk(int n_elems) {
+  return n_elems < kBuildChunk ? (n_elems > 1 ? n_elems : 1) : kBuildChunk;
+}
+__host__ __device__ inline int build_scratch_scalars(int chunk) {
+  return (chunk + (chunk / 2 + 1) + (chunk / 4 + 1) + 1) * 49;
+}
+constexpr int kBuildScratch = (kBuildChunk + (kBuildChunk / 2 + 1) + (kBuildChunk / 4 + 1) + 1) * 49;  // full chunk
 
 template <typename T>
 __device__ __forceinline__ T mat_product_entry(const T* A, const T* Bm, int ij) {
@@ -73,14 +82,15 @@ __device__ __forceinline__ T mat_product_entry(const T* A, const T* Bm, int ij) 
 
 template <typename T>
 __device__ void build_compose_sample(const LatticeDev& lat, int64_t b, T energy_in, T* s_steps,
-                                     T* s_energy, T* s_scratch /* kBuildScratch */) {
+                                     T* s_energy, T* s_scratch /* build_scratch_scalars(chunk) */,
+                                     int chunk = kBuildChunk) {
   const int tid = threadIdx.x;
   const int E = lat.n_elems, S = lat.n_steps;
   const T* pool = static_cast<const T*>(lat.pool);
   T* bufA = s_scratch;
-  T* bufB = bufA + kBuildChunk * 49;
-  T* bufC = bufB + kBuildTreeB * 49;
-  T* carry = bufC + kBuildTreeC * 49;
+  T* bufB = bufA + chunk * 49;
+  T* bufC = bufB + (chunk / 2 + 1) * 49;
+  T* carry = bufC + (chunk / 4 + 1) * 49;
   const int per_round = blockDim.x / 49;  // products per round
   const int my_prod = tid / 49, my_ij = tid - my_prod * 49;
 
@@ -102,8 +112,8 @@ __device__ void build_compose_sample(const LatticeDev& lat, int64_t b, T energy_
   __syncthreads();
 
   int s_cur = 0;  // first step that may intersect the current chunk (uniform)
-  for (int e0 = 0; e0 < E; e0 += kBuildChunk) {
-    const int ne = (E - e0) < kBuildChunk ? (E - e0) : kBuildChunk;
+  for (int e0 = 0; e0 < E; e0 += chunk) {
+    const int ne = (E - e0) < chunk ? (E - e0) : chunk;
     // phase 1
     for (int t = tid; t < ne; t += blockDim.x) {
       const int e = e0 + t;
@@ -1061,7 +1071,8 @@ __global__ __launch_bounds__(256) void k_track_moments(LatticeDev lat, const T* 
                                                        T* cov_out, T* __restrict__ energy_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* s_scratch = reinterpret_cast<T*>(smem_raw);
-  T* s_steps = s_scratch + kBuildScratch;
+  const int chunk = build_chunk(lat.n_elems);
+  T* s_steps = s_scratch + build_scratch_scalars(chunk);
   T* s_energy = s_steps + (size_t)lat.n_steps * LYNX_STEP_STRIDE;
   T* s_mu = s_energy + lat.n_steps + 1;  // 8
   T* s_cov = s_mu + 8;                   // 49
@@ -1070,7 +1081,7 @@ __global__ __launch_bounds__(256) void k_track_moments(LatticeDev lat, const T* 
 
   const int64_t b = blockIdx.x;
   const int lane = threadIdx.x;
-  build_compose_sample<T>(lat, b, energy_in[b], s_steps, s_energy, s_scratch);
+  build_compose_sample<T>(lat, b, energy_in[b], s_steps, s_energy, s_scratch, chunk);
 
   if (lane < 7) s_mu[lane] = mu_in[b * 7 + lane];
   if (lane < 49) s_cov[lane] = cov_in[b * 49 + lane];

@@ -847,7 +847,7 @@ template <typename T>
 static int launch_track_moments(lynx_ctx* ctx, lynx_lattice* lat, const void* d_energy_in, const void* d_mu_in,
                                 const void* d_cov_in, void* d_mu_out, void* d_cov_out, void* d_energy_out) {
   const size_t lds =
-      ((size_t)kBuildScratch + (size_t)lat->n_steps * LYNX_STEP_STRIDE + lat->n_steps + 1 + 8 + 49 + 49 + 16) * sizeof(T);
+      ((size_t)build_scratch_scalars(build_chunk(lat->n_elems)) + (size_t)lat->n_steps * LYNX_STEP_STRIDE + lat->n_steps + 1 + 8 + 49 + 49 + 16) * sizeof(T);
   int rc = allow_lds(ctx, k_track_moments<T>, lds);
   if (rc) return rc;
   const unsigned threads = lat->batch <= 4096 ? 256u : 64u;
