@@ -54,3 +54,13 @@ def pytest_collection_modifyitems(config, items):
     if any("gpu" in item.keywords for item in items) and config.getoption("-m") == "gpu":
         if _gpu_count() == 0:
             raise pytest.UsageError("-m gpu requested but liblynxhip sees no GPU (or is not built)")
+
+
+# hypothesis: the same examples on every run (no flaky discoveries in CI), no per-example deadline
+try:
+    from hypothesis import settings as _hyp_settings
+
+    _hyp_settings.register_profile("lynx", derandomize=True, deadline=None)
+    _hyp_settings.load_profile("lynx")
+except ImportError:  # pragma: no cover
+    pass
