@@ -318,7 +318,9 @@ def main():
         kern_s = kern_ms / 1e3 / max(launches, 1)
         achieved = alg_bytes / kern_s / 1e9 if launches else None
         result = {
-            "metric": "particle-element-steps/sec (whole node), Segment.track ParticleBeam",
+            # BASELINE.json's metric, verbatim; `value` is its first half (whole-node steps/s), the
+            # achieved HBM GB/s is `roofline.achieved` (kernel) and `hbm_gbs_whole_step` (wall clock)
+            "metric": "particle-element-steps/sec (whole node) + achieved HBM GB/s, Segment.track ParticleBeam",
             "value": steps_per_pass * args.steps / elapsed,
             "unit": "particle-element-steps/s",
             "n_gpus": world,
