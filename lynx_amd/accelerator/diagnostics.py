@@ -256,14 +256,14 @@ class Screen(Element):
                 mu = np.array(incoming._mu)
                 mu[..., 0] -= mis[..., 0]
                 mu[..., 2] -= mis[..., 1]
-                copy._mu_d = Dual(mu)
+                copy._mu_d = Dual(mu, owned=True)
             else:
                 # the reference subtracts the y misalignment from coordinate 1 (x'), not from
                 # y (screen.py:134-135); kept as it is
                 host = np.array(incoming.particles)
                 host[..., 0] -= mis[..., None, 0]
                 host[..., 1] -= mis[..., None, 1]
-                copy._particles = Dual(host)
+                copy._particles = Dual(host, owned=True)
                 copy._batch = None
                 copy._moments = None
         self.set_read_beam(copy)

@@ -22,6 +22,7 @@ from typing import Optional
 import numpy as np
 
 from .. import _ffi, engine
+from ..device import frozen
 
 _anonymous = itertools.count()
 
@@ -75,7 +76,11 @@ class Element:
         self.name = name if name is not None else generate_unique_name()
 
     def __setattr__(self, key, value):
-        # every parameter change invalidates the packed lattice programs this element is in
+        # every parameter change invalidates the packed lattice programs this element is in;
+        # arrays are kept as private read-only copies, so that an in-place write (`quad.k1[0] = 5`),
+        # which no version counter could see, raises instead of leaving a stale device copy behind
+        if isinstance(value, np.ndarray) and not key.startswith("_"):
+            value = frozen(value)
         object.__setattr__(self, key, value)
         if not key.startswith("_"):
             object.__setattr__(self, "_version", self._version + 1)
@@ -153,7 +158,8 @@ class Element:
         for attr, tail in (("length", 0), *self._batched):
             if attr in self._kept_on_broadcast:
                 continue
-            object.__setattr__(twin, attr, _rep(getattr(self, attr), (*shape, *((1,) if tail else ()))))
+            object.__setattr__(twin, attr, frozen(_rep(getattr(self, attr), (*shape, *((1,) if tail else ()))),
+                                                  copy=False))
         return twin
 
     @property

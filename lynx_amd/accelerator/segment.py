@@ -6,6 +6,7 @@ barriers (active BPMs); plotting and the file-format constructors are out of sco
 
 from __future__ import annotations
 
+import itertools
 from typing import Optional
 
 import numpy as np
@@ -27,16 +28,20 @@ class Segment(Element):
     def __init__(self, elements: list, name: Optional[str] = None) -> None:
         super().__init__(name=name)
         object.__setattr__(self, "elements", list(elements))
-        for element in self.elements:
-            # Elements are reachable as attributes by name; duplicates become a list
-            # (segment.py:45-54).
-            if element.name in self.__dict__:
-                if isinstance(self.__dict__[element.name], list):
-                    self.__dict__[element.name].append(element)
-                else:
-                    self.__dict__[element.name] = [self.__dict__[element.name], element]
-            else:
-                self.__dict__[element.name] = element
+        # name -> elements carrying it, in lattice order; `segment.<name>` resolves through
+        # `__getattr__` to the element, or to the list of them when the name is not unique
+        # (behaviour of segment.py:45-54)
+        index: dict = {}
+        for member in self.elements:
+            index.setdefault(member.name, []).append(member)
+        object.__setattr__(self, "_by_name", index)
+
+    def __getattr__(self, key):
+        # only reached when normal lookup fails: properties and methods of the class win
+        found = self.__dict__.get("_by_name", {}).get(key)
+        if found is None:
+            raise AttributeError(f"{type(self).__name__!r} object has no attribute {key!r}")
+        return found[0] if len(found) == 1 else found
 
     def __setattr__(self, key, value):
         object.__setattr__(self, key, value)
@@ -48,56 +53,48 @@ class Segment(Element):
         return sum(e._version for e in self.elements)
 
     def subcell(self, start: str, end: str) -> "Segment":
-        """Extract a subcell `[start, end]` from this segment (segment.py:56-68)."""
-        subcell = []
-        is_in_subcell = False
-        for element in self.elements:
-            if element.name == start:
-                is_in_subcell = True
-            if is_in_subcell:
-                subcell.append(element)
-            if element.name == end:
-                break
-        return self.__class__(subcell)
+        """
+        The stretch from the first element named `start` through the first element named `end`
+        (behaviour of segment.py:56-68: the scan stops at the first `end` wherever it is, so an
+        `end` in front of `start` gives an empty segment; a missing `end` runs to the last element).
+        """
+        names = [member.name for member in self.elements]
+        stop = names.index(end) if end in names else len(names) - 1
+        if start not in names[: stop + 1]:
+            return self.__class__([])
+        return self.__class__(self.elements[names.index(start): stop + 1])
+
+    def _leaves(self):
+        """Non-segment elements in lattice order, nested segments opened up."""
+        for member in self.elements:
+            if isinstance(member, Segment):
+                yield from member._leaves()
+            else:
+                yield member
 
     def flattened(self) -> "Segment":
-        """All sub-segments resolved into one top-level segment (segment.py:70-82)."""
-        flattened_elements = []
-        for element in self.elements:
-            if isinstance(element, Segment):
-                flattened_elements += element.flattened().elements
-            else:
-                flattened_elements.append(element)
-        return Segment(elements=flattened_elements, name=self.name)
+        """All sub-segments resolved into one top-level segment (behaviour of segment.py:70-82)."""
+        return Segment(elements=list(self._leaves()), name=self.name)
 
     def transfer_maps_merged(self, incoming_beam, except_for: Optional[list] = None) -> "Segment":
         """
-        Segment where runs of skippable elements are merged into `CustomTransferMap`s
-        (segment.py:84-132).  The beam is tracked along to know the energy at each run.
+        Every maximal stretch of skippable elements not named in `except_for` replaced by one
+        `CustomTransferMap` (behaviour of segment.py:84-132).  The beam is carried along only for
+        its energy at each stretch.  As in the reference a one-element stretch stays what it is,
+        except at the very end of the lattice, where it is wrapped too.
         """
-        if except_for is None:
-            except_for = []
-        merged_elements = []
-        skippable_elements = []
-        tracked_beam = incoming_beam
-        for element in self.elements:
-            if element.is_skippable and element.name not in except_for:
-                skippable_elements.append(element)
-            else:
-                if len(skippable_elements) == 1:
-                    merged_elements.append(skippable_elements[0])
-                    tracked_beam = skippable_elements[0].track(tracked_beam)
-                elif len(skippable_elements) > 1:
-                    merged_elements.append(
-                        CustomTransferMap.from_merging_elements(skippable_elements, incoming_beam=tracked_beam))
-                    tracked_beam = merged_elements[-1].track(tracked_beam)
-                skippable_elements = []
-                merged_elements.append(element)
-                tracked_beam = element.track(tracked_beam)
-        if len(skippable_elements) > 0:
-            merged_elements.append(
-                CustomTransferMap.from_merging_elements(skippable_elements, incoming_beam=tracked_beam))
-        return Segment(elements=merged_elements, name=self.name)
+        protected = set(except_for or ())
+        groups = [(mergeable, list(members)) for mergeable, members in itertools.groupby(
+            self.elements, key=lambda el: el.is_skippable and el.name not in protected)]
+        out, beam = [], incoming_beam
+        for position, (mergeable, members) in enumerate(groups):
+            if mergeable and (len(members) > 1 or position == len(groups) - 1):
+                members = [CustomTransferMap.from_merging_elements(members, incoming_beam=beam)]
+            out.extend(members)
+            if not mergeable or position < len(groups) - 1:  # a merged tail has nothing downstream
+                for member in members:
+                    beam = member.track(beam)
+        return Segment(elements=out, name=self.name)
 
     def without_inactive_markers(self, except_for: Optional[list] = None) -> "Segment":
         """segment.py:134-159 (removes every Marker not named in `except_for`)."""

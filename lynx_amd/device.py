@@ -36,8 +36,12 @@ class Runtime:
             device = int(os.environ.get("LYNX_DEVICE", os.environ.get("LOCAL_RANK", "0")))
             count = C.c_int(0)
             self.lib.lynx_device_count(C.byref(count))
-            if count.value > 0:
-                device %= count.value
+            if 0 < count.value <= device and os.environ.get("LYNX_ALLOW_GPU_SHARING") == "1":
+                device %= count.value  # rehearsals on a box with fewer GPUs than ranks (no RCCL there)
+            elif 0 < count.value <= device:
+                raise _ffi.LynxError(
+                    f"rank-local device ordinal {device} but only {count.value} GPU(s) visible: one process "
+                    "drives one GPU (set LYNX_DEVICE, or LYNX_ALLOW_GPU_SHARING=1 for a rehearsal)")
         handle = C.c_void_p()
         _ffi.check(self.lib.lynx_ctx_create(int(device), C.byref(handle)))
         self.ctx = handle
@@ -179,6 +183,15 @@ class DeviceArray:
         return f"DeviceArray(shape={self.shape}, dtype={self.dtype}, device={self.rt.device})"
 
 
+def frozen(value, copy: bool = True) -> np.ndarray:
+    """`value` as a read-only ndarray; a writable input is copied first unless `copy` is False."""
+    arr = np.asarray(value)
+    if arr.flags.writeable:
+        arr = arr.copy() if copy else arr.view()
+        arr.setflags(write=False)
+    return arr
+
+
 def as_host(x) -> np.ndarray:
     """NumPy view/copy of a host array, DeviceArray or sequence."""
     if isinstance(x, DeviceArray):
@@ -193,9 +206,15 @@ class Dual:
     back when somebody looks at it.
     """
 
-    def __init__(self, host=None, dev: DeviceArray | None = None):
+    def __init__(self, host=None, dev: DeviceArray | None = None, owned: bool = False):
+        """
+        The host side is kept READ-ONLY and, unless `owned`, as a private copy: the device copy and
+        everything derived from it (moment records, packed lattices) is cached, so an in-place
+        write -- through the array handed out by a property or through the caller's original --
+        would otherwise be silently ignored.  It raises instead; assign a new array.
+        """
         assert host is not None or dev is not None
-        self._host = None if host is None else np.asarray(host)
+        self._host = None if host is None else frozen(host, copy=not owned)
         self._dev = dev
         self._bcast = {}
 
@@ -213,7 +232,7 @@ class Dual:
 
     def host(self) -> np.ndarray:
         if self._host is None:
-            self._host = self._dev.numpy()
+            self._host = frozen(self._dev.numpy(), copy=False)
         return self._host
 
     def device(self, rt: Runtime | None = None) -> DeviceArray:

@@ -114,4 +114,7 @@ class RcclCommunicator:
         return out
 
     def close(self):
-        self.rt.lib.lynx_comm_destroy(self.rt.ctx)
+        """Destroy the communicator (collective: every rank calls it).  No-op once the runtime is closed."""
+        if not self.rt.closed and not getattr(self, "_closed", False):
+            self._closed = True
+            self.rt.check(self.rt.lib.lynx_comm_destroy(self.rt.ctx))

@@ -213,7 +213,7 @@ class ParticleBeam(Beam):
         host = np.array(beam._particles.host())
         xyz = xyz.reshape(*shape, n, 3)
         host[..., 0], host[..., 2], host[..., 4] = xyz[..., 0], xyz[..., 1], xyz[..., 2]
-        beam._particles = Dual(host)
+        beam._particles = Dual(host, owned=True)
         return beam
 
     @classmethod
@@ -329,7 +329,7 @@ class ParticleBeam(Beam):
     def _set_coordinate(self, c: int, value):
         host = np.array(self.particles)  # a shared beam becomes a physical one when written to
         host[..., c] = value
-        self._particles = Dual(host)
+        self._particles = Dual(host, owned=True)
         self._batch = None
         if self._charges is not None:
             self._charges = np.ascontiguousarray(np.broadcast_to(self._charges, host.shape[:-1]))

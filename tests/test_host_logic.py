@@ -290,3 +290,81 @@ def test_header_is_plain_c(tmp_path, built_library):
                     "-o", str(exe)], check=True)
     done = subprocess.run([str(exe)], capture_output=True, text=True)
     assert done.returncode == 0 and done.stdout.startswith("lynx"), (done.returncode, done.stdout, done.stderr)
+
+
+# ---------------------------------------------------------------------------------------------
+# cached device state cannot go stale behind the caller's back
+# ---------------------------------------------------------------------------------------------
+
+
+def test_element_parameters_are_private_read_only_copies():
+    """`quad.k1[0] = 5` cannot be seen by any version counter: it must raise, and the caller's
+    own array must not be aliased (the reference recomputes from live tensors on every call)."""
+    k1 = np.array([4.2, -4.2], dtype=np.float32)
+    quad = lx.Quadrupole(np.array([0.2, 0.2], dtype=np.float32), k1=k1)
+    with pytest.raises(ValueError, match="read-only"):
+        quad.k1[0] = 5.0
+    with pytest.raises(ValueError, match="read-only"):
+        quad.misalignment[..., 0] += 1e-3
+    k1[0] = 9.0  # the caller's array is theirs
+    assert quad.k1[0] == np.float32(4.2)
+    version = quad._version
+    quad.k1 = k1  # assignment is the supported way and is seen
+    assert quad._version == version + 1 and quad.k1[0] == np.float32(9.0)
+    assert not quad.broadcast((3,)).k1.flags.writeable
+
+
+def test_beam_arrays_are_private_read_only_copies():
+    P = np.zeros((1, 4, 7), dtype=np.float32)
+    P[..., 6] = 1
+    beam = lx.ParticleBeam(P, np.array([1e8], dtype=np.float32))
+    with pytest.raises(ValueError, match="read-only"):
+        beam.particles[..., 0] -= 1e-3
+    P[0, 0, 0] = 7.0
+    assert np.asarray(beam.particles)[0, 0, 0] == 0.0
+    pb = lx.ParameterBeam.from_parameters()
+    with pytest.raises(ValueError, match="read-only"):
+        pb._mu[..., 0] = 1.0
+    with pytest.raises(ValueError, match="read-only"):
+        pb.energy[0] = 1.0
+
+
+def test_rank_local_device_beyond_the_visible_gpus_is_an_error(built_library, monkeypatch):
+    """Two ranks on one GPU is how round 1's N=2 rehearsal ended in `ncclCommInitRank: invalid usage`."""
+    from lynx_amd import device
+
+    n = ctypes.c_int(0)
+    _ffi.load().lynx_device_count(ctypes.byref(n))
+    monkeypatch.setenv("LYNX_DEVICE", str(max(n.value, 1) + 3))
+    monkeypatch.delenv("LYNX_ALLOW_GPU_SHARING", raising=False)
+    with pytest.raises(_ffi.LynxError, match="GPU|device"):
+        device.Runtime()
+
+
+def test_objects_that_outlive_a_closed_runtime_are_dropped_quietly(built_library):
+    """
+    Round 1's `pytest exit 139` (gpurun_out/pytest1.log): `PackedLattice.__del__` and array
+    finalizers ran at interpreter shutdown AFTER the context had been destroyed and called
+    `lynx_lattice_destroy` / `lynx_buf_free` on freed memory.  Since then a closed runtime turns
+    every later release into a no-op; this pins it without a GPU (no C entry point may be
+    reached once `closed` is set -- the stand-in library raises if one is).
+    """
+    from lynx_amd import device, parallel
+
+    class Tripwire:
+        def __getattr__(self, name):
+            raise AssertionError(f"{name} called on a closed runtime")
+
+    rt = device.Runtime.__new__(device.Runtime)
+    rt.lib, rt.ctx, rt.device, rt.closed = Tripwire(), ctypes.c_void_p(1), 0, True
+    arr = device.DeviceArray.__new__(device.DeviceArray)
+    arr.rt, arr.ptr = rt, 1234
+    rt.free(arr.ptr)  # what the array's weakref finalizer calls
+    lat = engine.PackedLattice.__new__(engine.PackedLattice)
+    lat.handle, lat.rt = ctypes.c_void_p(99), rt
+    lat.release()
+    assert lat.handle is None
+    comm = parallel.RcclCommunicator.__new__(parallel.RcclCommunicator)
+    comm.rt = rt
+    comm.close()
+    rt.close()  # idempotent
