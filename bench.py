@@ -11,6 +11,12 @@ composes every sample's element maps, the launch that streams the particles thro
 all-gather of the per-sample moment records.
 Particles, lattice parameters and outputs are resident in HBM when the timed region starts.
 
+N > 1: one process per GPU (torchrun only LAUNCHES them: RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* from the environment); rendezvous, barriers and the max over ranks go over
+`lynx_amd.rendezvous` (standard-library sockets) and the data exchange over RCCL -- the process
+never imports torch.  If the RCCL communicator cannot be built the run prints a line with
+`"value": null` and exits 3 (`--allow-host-gather` turns that into a host gather that says so).
+
 Workload (default `c4`): BASELINE.json config 4, the configuration the metric's target is
 quoted on ("1024-batch x 100k-particle x 128-element lattice"): 1024 lattice-parameter
 samples (k1 scan) x 128-element FODO x 100 000 particles, fp32 -- 5.73 GB of algorithmic
@@ -79,32 +85,81 @@ def build_segment(lx, name, batch, cells, dtype, rank, world):
     return lx.Segment(elements)
 
 
-def cpu_baseline(name, particles, cells, dtype, budget_s=12.0):
-    """The oracle (NumPy restatement of the reference algorithm) on a bounded sample, 1 thread."""
+def host_cores() -> int:
+    """CPUs this process may really use: scheduler affinity capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: (t.strip(), None))):
+        try:
+            quota, period = parse(Path(path).read_text())
+            if period is None:
+                period = Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text().strip()
+            if quota not in ("max", "-1"):
+                n = min(n, max(1, int(int(quota) / int(period))))
+            break
+        except (OSError, ValueError):
+            continue
+    return max(1, n)
+
+
+def _cpu_sample(name, particles, cells, dtype, bs, seed):
     from oracle import lynx_oracle as o
 
-    try:
-        from threadpoolctl import threadpool_limits
-    except Exception:  # pragma: no cover
-        threadpool_limits = None
-    if name == "c5":
-        return None
-    bs = 8 if name == "c4" else 1
     n = particles if name != "c3big" else 1_000_000
     if name == "c2":
         specs = o.ares_like_segment(dtype, (bs,))
     else:
         scale = 0.5 + np.arange(bs) / max(bs - 1, 1) if bs > 1 else None
         specs = o.fodo_segment(cells, np.dtype(dtype).type, (bs,), scale)
-    P = o.gaussian_particles((bs,), n, seed=2, dtype=dtype, sigma=[1e-4, 1e-5, 1e-4, 1e-5, 1e-5, 1e-3])
+    P = o.gaussian_particles((bs,), n, seed=seed, dtype=dtype, sigma=[1e-4, 1e-5, 1e-4, 1e-5, 1e-5, 1e-3])
     beam = o.particle_beam(P, np.full((bs,), 1e8, dtype=dtype), dtype)
-    E = len(specs)
 
     def run():
-        out = o.segment_track(specs, beam, dtype)
-        o.beam_moments(out)
+        o.beam_moments(o.segment_track(specs, beam, dtype))
 
-    ctx = threadpool_limits(limits=1) if threadpool_limits else None
+    return run, bs * n * len(specs), len(specs), n
+
+
+def _cpu_worker(job):
+    """One process of the all-cores leg: its own samples, one BLAS thread, until the deadline."""
+    name, particles, cells, dtype, bs, seed, t_start, t_stop = job
+    try:
+        from threadpoolctl import threadpool_limits
+
+        threadpool_limits(limits=1)
+    except Exception:  # pragma: no cover
+        pass
+    run, steps_per_pass, _, _ = _cpu_sample(name, particles, cells, dtype, bs, seed)
+    run()
+    while time.time() < t_start:
+        time.sleep(0.01)
+    reps = 0
+    while True:
+        run()
+        reps += 1
+        if time.time() > t_stop:
+            return reps * steps_per_pass, time.time()
+
+
+def cpu_baseline(name, particles, cells, dtype, budget_s=10.0):
+    """
+    The oracle (NumPy restatement of the reference algorithm: per-sample composition, then one
+    `matmul(P, T^T)` and the moment read-out) on a bounded sample of the workload, timed on this box's
+    host cores: one thread, and one single-threaded process per usable core (north_star: "the
+    reference's own CPU path timed on the host cores of the same box, core count stated").  Must be
+    called BEFORE the process touches the GPU (the all-cores leg forks).
+    """
+    import multiprocessing as mp
+
+    if name == "c5":
+        return None
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:  # pragma: no cover
+        threadpool_limits = None
+    bs = 8 if name == "c4" else 1
+    run, steps_per_pass, E, n = _cpu_sample(name, particles, cells, dtype, bs, 2)
+    limiter = threadpool_limits(limits=1) if threadpool_limits else None
     try:
         run()
         reps, t0 = 0, time.perf_counter()
@@ -115,12 +170,56 @@ def cpu_baseline(name, particles, cells, dtype, budget_s=12.0):
             if dt > budget_s or reps >= 2000:
                 break
     finally:
-        if ctx is not None:
-            ctx.unregister() if hasattr(ctx, "unregister") else None
-    steps = bs * n * E * reps
-    return {"value": steps / dt, "unit": "particle-element-steps/s", "cores": 1, "kind": "port",
-            "sample": f"oracle (NumPy restatement) on {bs} samples x {n} particles x {E} elements, "
-                      f"{reps} passes in {dt:.1f} s, 1 thread of {os.cpu_count()} host cores"}
+        if limiter is not None:
+            limiter.restore_original_limits()
+    one = steps_per_pass * reps / dt
+
+    cores = min(host_cores(), 64)
+    per_worker = 2 if name == "c4" else 1
+    t_start = time.time() + 3.0 + 0.05 * cores  # every worker has built its sample by then
+    jobs = [(name, particles, cells, dtype, per_worker, 100 + w, t_start, t_start + budget_s) for w in range(cores)]
+    with mp.get_context("fork").Pool(cores) as pool:
+        done = pool.map(_cpu_worker, jobs, chunksize=1)
+    total = sum(d[0] for d in done)
+    wall = max(d[1] for d in done) - t_start
+    return {"value": total / wall, "unit": "particle-element-steps/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (NumPy restatement of the reference's algorithm) on {cores} processes x {per_worker} "
+                      f"samples x {n} particles x {E} elements, one BLAS thread each, {wall:.1f} s "
+                      f"({os.cpu_count()} logical CPUs on the host, {host_cores()} usable by this job)",
+            "one_thread": {"value": one, "cores": 1,
+                           "sample": f"{bs} samples x {n} particles x {E} elements, {reps} passes in {dt:.1f} s"}}
+
+
+METRIC = "particle-element-steps/sec (whole node) + achieved HBM GB/s, Segment.track ParticleBeam"
+
+
+def bring_up_rccl(rt, rdzv, rank, world, timeout_s):
+    """
+    -> (communicator or None, reason or None, stuck).
+    RCCL communicator over the ranks of this launch, or the reason there is none.  The unique id
+    travels over the rendezvous sockets; the blocking `ncclCommInitRank` runs under a watchdog.
+    A bring-up that does not RETURN leaves a thread inside RCCL on this context: nothing may be
+    launched on it any more, so the caller must end the process (non-zero) in that case.
+    """
+    import threading
+
+    from lynx_amd.parallel import RcclCommunicator, rccl_unique_id
+
+    uid = rdzv.broadcast(rccl_unique_id(rt) if rank == 0 else None)
+    attempt: dict = {}
+
+    def work():
+        try:
+            attempt["comm"] = RcclCommunicator(world, rank, lambda _: uid, rt)
+        except Exception as exc:  # noqa: BLE001
+            attempt["error"] = f"{type(exc).__name__}: {exc}"
+
+    worker = threading.Thread(target=work, daemon=True)
+    worker.start()
+    worker.join(timeout=timeout_s)
+    if worker.is_alive():
+        return None, f"ncclCommInitRank did not return within {timeout_s:.0f} s", True
+    return attempt.get("comm"), attempt.get("error"), False
 
 
 def main():
@@ -138,6 +237,11 @@ def main():
                          "one physical beam per sample; reported with its own algorithmic bytes, never the default")
     ap.add_argument("--grad", action="store_true",
                     help="step = forward + reverse pass (gradient of sum of var(x) w.r.t. every element parameter)")
+    ap.add_argument("--allow-host-gather", action="store_true",
+                    help="N > 1 only: if the RCCL communicator cannot be built, gather the moment records through the "
+                         "rendezvous sockets instead of failing (config.gather says so); without it the run exits 3")
+    ap.add_argument("--sync-every-step", action="store_true",
+                    help="latency mode: wait for the GPU after every step (no overlap between consecutive calls)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -145,21 +249,22 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         sys.exit(f"--gpus {args.gpus} needs torchrun with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
 
-    dist = None
-    if world > 1:
-        import torch.distributed as dist  # plumbing only: rendezvous, barrier, max over ranks
-
-        dist.init_process_group("gloo")
-
-    import lynx_amd as lx
-    from lynx_amd.device import get_runtime
-    from lynx_amd.parallel import RcclCommunicator
-
-    rt = get_runtime()
     batch, particles, cells, dtype, descr = WORKLOADS[args.workload]
     batch = args.batch or batch
     particles = args.particles or particles
     dtype = np.dtype(dtype).type
+
+    # CPU baseline first: it forks worker processes, which must happen before this process opens the GPU
+    baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        baseline = cpu_baseline(args.workload, particles, cells, dtype)
+
+    import lynx_amd as lx
+    from lynx_amd.device import get_runtime
+    from lynx_amd.rendezvous import Rendezvous
+
+    rdzv = Rendezvous(rank, world)  # standard-library sockets; no second communication stack in the process
+    rt = get_runtime()
     lx.config.fused_moments = not args.no_moments
 
     segment = build_segment(lx, args.workload, batch, cells, dtype, rank, world)
@@ -171,54 +276,49 @@ def main():
         beam = beam.broadcast((batch,))
         assert beam.is_shared
 
-    comm, gather_kind, abandon_comm = None, "none", False
+    config = {"workload": f"{args.workload}: {descr}", "batch_per_gpu": batch, "global_batch": batch * world,
+              "particles": particles, "elements": n_elements, "fused_moments": not args.no_moments,
+              "reverse_pass": bool(args.grad),
+              "incoming_beam": "one beam shared by the batch (lazy broadcast)" if args.shared_input else "one physical beam per sample",
+              "gather": "none", "parallelism": f"{'particle' if batch == 1 else 'batch'}-sharded x{world}",
+              "pipelined_calls": not args.sync_every_step}
+
+    def finish(code):
+        """Ordinary end of the process; the hard exit is only for a thread stuck inside RCCL."""
+        rdzv.close()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        if code == "stuck":
+            os._exit(3)
+        sys.exit(code)
+
+    comm = None
     force_comm = os.environ.get("LYNX_FORCE_COMM") == "1"  # exercise the RCCL path at world_size 1
     if world > 1 or force_comm:
-        def exchange(uid):
-            if dist is None:
-                return uid
-            box = [uid]
-            dist.broadcast_object_list(box, src=0)
-            return box[0]
-
-        # The id travels over gloo on this thread; the blocking ncclCommInitRank runs under a
-        # watchdog, so that a communicator that cannot be brought up (error or no answer within
-        # LYNX_COMM_TIMEOUT_S) costs the transport, not the run.
-        import threading
-
-        from lynx_amd.parallel import rccl_unique_id
-
-        uid = exchange(rccl_unique_id(rt) if rank == 0 else None)
-        attempt: dict = {}
-
-        def bring_up():
-            try:
-                attempt["comm"] = RcclCommunicator(world, rank, lambda _: uid, rt)
-            except Exception as exc:
-                attempt["error"] = exc
-
-        worker = threading.Thread(target=bring_up, daemon=True)
-        worker.start()
-        worker.join(timeout=float(os.environ.get("LYNX_COMM_TIMEOUT_S", "180")))
-        if worker.is_alive():
-            attempt["error"] = TimeoutError("ncclCommInitRank did not return")
-            abandon_comm = True
-        comm = attempt.get("comm")
-        if comm is not None:
-            gather_kind = "rccl-allgather"
-        else:  # the run must still produce its line; say loudly what happened
-            print(f"[rank {rank}] RCCL communicator failed ({attempt.get('error')}); moment records will be gathered "
-                  "through the host with gloo", file=sys.stderr, flush=True)
-            gather_kind = "gloo-host-fallback"
-        if dist is not None:
-            # every rank must use the same transport
-            import torch
-
-            ok = torch.tensor([1 if comm is not None else 0])
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0 and comm is not None:
-                # a peer has no communicator: tearing ours down could wait for it forever
-                comm, gather_kind, abandon_comm = None, "gloo-host-fallback", True
+        comm, why, stuck = bring_up_rccl(rt, rdzv, rank, world, float(os.environ.get("LYNX_COMM_TIMEOUT_S", "300")))
+        if comm is None:
+            print(f"[rank {rank}] RCCL communicator failed: {why}", file=sys.stderr, flush=True)
+        try:
+            everyone = (not stuck) and rdzv.all_true(comm is not None)
+        except (OSError, TimeoutError, ConnectionError) as exc:  # a peer is gone
+            everyone, why = False, why or f"a peer left the rendezvous ({exc})"
+        if stuck or not everyone:
+            config["gather"] = "rccl-failed"
+            if not stuck and args.allow_host_gather:
+                if comm is not None:
+                    comm.close()
+                    comm = None
+                config["gather"] = "host-tcp-fallback"
+            else:
+                if rank == 0:
+                    print(json.dumps({"metric": METRIC, "value": None, "unit": "particle-element-steps/s",
+                                      "n_gpus": world, "error": f"RCCL communicator could not be built: {why}",
+                                      "config": config}))
+                finish("stuck" if stuck else 3)
+        else:
+            config["gather"] = "rccl-allgather"
+            config.update(comm.info())
+            assert config["rccl_ranks"] == world, config
 
     grad_cov_bar = None
     if args.grad:
@@ -233,39 +333,29 @@ def main():
             grads = vjp(cov_bar=grad_cov_bar)
             return vjp.outgoing, grads
         out = segment.track(beam)
+        if args.sync_every_step:
+            rt.sync()
         if out._moments is None or (world == 1 and comm is None):
             return out, None
         if comm is not None:
             return out, comm.all_gather(out._moments.device(rt).reshape(batch, 36))
-        import torch
-
-        local = torch.from_numpy(np.ascontiguousarray(out.moment_record().reshape(batch, 36)))
-        parts = [torch.empty_like(local) for _ in range(world)]
-        dist.all_gather(parts, local)
-        return out, np.stack([p.numpy() for p in parts])
+        parts = rdzv.all_gather(np.ascontiguousarray(out.moment_record().reshape(batch, 36)).tobytes())
+        return out, np.stack([np.frombuffer(p, dtype=np.float64).reshape(batch, 36) for p in parts])
 
     for _ in range(args.warmup):
         last = step()
     rt.sync()
-    if dist is not None:
-        dist.barrier()
+    rdzv.barrier()
     rt.sync()
     rt.profile_begin()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         last = step()
     rt.sync()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = time.perf_counter() - t0  # this rank's K steps, GPU drained
+    rdzv.barrier()
     kern_ms, launches = rt.profile_end()
-
-    if dist is not None:
-        import torch
-
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = rdzv.max(elapsed)  # the slowest rank's clock between the two barriers
 
     # sanity on the last result (outside the timed region): finite moments, right count
     out, gathered = last
@@ -285,7 +375,7 @@ def main():
 
     copy_gbs = None
     if rank == 0 and world == 1:
-        # practical ceiling on this box: plain 16 B/lane device copy of one pass' bytes
+        # practical ceiling on this box: plain 16 B/lane device copy of one pass' bytes, three launch shapes
         try:
             copy_gbs = rt.copy_bandwidth(min(batch * particles * 7 * np.dtype(dtype).itemsize, 4 << 30))
         except Exception as exc:  # pragma: no cover
@@ -320,7 +410,7 @@ def main():
         result = {
             # BASELINE.json's metric, verbatim; `value` is its first half (whole-node steps/s), the
             # achieved HBM GB/s is `roofline.achieved` (kernel) and `hbm_gbs_whole_step` (wall clock)
-            "metric": "particle-element-steps/sec (whole node) + achieved HBM GB/s, Segment.track ParticleBeam",
+            "metric": METRIC,
             "value": steps_per_pass * args.steps / elapsed,
             "unit": "particle-element-steps/s",
             "n_gpus": world,
@@ -332,30 +422,24 @@ def main():
             "vs_baseline": None,
             "dtype": "f32" if itemsize == 4 else "f64",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {descr}", "batch_per_gpu": batch, "global_batch": batch * world,
-                       "particles": particles, "elements": n_elements, "fused_moments": not args.no_moments, "reverse_pass": bool(args.grad),
-                       "incoming_beam": "one beam shared by the batch (lazy broadcast)" if args.shared_input else "one physical beam per sample",
-                       "gather": gather_kind, "parallelism": f"{'particle' if batch == 1 else 'batch'}-sharded x{world}"},
+            "config": config,
             "roofline": {"bound": "hbm", "kernel": "k_track_direct", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": kern_s * 1e3, "launches": launches},
             "hbm_gbs_whole_step": alg_bytes * world * args.steps / elapsed / 1e9,
-            "hbm_copy_kernel_gbs": copy_gbs,
+            # the practical ceiling: best plain-copy shape measured in this process (MI355X_MICROARCH.md: ~6.3 TB/s)
+            "hbm_copy_kernel_gbs": max(copy_gbs.values()) if copy_gbs else None,
+            "hbm_copy_kernel_shapes": copy_gbs,
             "device": rt.info(),
         }
-        if not args.no_cpu_baseline and world == 1:
-            result["cpu_baseline"] = cpu_baseline(args.workload, particles, cells, dtype)
+        if baseline is not None:
+            result["cpu_baseline"] = baseline
         print(json.dumps(result))
     if comm is not None:
         comm.close()
-    if dist is not None:
-        dist.destroy_process_group()
-    if abandon_comm:  # a half-built RCCL communicator may block interpreter shutdown
-        sys.stdout.flush()
-        sys.stderr.flush()
-        os._exit(0)
+    finish(0)
 
 
 if __name__ == "__main__":

@@ -134,8 +134,11 @@ int lynx_profile_begin(lynx_ctx* ctx);
 int lynx_profile_end(lynx_ctx* ctx, double* total_ms, int64_t* launches);
 
 /* Calibration: average time of a plain 16-byte-per-lane copy of `bytes` (read + write),
- * i.e. the practical HBM ceiling of this GPU for a stream shaped like a tracking pass. */
-int lynx_diag_copy(lynx_ctx* ctx, void* d_dst, const void* d_src, size_t bytes, int repeats, float* avg_ms);
+ * i.e. the practical HBM ceiling of this GPU for a stream shaped like a tracking pass.
+ * vec_per_thread: 16-byte vectors each thread copies (a workgroup owns one contiguous block of
+ * 256 * vec_per_thread vectors); 0 = grid-stride loop.  1 is the fastest shape on MI355X.     */
+int lynx_diag_copy(lynx_ctx* ctx, void* d_dst, const void* d_src, size_t bytes, int repeats,
+                   int vec_per_thread, float* avg_ms);
 
 /* ---- device buffers (reference: jax.Array storage behind `ParticleBeam.particles`,
  *      particle_beam.py:24-45; the Python side owns the handles) ----------------------- */
@@ -264,6 +267,8 @@ int lynx_fill_gaussian(lynx_ctx* ctx, int dtype, int64_t batch, int64_t n_partic
 int lynx_comm_unique_id(char* id_out /* LYNX_UNIQUE_ID_BYTES */);
 int lynx_comm_init(lynx_ctx* ctx, int n_ranks, int rank, const char* id);
 int lynx_comm_destroy(lynx_ctx* ctx);
+/* what the communicator actually is: RCCL version code (ncclGetVersion), ranks, this rank; ranks = 0 when there is none */
+int lynx_comm_info(lynx_ctx* ctx, int32_t* rccl_version, int32_t* n_ranks, int32_t* rank);
 /* all-gather `count` float64 per rank: d_recv [n_ranks][count] */
 int lynx_gather_moments(lynx_ctx* ctx, const double* d_send, double* d_recv, int64_t count);
 

@@ -67,7 +67,7 @@ SIGNATURES = {
     "lynx_timer_stop": (_i, [_vp, C.POINTER(C.c_float)]),
     "lynx_profile_begin": (_i, [_vp]),
     "lynx_profile_end": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
-    "lynx_diag_copy": (_i, [_vp, _vp, _vp, _sz, _i, C.POINTER(C.c_float)]),
+    "lynx_diag_copy": (_i, [_vp, _vp, _vp, _sz, _i, _i, C.POINTER(C.c_float)]),
     "lynx_buf_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "lynx_buf_free": (_i, [_vp, _vp]),
     "lynx_buf_h2d": (_i, [_vp, _vp, _vp, _sz]),
@@ -96,6 +96,7 @@ SIGNATURES = {
     "lynx_comm_unique_id": (_i, [C.c_char_p]),
     "lynx_comm_init": (_i, [_vp, _i, _i, C.c_char_p]),
     "lynx_comm_destroy": (_i, [_vp]),
+    "lynx_comm_info": (_i, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "lynx_gather_moments": (_i, [_vp, _vp, _vp, _i64]),
 }
 

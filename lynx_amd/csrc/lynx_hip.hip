@@ -989,11 +989,13 @@ int lynx_fill_gaussian(lynx_ctx* ctx, int dtype, int64_t batch, int64_t n_partic
 
 // ---- diagnostics: practical HBM ceiling ------------------------------------------------------
 
-int lynx_diag_copy(lynx_ctx* ctx, void* d_dst, const void* d_src, size_t bytes, int repeats, float* avg_ms) {
-  if (!ctx || !d_dst || !d_src || bytes % 16 || repeats <= 0) return fail(ctx, LYNX_ERR_INVALID, "bad argument");
+int lynx_diag_copy(lynx_ctx* ctx, void* d_dst, const void* d_src, size_t bytes, int repeats, int vec_per_thread,
+                   float* avg_ms) {
+  if (!ctx || !d_dst || !d_src || bytes % 16 || repeats <= 0 || vec_per_thread < 0 || vec_per_thread > 64)
+    return fail(ctx, LYNX_ERR_INVALID, "bad argument");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const int64_t n_vec = (int64_t)(bytes / 16);
-  const int vpt = env_int("LYNX_COPY_VPT", 4);  // 0 = grid-stride
+  const int vpt = vec_per_thread;  // 0 = grid-stride
   const unsigned grid = vpt > 0 ? (unsigned)((n_vec + 256LL * vpt - 1) / (256LL * vpt))
                                 : (unsigned)std::min<int64_t>((n_vec + 255) / 256, 256 * 16);
   hipLaunchKernelGGL(k_diag_copy, dim3(grid), dim3(256), 0, ctx->stream, (const lynx_f32x4*)d_src,
@@ -1037,6 +1039,23 @@ int lynx_comm_destroy(lynx_ctx* ctx) {
     NCCL_TRY(ctx, ncclCommDestroy(ctx->comm));
     ctx->comm = nullptr;
     ctx->comm_ranks = 0;
+  }
+  return LYNX_OK;
+}
+
+int lynx_comm_info(lynx_ctx* ctx, int32_t* rccl_version, int32_t* n_ranks, int32_t* rank) {
+  if (!ctx || !rccl_version || !n_ranks || !rank) return fail(ctx, LYNX_ERR_INVALID, "null argument");
+  int v = 0;
+  NCCL_TRY(ctx, ncclGetVersion(&v));
+  *rccl_version = v;
+  *n_ranks = 0;
+  *rank = -1;
+  if (ctx->comm) {
+    int n = 0, r = -1;
+    NCCL_TRY(ctx, ncclCommCount(ctx->comm, &n));
+    NCCL_TRY(ctx, ncclCommUserRank(ctx->comm, &r));
+    *n_ranks = n;
+    *rank = r;
   }
   return LYNX_OK;
 }

@@ -105,6 +105,14 @@ class RcclCommunicator:
         assert isinstance(uid, (bytes, bytearray)) and len(uid) == _ffi.UNIQUE_ID_BYTES
         self.rt.check(self.rt.lib.lynx_comm_init(self.rt.ctx, n_ranks, rank, bytes(uid)))
 
+    def info(self) -> dict:
+        """RCCL version and the communicator's own idea of its size and this rank (`lynx_comm_info`)."""
+        v, n, r = C.c_int32(), C.c_int32(), C.c_int32()
+        self.rt.check(self.rt.lib.lynx_comm_info(self.rt.ctx, C.byref(v), C.byref(n), C.byref(r)))
+        code = v.value  # NCCL_VERSION_CODE: major*10000 + minor*100 + patch since 2.9
+        return {"rccl_version": f"{code // 10000}.{code // 100 % 100}.{code % 100}", "rccl_ranks": n.value,
+                "rccl_rank": r.value}
+
     def all_gather(self, local: DeviceArray) -> DeviceArray:
         """(rows, 36) float64 per rank -> (n_ranks, rows, 36) on every rank (async on the stream)."""
         assert local.dtype == np.float64

@@ -170,3 +170,52 @@ def test_world_size_2_particle_sharding_equals_single_process():
         np.testing.assert_allclose(merged[..., :7], reference[..., :7], rtol=1e-12, atol=1e-18)
         np.testing.assert_allclose(merged[..., 7:28], reference[..., 7:28], rtol=1e-9, atol=1e-24)
         assert merged[0, 35] == 3001
+
+
+# ---------------------------------------------------------------------------------------------
+# lynx_amd.rendezvous: the standard-library rendezvous bench.py uses at N > 1 (no torch, no gloo)
+# ---------------------------------------------------------------------------------------------
+
+
+def _rdzv_rank(rank, world, key, queue):
+    import struct
+
+    from lynx_amd.rendezvous import Rendezvous
+
+    rz = Rendezvous(rank, world, key=key, timeout_s=60)
+    uid = rz.broadcast(bytes(range(128)) if rank == 0 else None)  # the RCCL unique id travels like this
+    rz.barrier()
+    top = rz.max(10.0 + rank)
+    a, b = shard_batch(GLOBAL_BATCH, world, rank)
+    rows = _records((a, b))
+    pad = np.zeros((shard_batch(GLOBAL_BATCH, world, 0)[1], 36))
+    pad[: b - a] = rows
+    parts = rz.all_gather(pad.tobytes())  # the --allow-host-gather path
+    gathered = np.stack([np.frombuffer(p, dtype=np.float64).reshape(pad.shape) for p in parts])
+    ok = rz.all_true(rank != 1)  # one rank reports failure: nobody may see "all true"
+    rz.close()
+    queue.put((rank, uid, top, assemble_records(gathered, GLOBAL_BATCH, world), ok, struct.calcsize("<d")))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_stdlib_rendezvous_broadcast_barrier_max_gather(world, tmp_path):
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    key = f"test-{os.getpid()}-{world}"
+    procs = [ctx.Process(target=_rdzv_rank, args=(r, world, key, queue)) for r in range(world)]
+    for p in reversed(procs):  # rank 0 last: the others must wait for its port file
+        p.start()
+    results = sorted(queue.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = _records((0, GLOBAL_BATCH))
+    for rank, uid, top, records, ok, _ in results:
+        assert uid == bytes(range(128))
+        assert top == 10.0 + world - 1
+        assert np.array_equal(records, want)  # bytes travel unchanged
+        assert ok is False
+    import tempfile
+    from pathlib import Path
+
+    assert not (Path(tempfile.gettempdir()) / f"lynx-rdzv-{key}.port").exists()
