@@ -32,7 +32,7 @@ struct LatticeDev {
   int32_t n_steps;
 };
 
-constexpr int kBuildChunk = 64;   // elements built in parallel per compose round
+constexpr int kBuildChunk = 64;   // elements built in parallel per compose round (k_build may use up to 128)
 constexpr int kTrackThreads = 256;
 constexpr int kPartialStride = 36;
 
@@ -44,31 +44,52 @@ template <typename T> __device__ __forceinline__ T shfl_t(T v, int src) { return
 //
 //   phase 0  thread 0 walks the steps and accumulates the beam energy across active
 //            cavities (cavity.py:130: E_out = E + V cos(phi)).
-//   phase 1  up to kBuildChunk elements are built in parallel, one element per thread,
-//            straight into LDS (transcendentals run element-parallel).
-//   phase 2  the chunk's maps of each step are multiplied together by a pairwise tree:
-//            level by level, neighbours (M_{2i+1} . M_{2i}) are merged, blockDim.x/49
-//            products per round with one lane per output entry, then the chunk product is
-//            left-multiplied onto the step's running map, tm = P_chunk . tm.
-//            The product is the reference's tm = M_n ... M_2 M_1 (segment.py:334-335); only
-//            the association differs (tree instead of left-to-right), i.e. rounding-level
-//            differences, in exchange for log2 instead of linear depth: the build is a pure
-//            latency chain and sits on the critical path of every call.
+//   phase 1  up to `chunk` elements are built in parallel, one element per thread, in the
+//            lattice's own precision T (the reference builds every element map in the beam's
+//            dtype).  Lane l of wave w takes element l * waves + w, so neighbouring elements
+//            -- usually of different kinds -- land on different waves and each wave runs as
+//            few different builders as possible, side by side on the CU's SIMDs.
+//   phase 2  the chunk's maps of each step are multiplied together by a pairwise tree IN
+//            FLOAT64 (also for float32 lattices): level by level neighbours (M_{2i+1} . M_{2i})
+//            are merged, seven lanes per product (one lane per output row), then the chunk
+//            product is left-multiplied onto the step's running map, tm = P_chunk . tm, and the
+//            finished step is rounded to T once.
+//            The product is the reference's tm = M_n ... M_2 M_1 (segment.py:334-335).  The
+//            reference multiplies left to right in T; a float32 tree instead measured 2e-5
+//            (sigma) / 5e-5 (sigma_xx') away from that chain on BASELINE config 4 -- inside the
+//            1e-4 tolerance, but half of it.  Accumulated in float64 the product is exact to
+//            ~1e-15 whatever the association, so what is left against the reference's float32
+//            chain is the chain's own rounding (6e-6 / 1e-5 on config 4, tests/test_gpu_parity.py),
+//            and the build keeps log2 instead of linear depth: it is a pure latency chain.
 //
-// LDS scratch: kBuildChunk*49 (maps) + kBuildTree*49 (two ping-pong levels + running map).
+// LDS scratch: see build_scratch_bytes().
 // ---------------------------------------------------------------------------------------
-// Scratch of a chunk of `c` elements: c maps + two tree levels (c/2+1, c/4+1) + the running map.
-// The ParameterBeam kernel sizes its chunk to the lattice (a 13-element lattice needs 4.9 KB
-// instead of 22.5 KB, so 4x as many of its one-wave workgroups fit a CU); k_build keeps the
-// full chunk (more resident 256-thread workgroups only slowed each other down: 135 -> 162 us
-// on BASELINE config 5).
-__host__ __device__ inline int build_chunk(int n_elems) {
-  return n_elems < kBuildChunk ? (n_elems > 1 ? n_elems : 1) : kBuildChunk;
+__host__ __device__ inline int build_chunk(int n_elems, int limit = kBuildChunk) {
+  return n_elems < limit ? (n_elems > 1 ? n_elems : 1) : limit;
 }
-__host__ __device__ inline int build_scratch_scalars(int chunk) {
-  return (chunk + (chunk / 2 + 1) + (chunk / 4 + 1) + 1) * 49;
+// float64 maps: chunk + two ping-pong tree levels (c/2+1, c/4+1) + the running map + one temporary;
+// float32 lattices add the staging area the builders write their T-typed maps to.  The chunk must
+// not exceed the workgroup size (one element per thread in phase 1).
+__host__ __device__ inline size_t build_scratch_bytes(int chunk, size_t elem_size) {
+  size_t b = (size_t)(chunk + (chunk / 2 + 1) + (chunk / 4 + 1) + 2) * 49 * sizeof(double);
+  if (elem_size == 4) b += (size_t)chunk * 49 * sizeof(float);
+  return (b + 15) / 16 * 16;
 }
-constexpr int kBuildScratch = (kBuildChunk + (kBuildChunk / 2 + 1) + (kBuildChunk / 4 + 1) + 1) * 49;  // full chunk
+
+// Row r of D = A . Bm (7x7, row-major, float64), ascending k -- one lane per output row
+__device__ __forceinline__ void mat_product_row(const double* A, const double* Bm, double* D, int r) {
+  double a[7], acc[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) a[k] = A[r * 7 + k];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) acc[j] = a[0] * Bm[j];
+#pragma unroll
+  for (int k = 1; k < 7; ++k)
+#pragma unroll
+    for (int j = 0; j < 7; ++j) acc[j] = fma(a[k], Bm[k * 7 + j], acc[j]);
+#pragma unroll
+  for (int j = 0; j < 7; ++j) D[r * 7 + j] = acc[j];
+}
 
 template <typename T>
 __device__ __forceinline__ T mat_product_entry(const T* A, const T* Bm, int ij) {
@@ -82,17 +103,21 @@ __device__ __forceinline__ T mat_product_entry(const T* A, const T* Bm, int ij) 
 
 template <typename T>
 __device__ void build_compose_sample(const LatticeDev& lat, int64_t b, T energy_in, T* s_steps,
-                                     T* s_energy, T* s_scratch /* build_scratch_scalars(chunk) */,
+                                     T* s_energy, unsigned char* s_scratch /* build_scratch_bytes(chunk, sizeof(T)) */,
                                      int chunk = kBuildChunk) {
   const int tid = threadIdx.x;
   const int E = lat.n_elems, S = lat.n_steps;
   const T* pool = static_cast<const T*>(lat.pool);
-  T* bufA = s_scratch;
-  T* bufB = bufA + chunk * 49;
-  T* bufC = bufB + (chunk / 2 + 1) * 49;
-  T* carry = bufC + (chunk / 4 + 1) * 49;
-  const int per_round = blockDim.x / 49;  // products per round
-  const int my_prod = tid / 49, my_ij = tid - my_prod * 49;
+  double* bufA = reinterpret_cast<double*>(s_scratch);
+  double* bufB = bufA + chunk * 49;
+  double* bufC = bufB + (chunk / 2 + 1) * 49;
+  double* carry = bufC + (chunk / 4 + 1) * 49;
+  double* tmp = carry + 49;
+  // where the builders write: straight into bufA for float64, into the staging area for float32
+  T* built = sizeof(T) == 8 ? reinterpret_cast<T*>(bufA) : reinterpret_cast<T*>(tmp + 49);
+  const int per_round = blockDim.x / 7;  // products per round, 7 row-lanes each
+  const int my_prod = tid / 7, my_row = tid - my_prod * 7;
+  const int waves = blockDim.x >> 6;
 
   if (tid == 0) {
     T e = energy_in;
@@ -115,16 +140,23 @@ __device__ void build_compose_sample(const LatticeDev& lat, int64_t b, T energy_
   for (int e0 = 0; e0 < E; e0 += chunk) {
     const int ne = (E - e0) < chunk ? (E - e0) : chunk;
     // phase 1
-    for (int t = tid; t < ne; t += blockDim.x) {
-      const int e = e0 + t;
-      lynx_elem el = lat.elems[e];
-      const int s = lat.elem_step[e];
-      const T* p = pool + el.param_offset + b * (int64_t)el.batch_stride;
-      const bool cav_step = lat.steps[s].kind == LYNX_STEP_CAVITY;
-      build_element<T>(el.kind, el.flags, p, s_energy[s], bufA + t * 49,
-                       cav_step ? s_steps + s * LYNX_STEP_STRIDE + LYNX_COEF_OFFSET : nullptr);
+    {
+      const int t = (tid & 63) * waves + (tid >> 6);
+      if (t < ne) {
+        const int e = e0 + t;
+        lynx_elem el = lat.elems[e];
+        const int s = lat.elem_step[e];
+        const T* p = pool + el.param_offset + b * (int64_t)el.batch_stride;
+        const bool cav_step = lat.steps[s].kind == LYNX_STEP_CAVITY;
+        build_element<T>(el.kind, el.flags, p, s_energy[s], built + t * 49,
+                         cav_step ? s_steps + s * LYNX_STEP_STRIDE + LYNX_COEF_OFFSET : nullptr);
+      }
     }
     __syncthreads();
+    if (sizeof(T) == 4) {
+      for (int i = tid; i < ne * 49; i += blockDim.x) bufA[i] = (double)built[i];
+      __syncthreads();
+    }
     // phase 2: every step that has elements in [e0, e0 + ne)
     while (s_cur < S) {
       const lynx_step st = lat.steps[s_cur];
@@ -135,15 +167,19 @@ __device__ void build_compose_sample(const LatticeDev& lat, int64_t b, T energy_
       const bool ends_here = st.last <= e0 + ne;
       const bool raw = st.kind == LYNX_STEP_CAVITY || (st.flags & LYNX_STEP_FLAG_RAW);
       // pairwise tree over bufA[lo .. hi)
-      const T* src = bufA + lo * 49;
+      const double* src = bufA + lo * 49;
       int count = hi - lo;
       int level = 0;
       while (count > 1) {
-        T* dst = (level & 1) ? bufC : bufB;
+        double* dst = (level & 1) ? bufC : bufB;
         const int half = count >> 1;
-        for (int pr = my_prod; pr < half; pr += per_round)
-          if (my_prod < per_round) dst[pr * 49 + my_ij] = mat_product_entry<T>(src + (2 * pr + 1) * 49, src + (2 * pr) * 49, my_ij);
-        if ((count & 1) && tid < 49) dst[half * 49 + tid] = src[(count - 1) * 49 + tid];
+        if (my_prod < per_round)
+          for (int pr = my_prod; pr < half; pr += per_round)
+            mat_product_row(src + (2 * pr + 1) * 49, src + (2 * pr) * 49, dst + pr * 49, my_row);
+        if ((count & 1) && tid >= blockDim.x - 49) {
+          const int q = tid - (blockDim.x - 49);
+          dst[half * 49 + q] = src[(count - 1) * 49 + q];
+        }
         __syncthreads();
         src = dst;
         count = half + (count & 1);
@@ -154,17 +190,16 @@ __device__ void build_compose_sample(const LatticeDev& lat, int64_t b, T energy_
         if (tid < 49) carry[tid] = src[tid];
       } else {
         if (starts_here) {
-          if (tid < 49) carry[tid] = (tid % 8 == 0) ? T(1) : T(0);
+          if (tid < 49) carry[tid] = (tid % 8 == 0) ? 1.0 : 0.0;
           __syncthreads();
         }
-        T v = T(0);
-        if (tid < 49) v = mat_product_entry<T>(src, carry, tid);
+        if (tid < 7) mat_product_row(src, carry, tmp, tid);
         __syncthreads();
-        if (tid < 49) carry[tid] = v;
+        if (tid < 49) carry[tid] = tmp[tid];
       }
       __syncthreads();
       if (ends_here) {
-        if (tid < 49) s_steps[s_cur * LYNX_STEP_STRIDE + tid] = carry[tid];
+        if (tid < 49) s_steps[s_cur * LYNX_STEP_STRIDE + tid] = (T)carry[tid];
         ++s_cur;
       } else {
         break;  // the step continues in the next chunk
@@ -361,32 +396,26 @@ __device__ __forceinline__ void apply_program(const LatticeDev& lat, const T* s_
 }
 
 // ---------------------------------------------------------------------------------------
-// k_build: standalone build+compose, one 256-thread workgroup per sample.
+// k_build: standalone build+compose, one workgroup per sample: 256 threads and chunks of up to
+// 64 elements when the batch fills the GPU, 1024 threads and chunks of up to 128 when it does not
+// (a single sample's 128-element lattice is then 7 tree levels deep instead of two rounds of 6).
+// Depends on the lattice and the incoming energy only -- not on the particles -- so consecutive
+// `track` calls can run it on a second stream underneath the previous call's streaming kernel.
+// The outgoing energy is parked in the last step's row (LYNX_ENERGY_OFFSET) for the streaming
+// kernel to publish; `energy_out` is only used by the synchronous lynx_build_compose entry.
 // ---------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void k_build(LatticeDev lat, const T* __restrict__ energy_in,
-                                               T* __restrict__ steps_out, T* __restrict__ energy_out,
-                                               const T* __restrict__ p_first, int64_t sample_stride,
-                                               int merge_pairs) {
+__global__ __launch_bounds__(1024) void k_build(LatticeDev lat, const T* __restrict__ energy_in,
+                                                T* __restrict__ steps_out, T* __restrict__ energy_out,
+                                                int chunk, int merge_pairs) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* s_scratch = reinterpret_cast<T*>(smem_raw);
-  T* s_steps = s_scratch + kBuildScratch;
+  T* s_steps = reinterpret_cast<T*>(smem_raw + build_scratch_bytes(chunk, sizeof(T)));
   T* s_energy = s_steps + (size_t)lat.n_steps * LYNX_STEP_STRIDE;
   const int64_t b = blockIdx.x;
   // zero the coefficient slots so that run steps have defined padding
   for (int i = threadIdx.x; i < lat.n_steps * LYNX_STEP_STRIDE; i += blockDim.x) s_steps[i] = T(0);
   __syncthreads();
-  build_compose_sample<T>(lat, b, energy_in[b], s_steps, s_energy, s_scratch);
-  if (p_first && threadIdx.x == 0) {
-    // reference point of the moment sums: this sample's first particle, tracked
-    T z[7];
-#pragma unroll
-    for (int i = 0; i < 7; ++i) z[i] = p_first[b * sample_stride + i];
-    apply_program<T>(lat, s_steps, z);
-#pragma unroll
-    for (int i = 0; i < 7; ++i) s_steps[LYNX_SHIFT_OFFSET + i] = z[i];
-  }
-  __syncthreads();
+  build_compose_sample<T>(lat, b, energy_in[b], s_steps, s_energy, smem_raw, chunk);
   if (merge_pairs) {
     // [run, cavity] pairs for the streaming kernel: slot of the cavity <- T_cav . T_run (one
     // 7x7 application per pair instead of two), slot of the run <- rows 4 and 5 of T_run, which
@@ -396,38 +425,31 @@ __global__ __launch_bounds__(256) void k_build(LatticeDev lat, const T* __restri
       T* run = s_steps + (s - 1) * LYNX_STEP_STRIDE;
       T* cav = s_steps + s * LYNX_STEP_STRIDE;
       T v = T(0);
-      if (threadIdx.x < 49) v = mat_product_entry<T>(cav, run, threadIdx.x);
+      if (threadIdx.x < 49) {  // product of the two rounded maps, accumulated in float64, rounded once
+        const int i = threadIdx.x / 7, j = threadIdx.x - i * 7;
+        double acc = (double)cav[i * 7] * (double)run[j];
+#pragma unroll
+        for (int k = 1; k < 7; ++k) acc = fma((double)cav[i * 7 + k], (double)run[k * 7 + j], acc);
+        v = (T)acc;
+      }
       __syncthreads();
       if (threadIdx.x < 49) cav[threadIdx.x] = v;
       if (threadIdx.x >= 64 && threadIdx.x < 78) run[threadIdx.x - 64] = run[28 + (threadIdx.x - 64)];
       __syncthreads();
     }
   }
+  if (lat.n_steps > 0 && threadIdx.x == 0)
+    s_steps[(lat.n_steps - 1) * LYNX_STEP_STRIDE + LYNX_ENERGY_OFFSET] = s_energy[lat.n_steps];
+  __syncthreads();
   T* dst = steps_out + b * (int64_t)lat.n_steps * LYNX_STEP_STRIDE;
   for (int i = threadIdx.x; i < lat.n_steps * LYNX_STEP_STRIDE; i += blockDim.x) dst[i] = s_steps[i];
   if (energy_out && threadIdx.x == 0) energy_out[b] = s_energy[lat.n_steps];
 }
 
-// ---------------------------------------------------------------------------------------
-// k_track: the streaming kernel.  grid.x = B * chunks; each 256-thread workgroup owns
-// `tiles_per_wg` consecutive tiles of TILE = 256*PPT particles of ONE sample.
-//
-// Per tile: the AoS tile travels HBM -> registers -> LDS as a flat array with 16-byte
-// accesses (perfectly coalesced; stride 7 never shows up on the HBM side).  Each lane then
-// picks its particles out of LDS with stride 7 words (7 is coprime with the 32/64 LDS
-// banks -> conflict-free), runs the program in registers, writes the result back into the
-// same LDS slots, and the tile leaves LDS again as a flat 16-byte stream.  The loads of
-// tile t+1 are issued before tile t is processed (register prefetch), so every workgroup
-// keeps a tile of HBM reads in flight while it computes and stores.
-//
-// Single-run programs (every all-skippable lattice: one composed 7x7 per sample) keep the
-// map in SGPRs for fp32 (it is wave-uniform), so the inner loop is 49 v_fma with a scalar
-// operand each and the map costs no VGPRs.
-// ---------------------------------------------------------------------------------------
-template <typename T, bool VEC> struct VecOf { using type = T; static constexpr int width = 1; };
 // clang native vectors (HIP's float4/double2 structs defeat SROA and land in scratch)
 typedef float lynx_f32x4 __attribute__((ext_vector_type(4)));
 typedef double lynx_f64x2 __attribute__((ext_vector_type(2)));
+template <typename T, bool VEC> struct VecOf { using type = T; static constexpr int width = 1; };
 template <> struct VecOf<float, true> { using type = lynx_f32x4; static constexpr int width = 4; };
 template <> struct VecOf<double, true> { using type = lynx_f64x2; static constexpr int width = 2; };
 
@@ -437,8 +459,9 @@ struct TrackArgs {
   int32_t tiles_per_wg;
   int32_t fused_build;   // 1: build+compose in the prologue, 0: read steps_in
   int32_t store;         // 1: write p_out
-  int32_t lds_tile_scalars;  // size of the tile/scratch region in scalars
-  int32_t interleave;    // direct kernel: 1 = a workgroup takes every `chunks`-th tile
+  int32_t lds_scratch_bytes;  // build scratch / moment-reduction slab in front of the step table
+  int32_t build_chunk;   // fused prologue: elements per compose round
+  int32_t interleave;    // 1 = a workgroup takes every `chunks`-th tile
   int64_t in_stride;     // scalars between the samples of p_in: N*7, or 0 for one shared incoming beam
   int32_t merged_pairs;  // the step table holds [run, cavity] pairs in merged form (see k_build)
 };
@@ -447,6 +470,35 @@ __device__ __forceinline__ float uniform_value(float v) {
   return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
 }
 __device__ __forceinline__ double uniform_value(double v) { return v; }  // stays in VGPRs / LDS
+// value of the first active lane, as a wave-uniform (scalar-register) value
+__device__ __forceinline__ float wave_first(float v) { return uniform_value(v); }
+__device__ __forceinline__ double wave_first(double v) {
+  const long long bits = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readfirstlane((int)(bits & 0xffffffffll));
+  const int hi = __builtin_amdgcn_readfirstlane((int)(bits >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// ---------------------------------------------------------------------------------------
+// Moment partial records.  A record holds sums over some particles of d = z - c and d d^T for a
+// reference point c near the beam (so that float32 partial sums do not cancel), layout:
+//   [0..5] sum d_i   [6] sum z_6   [7..27] sum d_i d_j (i <= j, row-major)   [28..33] c   [35] count
+// Every wave takes ITS OWN first tracked particle as c -- no pass over the beam, no dependence of
+// the map build on the particles -- and records are moved to a common reference point when they
+// are added up (workgroup reduction, k_finalize_moments), exactly, in float64:
+//   sum (z - c0)_i                = D_i + n e_i                           e = c - c0
+//   sum (z - c0)_i (z - c0)_j     = DD_ij + e_i D_j + D_i e_j + n e_i e_j
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double moment_slot_moved(const double* row, const double* c0, int j) {
+  if (j == 6 || j >= 28) return row[j];
+  const double n = row[35];
+  if (j < 6) return row[j] + n * (row[28 + j] - c0[j]);
+  int k = j - 7, i = 0, len = 6;  // upper-triangle index -> (i, jj)
+  while (k >= len) { k -= len; --len; ++i; }
+  const int jj = i + k;
+  const double ei = row[28 + i] - c0[i], ej = row[28 + jj] - c0[jj];
+  return row[j] + ei * row[jj] + row[i] * ej + n * ei * ej;
+}
 
 template <typename T> struct MomentAcc {
   double d[6], dd[21], one, cnt;
@@ -458,7 +510,7 @@ template <typename T> struct MomentAcc {
     one = 0.0;
     cnt = 0.0;
   }
-  __device__ __forceinline__ void add(const T (&z)[7], const T (&shift)[7]) {
+  __device__ __forceinline__ void add(const T (&z)[7], const T (&shift)[6]) {
     double e[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
@@ -478,176 +530,35 @@ template <typename T> struct MomentAcc {
   }
 };
 
-template <typename T, int PPT, bool VEC, bool MOMENTS>
-__global__ __launch_bounds__(kTrackThreads) void k_track(
-    LatticeDev lat, TrackArgs a, const T* __restrict__ energy_in, const T* p_in, T* p_out,
-    T* __restrict__ energy_out, const T* __restrict__ steps_in, double* __restrict__ partials) {
-  constexpr int TILE = kTrackThreads * PPT;
-  using V = typename VecOf<T, VEC>::type;
-  constexpr int VW = VecOf<T, VEC>::width;
-  constexpr int NV = (TILE * 7 / VW + kTrackThreads - 1) / kTrackThreads;  // vectors per thread and tile
-
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* s_tile = reinterpret_cast<T*>(smem_raw);                      // tile, aliases build scratch
-  T* s_steps = s_tile + a.lds_tile_scalars;                        // [S][64]
-  T* s_energy = s_steps + (size_t)lat.n_steps * LYNX_STEP_STRIDE;  // [S+1]
-
-  const int tid = threadIdx.x;
-  const int64_t b = blockIdx.x / a.chunks;
-  const int chunk = blockIdx.x % a.chunks;
-  const int64_t N = a.n_particles;
-  const int S = lat.n_steps;
-  const int64_t first_tile = (int64_t)chunk * a.tiles_per_wg;
-
-  // Issue the first tile's loads before the build prologue: they fly while the map is built.
-  V pre[NV];
-  {
-    const int64_t tile_start = first_tile * TILE;
-    const int cnt = (int)((N - tile_start) < TILE ? (N - tile_start) : TILE);
-    const V* src = reinterpret_cast<const V*>(p_in + b * a.in_stride + tile_start * 7);
-    const int nvec = cnt * 7 / VW;
-    // clamped index instead of a guarded load: keeps `pre` in registers (a guarded
-    // element-wise assignment sends the array to scratch and serialises the prefetch)
-#pragma unroll
-    for (int r = 0; r < NV; ++r) {
-      const int v = r * kTrackThreads + tid;
-      pre[r] = src[v < nvec ? v : nvec - 1];
-    }
-  }
-
-  if (a.fused_build) {
-    build_compose_sample<T>(lat, b, energy_in[b], s_steps, s_energy, s_tile);
-    if (energy_out && chunk == 0 && tid == 0) energy_out[b] = s_energy[S];
-  } else if (S > 0) {
-    load_steps_sample<T>(steps_in + b * (int64_t)S * LYNX_STEP_STRIDE, S, s_steps);
-  }
-
-  const bool one_run = (S == 1) && (lat.steps[0].kind == LYNX_STEP_RUN);
-  T m0[49];  // the single composed map, wave-uniform
-  if (one_run) {
-#pragma unroll
-    for (int i = 0; i < 49; ++i) m0[i] = uniform_value(s_steps[i]);
-  }
-
-  // Moment accumulation (float64): d = z - c with c = the transformed first particle of
-  // the sample (same value in every workgroup of the sample) to avoid cancellation.
-  MomentAcc<T> acc;
-  T shift[7];
-  if (MOMENTS) {
-    acc.clear();
-    const T* p0 = p_in + b * a.in_stride;
-#pragma unroll
-    for (int i = 0; i < 7; ++i) shift[i] = p0[i];
-    apply_program<T>(lat, s_steps, shift);
-  }
-
-  for (int t = 0; t < a.tiles_per_wg; ++t) {
-    const int64_t tile_start = (first_tile + t) * TILE;
-    if (tile_start >= N) break;
-    const int cnt = (int)((N - tile_start) < TILE ? (N - tile_start) : TILE);
-    const int nvec = cnt * 7 / VW;
-    const int64_t goff = (b * N + tile_start) * 7;
-
-    // registers -> LDS (flat)
-    {
-      V* dst = reinterpret_cast<V*>(s_tile);
-#pragma unroll
-      for (int r = 0; r < NV; ++r) {
-        const int v = r * kTrackThreads + tid;
-        if (v < nvec) dst[v] = pre[r];
-      }
-    }
-    __syncthreads();
-
-    // prefetch the next tile of this workgroup
-    {
-      const int64_t next_start = tile_start + TILE;
-      if (t + 1 < a.tiles_per_wg && next_start < N) {
-        const int ncnt = (int)((N - next_start) < TILE ? (N - next_start) : TILE);
-        const V* src = reinterpret_cast<const V*>(p_in + b * a.in_stride + next_start * 7);
-        const int nnvec = ncnt * 7 / VW;
-#pragma unroll
-        for (int r = 0; r < NV; ++r) {
-          const int v = r * kTrackThreads + tid;
-          pre[r] = src[v < nnvec ? v : nnvec - 1];
-        }
-      }
-    }
-
-#pragma unroll 1
-    for (int q = 0; q < PPT; ++q) {
-      const int pi = q * kTrackThreads + tid;
-      if (pi < cnt) {
-        T z[7];
-#pragma unroll
-        for (int c = 0; c < 7; ++c) z[c] = s_tile[pi * 7 + c];
-        if (one_run) {
-          apply_step<T>(m0, LYNX_STEP_RUN, 0, z);
-        } else {
-          apply_program<T>(lat, s_steps, z);
-        }
-        if (a.store) {
-#pragma unroll
-          for (int c = 0; c < 7; ++c) s_tile[pi * 7 + c] = z[c];
-        }
-        if (MOMENTS) acc.add(z, shift);
-      }
-    }
-
-    if (a.store) {
-      __syncthreads();
-      V* dstg = reinterpret_cast<V*>(p_out + goff);
-      const V* srcl = reinterpret_cast<const V*>(s_tile);
-#pragma unroll
-      for (int r = 0; r < NV; ++r) {
-        const int v = r * kTrackThreads + tid;
-        if (v < nvec) dstg[v] = srcl[v];
-      }
-    }
-    __syncthreads();  // the tile buffer is rewritten by the next iteration
-  }
-
-  if (MOMENTS) {
-    // wave reduction (xor butterfly over 64 lanes), then across the 4 waves through LDS
-    double* s_red = reinterpret_cast<double*>(s_tile);  // 4 waves x 29
-    const int wave = tid >> 6, lane = tid & 63;
-#define LYNX_WAVE_SUM(dst_idx, value)                                        \
-    {                                                                          \
-      double v_ = (value);                                                     \
-      for (int off = 32; off >= 1; off >>= 1) v_ += __shfl_xor(v_, off, 64);   \
-      if (lane == 0) s_red[wave * 29 + (dst_idx)] = v_;                        \
-    }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) LYNX_WAVE_SUM(i, acc.d[i]);
-    LYNX_WAVE_SUM(6, acc.one);
-#pragma unroll
-    for (int i = 0; i < 21; ++i) LYNX_WAVE_SUM(7 + i, acc.dd[i]);
-    LYNX_WAVE_SUM(28, acc.cnt);
-#undef LYNX_WAVE_SUM
-    __syncthreads();
-    double* dst = partials + ((int64_t)b * a.chunks + chunk) * kPartialStride;
-    if (tid < 29) {
-      double v = s_red[tid] + s_red[29 + tid] + s_red[58 + tid] + s_red[87 + tid];
-      dst[tid == 28 ? 35 : tid] = v;
-    } else if (tid >= 32 && tid < 39) {
-      dst[28 + (tid - 32)] = (double)shift[tid - 32];
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------------------
-// k_track_direct: streaming kernel without the LDS transpose.
+// k_track_direct: the streaming kernel.  grid.x = B * chunks; each 256-thread workgroup owns
+// `tiles_per_wg` tiles of 256 * UNROLL particles of ONE sample and every lane carries UNROLL
+// particles per iteration in registers.  There is no workgroup barrier in the loop, the map sits in
+// SGPRs (fp32) or is re-read from LDS (fp64), so occupancy -- not a tile pipeline -- hides the memory
+// latency; the loads of a tile are issued one iteration ahead of its use.
 //
-// Lane l of a wave owns particle (base + l): it loads its 7 scalars straight from HBM with
-// two (fp32: 16 B + 12 B) or four (fp64: 3 x 16 B + 8 B) dword-aligned vector loads.  A wave
-// instruction therefore sweeps a contiguous 64 x 28 B (or 56 B) span, every byte of every
-// 128-B line is consumed by the wave that touched it, and HBM traffic stays at the
-// algorithmic 2 x 7 x sizeof(T) per particle.  There is no barrier in the loop, the map
-// sits in SGPRs (fp32) or is re-read from LDS (fp64), so occupancy -- not a tile pipeline
-// -- hides the memory latency.  UNROLL particles per lane are in flight per iteration.
+// Two ways from HBM to a lane's registers (XPOSE):
+//
+//   false  lane l of a wave owns particles (base + l + 256 u): it loads its 7 scalars straight from
+//          HBM with two (fp32: 16 B + 12 B) or four (fp64: 3 x 16 B + 8 B) dword-aligned vector loads.
+//          A wave instruction sweeps a 64 x 28 B (56 B) span in 16-byte pieces 28 (56) bytes apart, i.e.
+//          every instruction touches every 128-B line of the span: traffic stays at the algorithmic
+//          2 x 7 x sizeof(T) per particle, but the address path works 2x (fp32) / 4x (fp64) harder
+//          per byte than a plain copy does.
+//   true   a WAVE owns 64 * P consecutive particles (P = 16 / sizeof(T): 4 fp32, 2 fp64) = 7168
+//          bytes = exactly seven full-width 1-KiB wave loads (global_load_dwordx4, every lane 16
+//          contiguous bytes: the access shape of the fastest plain copy).  The tile goes through a
+//          wave-PRIVATE 7-KiB LDS region as a flat array (ds_write_b128, conflict-free) and comes
+//          back transposed: lane l reads bytes [112 l, 112 l + 112) = its P consecutive particles
+//          (7 x ds_read_b128, 112-byte lane stride: conflict-free).  LDS operations of one wave
+//          execute in order, so no barrier is involved -- only a compiler fence.  Results leave
+//          the same way.  (Round 1's LDS-tiled kernel transposed per WORKGROUP, with three
+//          barriers per tile, and lost to the direct form; this one has none.)
+//          Needs UNROLL == P.  A wave tile that is cut by the end of the sample falls back to the
+//          per-particle accesses of the other form.
 //
 // MOM: 0 = no moments, 1 = float64 accumulation per particle, 2 = per-iteration float32
-// partial sums (UNROLL particles, shifted by the sample's reference point) folded into
+// partial sums (UNROLL particles, shifted by the wave's reference point) folded into
 // float64 accumulators once per iteration, 3 = float32 per-lane sums for the whole
 // workgroup lifetime (only chosen when a lane sees <= 32 particles; 58 fewer VGPRs), the
 // float64 part then starts at the workgroup reduction.
@@ -655,6 +566,8 @@ __global__ __launch_bounds__(kTrackThreads) void k_track(
 typedef float lynx_f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float lynx_f32x3u __attribute__((ext_vector_type(3), aligned(4)));
 typedef double lynx_f64x2u __attribute__((ext_vector_type(2), aligned(8)));
+typedef unsigned int lynx_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int lynx_u32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
 // A particle is 7 scalars = 28 / 56 bytes: it starts on a 4- / 8-byte boundary only, hence
 // the under-aligned vector types (global dwordx4 / dwordx3 / dwordx2 accesses need no more).
@@ -684,227 +597,121 @@ __device__ __forceinline__ void store_particle(double* p, const double (&z)[7]) 
   p[6] = z[6];
 }
 
+// -- wave tiles (XPOSE) -------------------------------------------------------------------
+constexpr int kWaveTileBytes = 7168;  // 64 lanes x 7 x 16 B = 64 * P particles of 7 scalars
+
+__device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+
+// seven full-width loads of the wave tile at `g` (dword-aligned)
+__device__ __forceinline__ void wave_tile_fetch(const void* g, int lane, lynx_u32x4 (&v)[7]) {
+  const lynx_u32x4u* src = reinterpret_cast<const lynx_u32x4u*>(g);
+#pragma unroll
+  for (int k = 0; k < 7; ++k) v[k] = src[k * 64 + lane];
+}
+__device__ __forceinline__ void wave_tile_store(void* g, int lane, const lynx_u32x4 (&v)[7]) {
+  lynx_u32x4u* dst = reinterpret_cast<lynx_u32x4u*>(g);
+#pragma unroll
+  for (int k = 0; k < 7; ++k) dst[k * 64 + lane] = v[k];
+}
+// flat tile (lane-interleaved 16-byte pieces) -> this lane's P consecutive particles, through the
+// wave's private LDS region
+template <typename T, int P>
+__device__ __forceinline__ void wave_tile_to_particles(const lynx_u32x4 (&v)[7], unsigned char* lds, int lane,
+                                                       T (&z)[P][7]) {
+  static_assert(P * 7 * sizeof(T) == 112, "a lane owns 112 bytes of the tile");
+  lynx_u32x4* l = reinterpret_cast<lynx_u32x4*>(lds);
+  wave_fence();  // earlier reads of the region (previous tile's results) are done
+#pragma unroll
+  for (int k = 0; k < 7; ++k) l[k * 64 + lane] = v[k];
+  wave_fence();
+  lynx_u32x4 w[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) w[k] = l[lane * 7 + k];
+  constexpr int PER = 16 / sizeof(T);  // scalars per 16-byte piece
+#pragma unroll
+  for (int f = 0; f < P * 7; ++f) {
+    const lynx_u32x4 q = w[f / PER];
+    if constexpr (sizeof(T) == 4) {
+      z[f / 7][f % 7] = __uint_as_float(q[f % PER]);
+    } else {
+      const unsigned long long bits = ((unsigned long long)q[(f % PER) * 2 + 1] << 32) | q[(f % PER) * 2];
+      z[f / 7][f % 7] = __longlong_as_double((long long)bits);
+    }
+  }
+}
+template <typename T, int P>
+__device__ __forceinline__ void wave_tile_from_particles(const T (&z)[P][7], unsigned char* lds, int lane,
+                                                         lynx_u32x4 (&v)[7]) {
+  lynx_u32x4* l = reinterpret_cast<lynx_u32x4*>(lds);
+  constexpr int PER = 16 / sizeof(T);
+  lynx_u32x4 w[7];
+#pragma unroll
+  for (int f = 0; f < P * 7; ++f) {
+    if constexpr (sizeof(T) == 4) {
+      w[f / PER][f % PER] = __float_as_uint(z[f / 7][f % 7]);
+    } else {
+      const unsigned long long bits = (unsigned long long)__double_as_longlong(z[f / 7][f % 7]);
+      w[f / PER][(f % PER) * 2] = (unsigned int)(bits & 0xffffffffull);
+      w[f / PER][(f % PER) * 2 + 1] = (unsigned int)(bits >> 32);
+    }
+  }
+  wave_fence();
+#pragma unroll
+  for (int k = 0; k < 7; ++k) l[lane * 7 + k] = w[k];
+  wave_fence();
+#pragma unroll
+  for (int k = 0; k < 7; ++k) v[k] = l[k * 64 + lane];
+}
+
 template <int MOM> struct MomScratch { using type = double; };
 template <> struct MomScratch<2> { using type = float; };  // float32 partial sums
 template <> struct MomScratch<3> { using type = float; };
 constexpr int kMomSlabScalars = 4 * 29 * 65;  // per workgroup, in units of MomScratch<MOM>::type
 
-template <typename T, int MOM, int UNROLL, bool FUSED>
-__global__ __launch_bounds__(kTrackThreads) void k_track_direct(
-    LatticeDev lat, TrackArgs a, const T* __restrict__ energy_in, const T* p_in, T* p_out,
-    T* __restrict__ energy_out, const T* __restrict__ steps_in, double* __restrict__ partials) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* s_scratch = reinterpret_cast<T*>(smem_raw);                   // build scratch / reduction
-  T* s_steps = s_scratch + a.lds_tile_scalars;                     // [S][64]
-  T* s_energy = s_steps + (size_t)lat.n_steps * LYNX_STEP_STRIDE;  // [S+1]
-
-  const int tid = threadIdx.x;
-  const int64_t b = blockIdx.x / a.chunks;
-  const int chunk = blockIdx.x % a.chunks;
-  const int64_t N = a.n_particles;
-  const int S = lat.n_steps;
-  // This workgroup's `a.tiles_per_wg` tiles of 256*UNROLL particles: either one contiguous
-  // stretch, or (a.interleave) every `chunks`-th tile, so that the workgroups of a sample
-  // advance through it side by side.
-  constexpr int64_t kTile = (int64_t)kTrackThreads * UNROLL;
-  const int64_t end = N;
-
-  // Software pipeline: the loads of a tile are issued one iteration ahead (the first ones
-  // right here, before the step table is fetched), so a workgroup always has a tile of HBM
-  // reads in flight while it computes and stores the previous one.
-  const T* src = p_in + b * a.in_stride;
-  T* dst = p_out + b * N * 7;
-  T zn[UNROLL][7];
-  {
-    const int64_t tile0 = a.interleave ? (int64_t)chunk : (int64_t)chunk * a.tiles_per_wg;
-    const int64_t i0 = tile0 * kTile + tid;
-#pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      const int64_t i = i0 + (int64_t)u * kTrackThreads;
-      load_particle(src + (i < end ? i : (i0 < end ? i0 : 0)) * 7, zn[u]);
-    }
-  }
-
-  const bool one_run = (S == 1) && (lat.steps[0].kind == LYNX_STEP_RUN);
-  constexpr bool kMapInRegs = sizeof(T) == 4;
-  // Pre-built single-run fp32 program: the map and the moment reference point come straight
-  // from the step table with wave-uniform (scalar) loads -- no LDS staging, no barrier.
-  constexpr bool kScalarTable = !FUSED && kMapInRegs;  // address space known at compile time
-  const bool scalar_table = kScalarTable && S > 0;
-  const T* g_steps = steps_in + b * (int64_t)S * LYNX_STEP_STRIDE;
-
-  if (FUSED) {
-    build_compose_sample<T>(lat, b, energy_in[b], s_steps, s_energy, s_scratch);
-    if (energy_out && chunk == 0 && tid == 0) energy_out[b] = s_energy[S];
-  } else if (S > 0 && !scalar_table) {
-    load_steps_sample<T>(g_steps, S, s_steps);
-  }
-
-  T m0[kMapInRegs ? 49 : 1];
-  if (one_run && kMapInRegs) {
-    if (scalar_table) {
-#pragma unroll
-      for (int i = 0; i < 49; ++i) m0[i] = uniform_value(g_steps[i]);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 49; ++i) m0[i] = uniform_value(s_steps[i]);
-    }
-  }
-
-  MomentAcc<T> acc;
-  T shift[7];
-  if (MOM) {
-    if (MOM != 3) acc.clear();
-    if (scalar_table) {
-#pragma unroll
-      for (int i = 0; i < 7; ++i) shift[i] = uniform_value(g_steps[LYNX_SHIFT_OFFSET + i]);
-    } else if (!FUSED && S > 0) {
-#pragma unroll
-      for (int i = 0; i < 7; ++i) shift[i] = s_steps[LYNX_SHIFT_OFFSET + i];  // from k_build
-    } else {
-      const T* p0 = p_in + b * a.in_stride;
-#pragma unroll
-      for (int i = 0; i < 7; ++i) shift[i] = p0[i];
-      apply_program<T>(lat, s_steps, shift);
-    }
-  }
-
+// Per-lane moment sums of the streaming kernel (see the MOM modes above).
+template <typename T, int MOM>
+struct LaneSums {
+  MomentAcc<T> acc;                                // MOM 1, 2
   float f_d[6], f_dd[21], f_one = 0.f, f_cnt = 0.f;  // MOM 2: per iteration, MOM 3: per workgroup
-  if (MOM == 3) {
+  __device__ __forceinline__ void clear_f() {
 #pragma unroll
     for (int k = 0; k < 6; ++k) f_d[k] = 0.f;
 #pragma unroll
     for (int k = 0; k < 21; ++k) f_dd[k] = 0.f;
+    f_one = 0.f;
   }
-  for (int it = 0; it < a.tiles_per_wg; ++it) {
-    const int64_t tile = a.interleave ? ((int64_t)it * a.chunks + chunk) : ((int64_t)chunk * a.tiles_per_wg + it);
-    const int64_t i0 = tile * kTile + tid;
-    if (i0 >= end) break;
-    if (!kMapInRegs) LYNX_FORGET();  // fp64: keep the map in LDS, not in 98 hoisted VGPRs
-    T z[UNROLL][7];
+  __device__ __forceinline__ void init() {
+    if (MOM == 1 || MOM == 2) acc.clear();
+    if (MOM == 3) clear_f();
+  }
+  __device__ __forceinline__ void begin_iteration() {
+    if (MOM == 2) clear_f();
+  }
+  __device__ __forceinline__ void add(const T (&z)[7], const T (&shift)[6]) {
+    if (MOM == 1) acc.add(z, shift);
+    if (MOM == 2 || MOM == 3) {
+      float e[6];
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u)
-#pragma unroll
-      for (int c = 0; c < 7; ++c) z[u][c] = zn[u][c];
-    if (it + 1 < a.tiles_per_wg) {  // prefetch the next tile of this workgroup
-      const int64_t tn = a.interleave ? ((int64_t)(it + 1) * a.chunks + chunk) : (tile + 1);
-      const int64_t j0 = tn * kTile + tid;
-#pragma unroll
-      for (int u = 0; u < UNROLL; ++u) {
-        const int64_t j = j0 + (int64_t)u * kTrackThreads;
-        load_particle(src + (j < end ? j : i0) * 7, zn[u]);
+      for (int k = 0; k < 6; ++k) {
+        e[k] = (float)(z[k] - shift[k]);
+        f_d[k] += e[k];
       }
+      f_one += (float)z[6];
+      // the 21 products of the upper triangle, spelled out (as nested loops with a running index the
+      // compiler left `e` in scratch memory once this moved into a member function)
+#define LYNX_DD(K, R, C) f_dd[K] = fmaf(e[R], e[C], f_dd[K]);
+      LYNX_DD(0, 0, 0) LYNX_DD(1, 0, 1) LYNX_DD(2, 0, 2) LYNX_DD(3, 0, 3) LYNX_DD(4, 0, 4) LYNX_DD(5, 0, 5)
+      LYNX_DD(6, 1, 1) LYNX_DD(7, 1, 2) LYNX_DD(8, 1, 3) LYNX_DD(9, 1, 4) LYNX_DD(10, 1, 5)
+      LYNX_DD(11, 2, 2) LYNX_DD(12, 2, 3) LYNX_DD(13, 2, 4) LYNX_DD(14, 2, 5)
+      LYNX_DD(15, 3, 3) LYNX_DD(16, 3, 4) LYNX_DD(17, 3, 5)
+      LYNX_DD(18, 4, 4) LYNX_DD(19, 4, 5)
+      LYNX_DD(20, 5, 5)
+#undef LYNX_DD
+      if (MOM == 2) acc.cnt += 1.0;
+      else f_cnt += 1.f;
     }
-    if (MOM == 2) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) f_d[k] = 0.f;
-#pragma unroll
-      for (int k = 0; k < 21; ++k) f_dd[k] = 0.f;
-      f_one = 0.f;
-    }
-    if (!one_run) {
-      // general program: steps outermost, so that each step's map is fetched once per
-      // iteration (fp32: 57 scalar loads into SGPRs; fp64: read from LDS) for all UNROLL
-      // particles of the lane; fp32 with an even UNROLL runs the particles as packed pairs
-      constexpr bool kPairs = kMapInRegs && UNROLL % 2 == 0;
-      lynx_f32x2 zp[kPairs ? UNROLL / 2 : 1][7];
-      if constexpr (kPairs) {
-#pragma unroll
-        for (int u = 0; u < UNROLL; u += 2)
-#pragma unroll
-          for (int c = 0; c < 7; ++c) zp[u / 2][c] = lynx_f32x2{(float)z[u][c], (float)z[u + 1][c]};
-      }
-      for (int sidx = 0; sidx < S; ++sidx) {
-        // merged [run, cavity] pair (see k_build): the run's slot holds the two rows that give the
-        // s and delta entering the cavity; they are formed first (their 14 scalars are dead before
-        // the 57 of the pair's map arrive: SGPRs are the scarce resource), then the loop moves on
-        // to the cavity's slot, which holds T_cav . T_run
-        bool merged = false;
-        lynx_f32x2 s_entry[kPairs ? UNROLL / 2 : 1], d_entry[kPairs ? UNROLL / 2 : 1];
-        lynx_step st = lat.steps[sidx];
-        if constexpr (kPairs && kScalarTable) {
-          if (a.merged_pairs && st.kind == LYNX_STEP_RUN && sidx + 1 < S &&
-              lat.steps[sidx + 1].kind == LYNX_STEP_CAVITY) {  // uniform
-            const float* tab = reinterpret_cast<const float*>(g_steps) + sidx * LYNX_STEP_STRIDE;
-            float pre[14];
-#pragma unroll
-            for (int q = 0; q < 14; ++q) pre[q] = uniform_value(tab[q]);
-#pragma unroll
-            for (int h = 0; h < UNROLL / 2; ++h) merged_pair_entry(pre, zp[h], s_entry[h], d_entry[h]);
-            merged = true;
-            ++sidx;
-            st = lat.steps[sidx];
-            LYNX_FORGET();
-          }
-        }
-        if constexpr (kMapInRegs) {
-          float m[57];
-          if (kScalarTable) {
-            const T* tab = g_steps + sidx * LYNX_STEP_STRIDE;  // global: s_load
-#pragma unroll
-            for (int q = 0; q < 57; ++q) m[q] = (float)uniform_value(tab[q]);
-          } else {
-            const T* tab = s_steps + sidx * LYNX_STEP_STRIDE;  // LDS
-#pragma unroll
-            for (int q = 0; q < 57; ++q) m[q] = (float)uniform_value(tab[q]);
-          }
-          if constexpr (kPairs) {
-#pragma unroll
-            for (int h = 0; h < UNROLL / 2; ++h)
-              apply_step_pair(m, st.kind, st.flags, zp[h], merged, s_entry[h], d_entry[h]);
-          } else {
-            float(&zf)[UNROLL][7] = reinterpret_cast<float(&)[UNROLL][7]>(z);
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u) apply_step<float>(m, st.kind, st.flags, zf[u]);
-          }
-        } else {
-          const T* tab = s_steps + sidx * LYNX_STEP_STRIDE;
-#pragma unroll
-          for (int u = 0; u < UNROLL; ++u) apply_step<T>(tab, st.kind, st.flags, z[u]);
-        }
-      }
-      if constexpr (kPairs) {
-#pragma unroll
-        for (int u = 0; u < UNROLL; u += 2)
-#pragma unroll
-          for (int c = 0; c < 7; ++c) {
-            z[u][c] = (T)zp[u / 2][c].x;
-            z[u + 1][c] = (T)zp[u / 2][c].y;
-          }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      const int64_t i = i0 + (int64_t)u * kTrackThreads;
-      const bool live = i < end;
-      if (one_run) {
-        if (kMapInRegs) apply_step<T>(m0, LYNX_STEP_RUN, 0, z[u]);
-        else apply_step<T>(s_steps, LYNX_STEP_RUN, 0, z[u]);
-      }
-      if (live) {
-        if (a.store) store_particle(dst + i * 7, z[u]);
-        if (MOM == 1) acc.add(z[u], shift);
-        if (MOM == 2 || MOM == 3) {
-          float e[6];
-#pragma unroll
-          for (int k = 0; k < 6; ++k) {
-            e[k] = (float)(z[u][k] - shift[k]);
-            f_d[k] += e[k];
-          }
-          f_one += (float)z[u][6];
-          int k = 0;
-#pragma unroll
-          for (int r = 0; r < 6; ++r)
-#pragma unroll
-            for (int c = r; c < 6; ++c) {
-              f_dd[k] = fmaf(e[r], e[c], f_dd[k]);
-              ++k;
-            }
-          if (MOM == 2) acc.cnt += 1.0;
-          else f_cnt += 1.f;
-        }
-      }
-    }
+  }
+  __device__ __forceinline__ void end_iteration() {
     if (MOM == 2) {
 #pragma unroll
       for (int k = 0; k < 6; ++k) acc.d[k] += (double)f_d[k];
@@ -913,17 +720,8 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_direct(
       acc.one += (double)f_one;
     }
   }
-
-  if (MOM) {
-    // Workgroup reduction of the 29 sums through LDS: every lane parks its values in a
-    // [29][65] slab of its wave (row pitch 65 -> conflict-free both ways), lanes 0..28 then
-    // each add up one row in float64.  A 64-lane shuffle tree of 29 values costs ~350
-    // ds_bpermute per wave; this costs 29 stores and 64 loads per lane and is the larger part
-    // of a workgroup's fixed cost when it only owns a few thousand particles.
-    using R = typename MomScratch<MOM>::type;
-    const int wave = tid >> 6, lane = tid & 63;
-    __syncthreads();  // the build scratch is reused
-    R* slab = reinterpret_cast<R*>(s_scratch) + wave * (29 * 65);
+  // value of slot i (0..5 d, 6 one, 7..27 dd, 28 count) as parked in the reduction slab
+  template <typename R> __device__ __forceinline__ void park(R* slab, int lane) const {
     if (MOM == 3) {
 #pragma unroll
       for (int i = 0; i < 6; ++i) slab[i * 65 + lane] = (R)f_d[i];
@@ -939,6 +737,299 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_direct(
       for (int i = 0; i < 21; ++i) slab[(7 + i) * 65 + lane] = (R)acc.dd[i];
       slab[28 * 65 + lane] = (R)acc.cnt;
     }
+  }
+};
+
+// the whole program on the UNROLL particles a lane holds in registers: steps outermost, so that each
+// step's map is fetched once per iteration (fp32: 57 scalar loads into SGPRs; fp64: read from LDS) for
+// all of them; fp32 with an even UNROLL runs the particles as packed pairs
+template <typename T, int UNROLL, bool SCALAR_TABLE>
+__device__ __forceinline__ void apply_program_lane(const LatticeDev& lat, int S, const T* g_steps, const T* s_steps,
+                                                   int merged_pairs, T (&z)[UNROLL][7]) {
+  constexpr bool kMapInRegs = sizeof(T) == 4;
+  constexpr bool kPairs = kMapInRegs && UNROLL % 2 == 0;
+  lynx_f32x2 zp[kPairs ? UNROLL / 2 : 1][7];
+  if constexpr (kPairs) {
+#pragma unroll
+    for (int u = 0; u < UNROLL; u += 2)
+#pragma unroll
+      for (int c = 0; c < 7; ++c) {  // member-wise: the brace initialiser sent z to scratch memory here
+        zp[u / 2][c].x = (float)z[u][c];
+        zp[u / 2][c].y = (float)z[u + 1][c];
+      }
+  }
+  for (int sidx = 0; sidx < S; ++sidx) {
+    // merged [run, cavity] pair (see k_build): the run's slot holds the two rows that give the
+    // s and delta entering the cavity; they are formed first (their 14 scalars are dead before
+    // the 57 of the pair's map arrive: SGPRs are the scarce resource), then the loop moves on
+    // to the cavity's slot, which holds T_cav . T_run
+    bool merged = false;
+    lynx_f32x2 s_entry[kPairs ? UNROLL / 2 : 1], d_entry[kPairs ? UNROLL / 2 : 1];
+    lynx_step st = lat.steps[sidx];
+    if constexpr (kPairs && SCALAR_TABLE) {
+      if (merged_pairs && st.kind == LYNX_STEP_RUN && sidx + 1 < S &&
+          lat.steps[sidx + 1].kind == LYNX_STEP_CAVITY) {  // uniform
+        const float* tab = reinterpret_cast<const float*>(g_steps) + sidx * LYNX_STEP_STRIDE;
+        float pre[14];
+#pragma unroll
+        for (int q = 0; q < 14; ++q) pre[q] = uniform_value(tab[q]);
+#pragma unroll
+        for (int h = 0; h < UNROLL / 2; ++h) merged_pair_entry(pre, zp[h], s_entry[h], d_entry[h]);
+        merged = true;
+        ++sidx;
+        st = lat.steps[sidx];
+        LYNX_FORGET();
+      }
+    }
+    if constexpr (kMapInRegs) {
+      T m[57];  // T = float here
+      if (SCALAR_TABLE) {
+        const T* tab = g_steps + sidx * LYNX_STEP_STRIDE;  // global: s_load
+#pragma unroll
+        for (int q = 0; q < 57; ++q) m[q] = uniform_value(tab[q]);
+      } else {
+        const T* tab = s_steps + sidx * LYNX_STEP_STRIDE;  // LDS
+#pragma unroll
+        for (int q = 0; q < 57; ++q) m[q] = uniform_value(tab[q]);
+      }
+      if constexpr (kPairs) {
+#pragma unroll
+        for (int h = 0; h < UNROLL / 2; ++h)
+          apply_step_pair(m, st.kind, st.flags, zp[h], merged, s_entry[h], d_entry[h]);
+      } else {
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) apply_step<T>(m, st.kind, st.flags, z[u]);
+      }
+    } else {
+      const T* tab = s_steps + sidx * LYNX_STEP_STRIDE;
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) apply_step<T>(tab, st.kind, st.flags, z[u]);
+    }
+  }
+  if constexpr (kPairs) {
+#pragma unroll
+    for (int u = 0; u < UNROLL; u += 2)
+#pragma unroll
+      for (int c = 0; c < 7; ++c) {
+        z[u][c] = (T)zp[u / 2][c].x;
+        z[u + 1][c] = (T)zp[u / 2][c].y;
+      }
+  }
+}
+
+template <typename T, int MOM, int UNROLL, bool FUSED, bool XPOSE>
+__global__ __launch_bounds__(kTrackThreads, (XPOSE ? 3 : 1)) void k_track_direct(
+    LatticeDev lat, TrackArgs a, const T* __restrict__ energy_in, const T* p_in, T* p_out,
+    T* __restrict__ energy_out, const T* __restrict__ steps_in, double* __restrict__ partials) {
+  static_assert(!XPOSE || (UNROLL * 7 * sizeof(T) == 112 && !FUSED), "XPOSE: a lane owns 112 bytes");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned char* s_scratch = smem_raw;                                 // build scratch / wave tiles / reduction
+  T* s_steps = reinterpret_cast<T*>(smem_raw + a.lds_scratch_bytes);    // [S][64]
+  T* s_energy = s_steps + (size_t)lat.n_steps * LYNX_STEP_STRIDE;       // [S+1]
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int64_t b = blockIdx.x / a.chunks;
+  const int chunk = blockIdx.x % a.chunks;
+  const int64_t end = a.n_particles;
+  const int S = lat.n_steps;
+  // This workgroup's `a.tiles_per_wg` tiles of 256*UNROLL particles: either one contiguous
+  // stretch, or (a.interleave) every `chunks`-th tile, so that the workgroups of a sample
+  // advance through it side by side.
+  constexpr int64_t kTile = (int64_t)kTrackThreads * UNROLL;
+  constexpr int64_t kWaveSpan = 64 * UNROLL;  // XPOSE: particles of a wave tile
+  // first particle of this lane within a tile, and the distance between its UNROLL particles
+  const int64_t lane_first = XPOSE ? (int64_t)wave * kWaveSpan + (int64_t)lane * UNROLL : (int64_t)tid;
+  constexpr int64_t kLaneStep = XPOSE ? 1 : kTrackThreads;
+  unsigned char* s_wave = s_scratch + wave * kWaveTileBytes;  // XPOSE: this wave's private tile
+#define LYNX_TILE_OF(IT) (a.interleave ? ((int64_t)(IT)*a.chunks + chunk) : ((int64_t)chunk * a.tiles_per_wg + (IT)))
+#define LYNX_WAVE_BASE(TILE) ((TILE)*kTile + (int64_t)wave * kWaveSpan)
+
+  // Software pipeline: the loads of a tile are issued one iteration ahead (the first ones
+  // right here, before the step table is fetched), so a workgroup always has a tile of HBM
+  // reads in flight while it computes and stores the previous one.
+  const T* src = p_in + b * a.in_stride;
+  T* dst = p_out + b * end * 7;
+  T zn[XPOSE ? 1 : UNROLL][7];   // !XPOSE: the next tile's particles
+  lynx_u32x4 vn[XPOSE ? 7 : 1];  //  XPOSE: the next wave tile, flat
+  {
+    const int64_t tile = LYNX_TILE_OF(0);
+    if constexpr (XPOSE) {
+      if (LYNX_WAVE_BASE(tile) + kWaveSpan <= end) wave_tile_fetch(src + LYNX_WAVE_BASE(tile) * 7, lane, vn);
+    } else {
+      const int64_t i0 = tile * kTile + lane_first;
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        const int64_t i = i0 + (int64_t)u * kLaneStep;
+        load_particle(src + (i < end ? i : (i0 < end ? i0 : 0)) * 7, zn[u]);
+      }
+    }
+  }
+
+  const bool one_run = (S == 1) && (lat.steps[0].kind == LYNX_STEP_RUN);
+  constexpr bool kMapInRegs = sizeof(T) == 4;
+  // Pre-built single-run fp32 program: the map comes straight from the step table with
+  // wave-uniform (scalar) loads -- no LDS staging, no barrier.
+  constexpr bool kScalarTable = !FUSED && kMapInRegs;  // address space known at compile time
+  const bool scalar_table = kScalarTable && S > 0;
+  const T* g_steps = steps_in + b * (int64_t)S * LYNX_STEP_STRIDE;
+
+  if (FUSED) {
+    build_compose_sample<T>(lat, b, energy_in[b], s_steps, s_energy, s_scratch, a.build_chunk);
+    if (energy_out && chunk == 0 && tid == 0) energy_out[b] = s_energy[S];
+  } else if (S > 0) {
+    if (!scalar_table) load_steps_sample<T>(g_steps, S, s_steps);
+    // the beam energy behind the last step was parked in the table by k_build
+    if (energy_out && chunk == 0 && tid == 0) energy_out[b] = g_steps[(S - 1) * LYNX_STEP_STRIDE + LYNX_ENERGY_OFFSET];
+  }
+
+  T m0[kMapInRegs ? 49 : 1];
+  if (one_run && kMapInRegs) {
+    if (scalar_table) {
+#pragma unroll
+      for (int i = 0; i < 49; ++i) m0[i] = uniform_value(g_steps[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 49; ++i) m0[i] = uniform_value(s_steps[i]);
+    }
+  }
+
+  LaneSums<T, MOM> sums;
+  sums.init();
+  T shift[6];  // this wave's reference point: its first tracked particle (wave-uniform)
+#pragma unroll
+  for (int i = 0; i < 6; ++i) shift[i] = T(0);
+
+  // float64 wave tiles stay in LDS and the lane's two particles are taken one after the other (two
+  // float64 particles + the prefetched tile + 29 float64 sums do not fit the registers of 3 waves/SIMD)
+  constexpr bool kLdsResident = XPOSE && sizeof(T) == 8;
+
+  for (int it = 0; it < a.tiles_per_wg; ++it) {
+    const int64_t tile = LYNX_TILE_OF(it);
+    const int64_t i0 = tile * kTile + lane_first;
+    if (XPOSE ? (LYNX_WAVE_BASE(tile) >= end) : (i0 >= end)) break;
+    if (!kMapInRegs) LYNX_FORGET();  // fp64: keep the map in LDS, not in 98 hoisted VGPRs
+    const bool full = XPOSE && (LYNX_WAVE_BASE(tile) + kWaveSpan <= end);  // wave-uniform
+    sums.begin_iteration();
+
+    if constexpr (kLdsResident) {
+      T* mine = reinterpret_cast<T*>(s_wave) + lane * (UNROLL * 7);  // this lane's particles inside the tile
+      if (full) {
+        lynx_u32x4* l = reinterpret_cast<lynx_u32x4*>(s_wave);
+        wave_fence();
+#pragma unroll
+        for (int k = 0; k < 7; ++k) l[k * 64 + lane] = vn[k];
+        wave_fence();
+      }
+      if (it + 1 < a.tiles_per_wg) {
+        const int64_t tn = LYNX_TILE_OF(it + 1);
+        if (LYNX_WAVE_BASE(tn) + kWaveSpan <= end) wave_tile_fetch(src + LYNX_WAVE_BASE(tn) * 7, lane, vn);
+      }
+#pragma unroll 1
+      for (int u = 0; u < UNROLL; ++u) {  // one particle at a time: register pressure, not issue rate, is what binds here
+        const int64_t i = i0 + u;
+        T z[1][7];
+        if (full) {
+#pragma unroll
+          for (int c = 0; c < 7; ++c) z[0][c] = mine[u * 7 + c];
+        } else {
+          load_particle(src + (i < end ? i : end - 1) * 7, z[0]);
+        }
+        if (one_run) apply_step<T>(s_steps, LYNX_STEP_RUN, 0, z[0]);
+        else apply_program_lane<T, 1, false>(lat, S, g_steps, s_steps, 0, z);
+        if (MOM && it == 0 && u == 0) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) shift[k] = wave_first(z[0][k]);
+        }
+        if (i < end) {
+          if (MOM) sums.add(z[0], shift);
+          if (a.store) {
+            if (full) {
+#pragma unroll
+              for (int c = 0; c < 7; ++c) mine[u * 7 + c] = z[0][c];
+            } else {
+              store_particle(dst + i * 7, z[0]);
+            }
+          }
+        }
+      }
+      if (a.store && full) {
+        lynx_u32x4 vo[7];
+        const lynx_u32x4* l = reinterpret_cast<const lynx_u32x4*>(s_wave);
+        wave_fence();
+#pragma unroll
+        for (int k = 0; k < 7; ++k) vo[k] = l[k * 64 + lane];
+        wave_tile_store(dst + LYNX_WAVE_BASE(tile) * 7, lane, vo);
+      }
+    } else {
+      T z[UNROLL][7];
+      if constexpr (XPOSE) {
+        if (full) {
+          wave_tile_to_particles<T, UNROLL>(vn, s_wave, lane, z);
+        } else {
+#pragma unroll
+          for (int u = 0; u < UNROLL; ++u) load_particle(src + (i0 + u < end ? i0 + u : end - 1) * 7, z[u]);
+        }
+        if (it + 1 < a.tiles_per_wg) {
+          const int64_t tn = LYNX_TILE_OF(it + 1);
+          if (LYNX_WAVE_BASE(tn) + kWaveSpan <= end) wave_tile_fetch(src + LYNX_WAVE_BASE(tn) * 7, lane, vn);
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+          for (int c = 0; c < 7; ++c) z[u][c] = zn[u][c];
+        if (it + 1 < a.tiles_per_wg) {  // prefetch the next tile of this workgroup
+          const int64_t j0 = LYNX_TILE_OF(it + 1) * kTile + lane_first;
+#pragma unroll
+          for (int u = 0; u < UNROLL; ++u) {
+            const int64_t j = j0 + (int64_t)u * kLaneStep;
+            load_particle(src + (j < end ? j : i0) * 7, zn[u]);
+          }
+        }
+      }
+      if (!one_run) apply_program_lane<T, UNROLL, kScalarTable>(lat, S, g_steps, s_steps, a.merged_pairs, z);
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        const int64_t i = i0 + (int64_t)u * kLaneStep;
+        if (one_run) {
+          if (kMapInRegs) apply_step<T>(m0, LYNX_STEP_RUN, 0, z[u]);
+          else apply_step<T>(s_steps, LYNX_STEP_RUN, 0, z[u]);
+        }
+        if (MOM && it == 0 && u == 0) {
+          // reference point of this wave's sums: the tracked particle of its first lane (which exists
+          // whenever any of the wave's particles does: indices grow with the lane)
+#pragma unroll
+          for (int k = 0; k < 6; ++k) shift[k] = wave_first(z[0][k]);
+        }
+        if (i < end) {
+          if (a.store && !(XPOSE && full)) store_particle(dst + i * 7, z[u]);
+          if (MOM) sums.add(z[u], shift);
+        }
+      }
+      if constexpr (XPOSE) {
+        if (a.store && full) {
+          lynx_u32x4 vo[7];
+          wave_tile_from_particles<T, UNROLL>(z, s_wave, lane, vo);
+          wave_tile_store(dst + LYNX_WAVE_BASE(tile) * 7, lane, vo);
+        }
+      }
+    }
+    sums.end_iteration();
+  }
+#undef LYNX_TILE_OF
+#undef LYNX_WAVE_BASE
+
+  if (MOM) {
+    // Workgroup reduction of the 29 sums through LDS: every lane parks its values in a
+    // [29][65] slab of its wave (row pitch 65 -> conflict-free both ways), lanes 0..28 then
+    // each add up one row in float64.  A 64-lane shuffle tree of 29 values costs ~350
+    // ds_bpermute per wave; this costs 29 stores and 64 loads per lane and is the larger part
+    // of a workgroup's fixed cost when it only owns a few thousand particles.
+    using R = typename MomScratch<MOM>::type;
+    __syncthreads();  // the scratch (build scratch / wave tiles) is reused
+    R* slab = reinterpret_cast<R*>(s_scratch) + wave * (29 * 65);
+    sums.park(slab, lane);
     __syncthreads();
     double tot = 0.0;
     if (lane < 29) {
@@ -947,15 +1038,30 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_direct(
       for (int k = 0; k < 64; ++k) tot += (double)row[k];
     }
     __syncthreads();
-    double* s_red = reinterpret_cast<double*>(s_scratch);  // 4 waves x 29
-    if (lane < 29) s_red[wave * 29 + lane] = tot;
+    // one record per wave (layout of moment_slot_moved), then the four are moved to wave 0's
+    // reference point and added in wave order
+    double* s_red = reinterpret_cast<double*>(s_scratch);  // [4][36]
+    if (lane < 28) s_red[wave * kPartialStride + lane] = tot;
+    if (lane == 28) s_red[wave * kPartialStride + 35] = tot;
+    // lane 0 publishes the reference point: it was assigned inside the loop, where lanes beyond the
+    // end of the sample are no longer active and so never received it
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) s_red[wave * kPartialStride + 28 + k] = (double)shift[k];
+      s_red[wave * kPartialStride + 34] = 0.0;
+    }
     __syncthreads();
     double* out = partials + ((int64_t)b * a.chunks + chunk) * kPartialStride;
-    if (tid < 29) {
-      double v = s_red[tid] + s_red[29 + tid] + s_red[58 + tid] + s_red[87 + tid];
-      out[tid == 28 ? 35 : tid] = v;
-    } else if (tid >= 32 && tid < 39) {
-      out[28 + (tid - 32)] = (double)shift[tid - 32];
+    if (tid < kPartialStride) {
+      double v;
+      if (tid >= 28 && tid < 35) {
+        v = s_red[tid];
+      } else {
+        v = 0.0;
+#pragma unroll
+        for (int w = 0; w < kTrackThreads / 64; ++w) v += moment_slot_moved(s_red + w * kPartialStride, s_red + 28, tid);
+      }
+      out[tid] = v;
     }
   }
 }
@@ -963,8 +1069,9 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_direct(
 // ---------------------------------------------------------------------------------------
 // k_finalize_moments: partials [B][chunks][36] -> moment records [B][36].
 // One workgroup per sample: 28 groups of 36 threads; thread (g, j) adds value j of the chunks
-// g, g + 28, ... (a group reads 36 consecutive doubles per chunk: coalesced), the 28 group sums
-// are then added in group order -- fixed assignment and order, no float atomics.
+// g, g + 28, ... (a group reads 36 consecutive doubles per chunk: coalesced), each moved to the
+// reference point of chunk 0 (moment_slot_moved); the 28 group sums are then added in group
+// order -- fixed assignment and order, no float atomics.
 // (The first version gave every thread whole rows and finished with 29 x 6 64-lane shuffles:
 // 12.6 us for the 131 chunks of BASELINE config 2, more than its streaming kernel.)
 // ---------------------------------------------------------------------------------------
@@ -992,24 +1099,28 @@ __global__ __launch_bounds__(1024) void k_finalize_moments(const double* __restr
                                                             int chunks, double* __restrict__ out) {
   __shared__ double s_g[kFinalGroups][kPartialStride];
   __shared__ double s[kPartialStride];
+  __shared__ double s_c0[8];
   const int64_t b = blockIdx.x;
   const int tid = threadIdx.x;
   const int g = tid / kPartialStride, j = tid - g * kPartialStride;
   const double* src = partials + b * (int64_t)chunks * kPartialStride;
+  if (tid < 7) s_c0[tid] = src[28 + tid];  // reference point of chunk 0
+  __syncthreads();
   if (g < kFinalGroups) {
     double v = 0.0;
     if (j < 28 || j == 35) {
-      // 8 independent loads in flight, added in chunk order (a B = 1 beam of 8 M particles has
+      // 4 independent rows in flight, added in chunk order (a B = 1 beam of 8 M particles has
       // ~8000 chunks: one load per latency made this kernel as long as half the streaming pass)
       int c = g;
-      for (; c + 7 * kFinalGroups < chunks; c += 8 * kFinalGroups) {
-        double t[8];
+      for (; c + 3 * kFinalGroups < chunks; c += 4 * kFinalGroups) {
+        double t[4];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) t[q] = src[(int64_t)(c + q * kFinalGroups) * kPartialStride + j];
+        for (int q = 0; q < 4; ++q)
+          t[q] = moment_slot_moved(src + (int64_t)(c + q * kFinalGroups) * kPartialStride, s_c0, j);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v += t[q];
+        for (int q = 0; q < 4; ++q) v += t[q];
       }
-      for (; c < chunks; c += kFinalGroups) v += src[(int64_t)c * kPartialStride + j];
+      for (; c < chunks; c += kFinalGroups) v += moment_slot_moved(src + (int64_t)c * kPartialStride, s_c0, j);
     }
     s_g[g][j] = v;
   }
@@ -1017,7 +1128,7 @@ __global__ __launch_bounds__(1024) void k_finalize_moments(const double* __restr
   if (tid < kPartialStride) {
     double v;
     if (tid >= 28 && tid < 35) {
-      v = src[tid];  // shift: identical in every chunk
+      v = s_c0[tid - 28];
     } else {
       v = 0.0;
 #pragma unroll
@@ -1029,29 +1140,44 @@ __global__ __launch_bounds__(1024) void k_finalize_moments(const double* __restr
   write_moment_record(s, out + b * LYNX_MOMENT_STRIDE, tid);
 }
 
-// Few chunks per sample (<= 64): one wave per sample, lane j owns value j and adds the
-// chunks in order (the loads are independent, only the adds chain).
-__global__ __launch_bounds__(64) void k_finalize_moments_small(const double* __restrict__ partials,
-                                                                int chunks, double* __restrict__ out) {
+// Few chunks per sample (<= 64): 256 threads per sample = 7 groups of 36; thread (g, j) adds value j of
+// chunks g, g + 7, ... with all its loads in flight at once (<= 10 rows), the group sums are added in
+// group order.  (One wave per sample with the chunks in sequence took 7-18 us on BASELINE config 4.)
+constexpr int kFinalSmallGroups = 7;
+__global__ __launch_bounds__(256) void k_finalize_moments_small(const double* __restrict__ partials,
+                                                                 int chunks, double* __restrict__ out) {
+  __shared__ double s_g[kFinalSmallGroups][kPartialStride];
   __shared__ double s[kPartialStride];
+  __shared__ double s_c0[8];
   const int64_t b = blockIdx.x;
   const int tid = threadIdx.x;
+  const int g = tid / kPartialStride, j = tid - g * kPartialStride;
   const double* src = partials + b * (int64_t)chunks * kPartialStride;
+  if (tid < 7) s_c0[tid] = src[28 + tid];
+  __syncthreads();
+  if (g < kFinalSmallGroups) {
+    double v = 0.0;
+    if (j < 28 || j == 35) {
+      double t[10];
+#pragma unroll
+      for (int q = 0; q < 10; ++q) {
+        const int c = g + q * kFinalSmallGroups;
+        t[q] = c < chunks ? moment_slot_moved(src + (int64_t)c * kPartialStride, s_c0, j) : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 10; ++q) v += t[q];
+    }
+    s_g[g][j] = v;
+  }
+  __syncthreads();
   if (tid < kPartialStride) {
     double v;
     if (tid >= 28 && tid < 35) {
-      v = src[tid];
+      v = s_c0[tid - 28];
     } else {
       v = 0.0;
-      int c = 0;
-      for (; c + 8 <= chunks; c += 8) {  // 8 loads in flight, added in chunk order
-        double t[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) t[q] = src[(int64_t)(c + q) * kPartialStride + tid];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v += t[q];
-      }
-      for (; c < chunks; ++c) v += src[(int64_t)c * kPartialStride + tid];
+      for (int q = 0; q < kFinalSmallGroups; ++q) v += s_g[q][tid];
     }
     s[tid] = v;
   }
@@ -1070,9 +1196,8 @@ __global__ __launch_bounds__(256) void k_track_moments(LatticeDev lat, const T* 
                                                        const T* mu_in, const T* cov_in, T* mu_out,
                                                        T* cov_out, T* __restrict__ energy_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* s_scratch = reinterpret_cast<T*>(smem_raw);
   const int chunk = build_chunk(lat.n_elems);
-  T* s_steps = s_scratch + build_scratch_scalars(chunk);
+  T* s_steps = reinterpret_cast<T*>(smem_raw + build_scratch_bytes(chunk, sizeof(T)));
   T* s_energy = s_steps + (size_t)lat.n_steps * LYNX_STEP_STRIDE;
   T* s_mu = s_energy + lat.n_steps + 1;  // 8
   T* s_cov = s_mu + 8;                   // 49
@@ -1081,7 +1206,7 @@ __global__ __launch_bounds__(256) void k_track_moments(LatticeDev lat, const T* 
 
   const int64_t b = blockIdx.x;
   const int lane = threadIdx.x;
-  build_compose_sample<T>(lat, b, energy_in[b], s_steps, s_energy, s_scratch, chunk);
+  build_compose_sample<T>(lat, b, energy_in[b], s_steps, s_energy, smem_raw, chunk);
 
   if (lane < 7) s_mu[lane] = mu_in[b * 7 + lane];
   if (lane < 49) s_cov[lane] = cov_in[b * 49 + lane];

@@ -10,7 +10,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
+#include <type_traits>
 #include <unordered_map>
 #include <vector>
 
@@ -22,6 +24,21 @@ using namespace lynx;
 struct lynx_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  // Second stream for k_build.  The map build of a `track` call depends on the lattice and the
+  // incoming energy only, so it runs underneath the previous call's streaming kernel:
+  //   s_build:  [wait: table slot free] k_build(n) -> table[n & 1]            record ev_built
+  //   stream :  [wait ev_built] k_track_direct(n), k_finalize(n)               record ev_streamed
+  // Every build is followed at once by the main stream's wait on it, so anything enqueued on the
+  // main stream later (copies, other kernels, lynx_sync) is ordered after every build so far.  The
+  // build stream in turn waits for the main stream when (a) it reuses a table slot (ev_streamed) or
+  // (b) the main stream may have written what the build reads (`main_dirty`, `main_wrote`).
+  hipStream_t s_build = nullptr;
+  hipEvent_t ev_built[2] = {nullptr, nullptr}, ev_streamed[2] = {nullptr, nullptr}, ev_mark = nullptr;
+  bool streamed_valid[2] = {false, false};
+  unsigned seq = 0;
+  bool main_dirty = false;            // unsynchronised device writes on the main stream (any buffer)
+  const void* main_wrote = nullptr;   // energy buffer the last streaming kernel published on the main stream
+  std::mutex mu;                      // allocator maps: finalizers may run on other threads
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   std::string err;
   hipDeviceProp_t prop;
@@ -31,8 +48,8 @@ struct lynx_ctx {
   // internal scratch (grown on demand, stream-ordered reuse)
   void* scratch_partials = nullptr;
   size_t scratch_partials_bytes = 0;
-  void* scratch_steps = nullptr;
-  size_t scratch_steps_bytes = 0;
+  void* scratch_steps[3] = {nullptr, nullptr, nullptr};  // two alternating step tables + the reverse pass's own
+  size_t scratch_steps_bytes[3] = {0, 0, 0};
   void* scratch_grad[3] = {nullptr, nullptr, nullptr};  // backward: partials, T_bar, build scratch
   size_t scratch_grad_bytes[3] = {0, 0, 0};
   ncclComm_t comm = nullptr;
@@ -89,6 +106,7 @@ static size_t size_class(size_t bytes) {
 }
 
 static int ctx_alloc(lynx_ctx* ctx, size_t bytes, void** out) {
+  std::lock_guard<std::mutex> lock(ctx->mu);
   const size_t sc = size_class(bytes);
   auto it = ctx->free_blocks.find(sc);
   if (it != ctx->free_blocks.end()) {
@@ -114,6 +132,7 @@ static int ctx_alloc(lynx_ctx* ctx, size_t bytes, void** out) {
 
 static int ctx_free(lynx_ctx* ctx, void* p) {
   if (!p) return LYNX_OK;
+  std::lock_guard<std::mutex> lock(ctx->mu);
   auto it = ctx->live.find(p);
   if (it == ctx->live.end()) return fail(ctx, LYNX_ERR_INVALID, "lynx_buf_free: unknown pointer");
   ctx->free_blocks.emplace(it->second, p);
@@ -124,6 +143,7 @@ static int ctx_free(lynx_ctx* ctx, void* p) {
 static int ensure_scratch(lynx_ctx* ctx, void** buf, size_t* have, size_t need) {
   if (*have >= need) return LYNX_OK;
   if (*buf) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->s_build));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipFree(*buf));
     *buf = nullptr;
@@ -161,6 +181,12 @@ int lynx_ctx_create(int device, lynx_ctx** out) {
   HIP_TRY(nullptr, hipSetDevice(device));
   HIP_TRY(nullptr, hipGetDeviceProperties(&ctx->prop, device));
   HIP_TRY(nullptr, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  HIP_TRY(nullptr, hipStreamCreateWithFlags(&ctx->s_build, hipStreamNonBlocking));
+  for (int i = 0; i < 2; ++i) {
+    HIP_TRY(nullptr, hipEventCreateWithFlags(&ctx->ev_built[i], hipEventDisableTiming));
+    HIP_TRY(nullptr, hipEventCreateWithFlags(&ctx->ev_streamed[i], hipEventDisableTiming));
+  }
+  HIP_TRY(nullptr, hipEventCreateWithFlags(&ctx->ev_mark, hipEventDisableTiming));
   HIP_TRY(nullptr, hipEventCreate(&ctx->ev_start));
   HIP_TRY(nullptr, hipEventCreate(&ctx->ev_stop));
   *out = ctx;
@@ -170,16 +196,24 @@ int lynx_ctx_create(int device, lynx_ctx** out) {
 int lynx_ctx_destroy(lynx_ctx* ctx) {
   if (!ctx) return LYNX_OK;
   (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->s_build);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
   for (auto& kv : ctx->free_blocks) (void)hipFree(kv.second);
   for (auto& kv : ctx->live) (void)hipFree(kv.first);
   if (ctx->scratch_partials) (void)hipFree(ctx->scratch_partials);
-  if (ctx->scratch_steps) (void)hipFree(ctx->scratch_steps);
-  for (int i = 0; i < 3; ++i)
+  for (int i = 0; i < 3; ++i) {
+    if (ctx->scratch_steps[i]) (void)hipFree(ctx->scratch_steps[i]);
     if (ctx->scratch_grad[i]) (void)hipFree(ctx->scratch_grad[i]);
+  }
+  for (int i = 0; i < 2; ++i) {
+    (void)hipEventDestroy(ctx->ev_built[i]);
+    (void)hipEventDestroy(ctx->ev_streamed[i]);
+  }
+  (void)hipEventDestroy(ctx->ev_mark);
   (void)hipEventDestroy(ctx->ev_start);
   (void)hipEventDestroy(ctx->ev_stop);
+  (void)hipStreamDestroy(ctx->s_build);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return LYNX_OK;
@@ -266,17 +300,21 @@ int lynx_buf_d2h(lynx_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
 int lynx_buf_d2d(lynx_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) {
   if (bytes == 0) return LYNX_OK;
   HIP_TRY(ctx, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  ctx->main_dirty = true;
   return LYNX_OK;
 }
 
 int lynx_buf_memset(lynx_ctx* ctx, void* d_dst, int value, size_t bytes) {
   if (bytes == 0) return LYNX_OK;
   HIP_TRY(ctx, hipMemsetAsync(d_dst, value, bytes, ctx->stream));
+  ctx->main_dirty = true;
   return LYNX_OK;
 }
 
 int lynx_pool_trim(lynx_ctx* ctx) {
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->s_build));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  std::lock_guard<std::mutex> lock(ctx->mu);
   for (auto& kv : ctx->free_blocks) (void)hipFree(kv.second);
   ctx->free_blocks.clear();
   return LYNX_OK;
@@ -422,16 +460,37 @@ static int allow_lds(lynx_ctx* ctx, K kernel, size_t bytes) {
 
 // ---- build + compose -------------------------------------------------------------------
 
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+
+// Launch shape of k_build: 256 threads and chunks of <= 64 elements (<= 32 for float32 lattices, whose
+// staging area would otherwise halve the resident workgroups) when the batch fills the GPU; 1024
+// threads and chunks of <= 128 when it does not -- then the tree depth is what a call waits for.
 template <typename T>
-static int launch_build(lynx_ctx* ctx, lynx_lattice* lat, const void* d_energy_in, void* d_steps_out,
-                        void* d_energy_out, const void* d_p_first = nullptr, int64_t sample_stride = 0,
-                        int merge_pairs = 0) {
-  const size_t lds = ((size_t)kBuildScratch + (size_t)lat->n_steps * LYNX_STEP_STRIDE + lat->n_steps + 1) * sizeof(T);
+static void build_shape(lynx_ctx* ctx, const lynx_lattice* lat, int* threads, int* chunk) {
+  const int64_t cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+  const bool wide = lat->batch * 2 <= cus;
+  *threads = wide ? 1024 : 256;
+  int limit = wide ? 128 : (sizeof(T) == 4 ? 32 : 64);
+  limit = env_int("LYNX_BUILD_CHUNK", limit);
+  if (limit > *threads) limit = *threads;
+  if (limit < 2) limit = 2;
+  *chunk = build_chunk(lat->n_elems, limit);
+}
+
+template <typename T>
+static int launch_build(lynx_ctx* ctx, lynx_lattice* lat, hipStream_t stream, const void* d_energy_in,
+                        void* d_steps_out, void* d_energy_out, int merge_pairs = 0) {
+  int threads, chunk;
+  build_shape<T>(ctx, lat, &threads, &chunk);
+  const size_t lds = build_scratch_bytes(chunk, sizeof(T)) +
+                     ((size_t)lat->n_steps * LYNX_STEP_STRIDE + lat->n_steps + 1) * sizeof(T);
   int rc = allow_lds(ctx, k_build<T>, lds);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_build<T>, dim3((unsigned)lat->batch), dim3(256), lds, ctx->stream, dev_view(lat),
-                     (const T*)d_energy_in, (T*)d_steps_out, (T*)d_energy_out, (const T*)d_p_first, sample_stride,
-                     merge_pairs);
+  hipLaunchKernelGGL(k_build<T>, dim3((unsigned)lat->batch), dim3((unsigned)threads), lds, stream, dev_view(lat),
+                     (const T*)d_energy_in, (T*)d_steps_out, (T*)d_energy_out, chunk, merge_pairs);
   HIP_TRY(ctx, hipGetLastError());
   return LYNX_OK;
 }
@@ -441,106 +500,80 @@ int lynx_build_compose(lynx_ctx* ctx, lynx_lattice* lat, const void* d_energy_in
   if (!ctx || !lat || !d_energy_in || !d_steps_out) return fail(ctx, LYNX_ERR_INVALID, "null argument");
   if (lat->batch > 0x7fffffffLL) return fail(ctx, LYNX_ERR_INVALID, "batch too large");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  return lat->dtype == LYNX_F64 ? launch_build<double>(ctx, lat, d_energy_in, d_steps_out, d_energy_out)
-                                : launch_build<float>(ctx, lat, d_energy_in, d_steps_out, d_energy_out);
+  ctx->main_dirty = true;
+  return lat->dtype == LYNX_F64 ? launch_build<double>(ctx, lat, ctx->stream, d_energy_in, d_steps_out, d_energy_out)
+                                : launch_build<float>(ctx, lat, ctx->stream, d_energy_in, d_steps_out, d_energy_out);
 }
 
 // ---- particle tracking -----------------------------------------------------------------
 
 struct TrackPlan {
-  int ppt;
-  bool vec;
-  bool direct;   // k_track_direct instead of the LDS-tiled k_track
-  int unroll;    // direct: particles per lane and iteration
-  int mom_mode;  // direct: 1 = float64 per particle, 2 = float32 partial sums per iteration
+  int unroll;    // particles per lane and iteration
+  int mom_mode;  // 1 = float64 per particle, 2 = float32 partial sums per iteration, 3 = float32 lane sums
+  bool xpose;    // wave tiles through LDS (full-width accesses) instead of per-particle accesses
   TrackArgs a;
   size_t lds;
   unsigned grid;
 };
 
-static int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return (v && *v) ? atoi(v) : dflt;
-}
-
 // Tuning knobs (environment, read per call; defaults are the measured best):
-//   LYNX_KERNEL=direct|lds   LYNX_UNROLL=1|2|4   LYNX_PPT=1|big   LYNX_MOM=1|2
+//   LYNX_XPOSE=0|1   LYNX_UNROLL=1|2|4   LYNX_MOM=1|2|3   LYNX_MIN_TILES_PER_WG=<n>
 //   LYNX_WGS_PER_CU=<n>      workgroups per CU over the whole launch
 template <typename T>
-static TrackPlan plan_track(lynx_ctx* ctx, int64_t B, int64_t N, int32_t S, bool fused, const void* p_in,
-                            const void* p_out, bool moments) {
+static TrackPlan plan_track(lynx_ctx* ctx, const lynx_lattice* lat, int64_t B, int64_t N, int32_t S, bool fused,
+                            bool moments) {
   TrackPlan p;
-  const char* kern = getenv("LYNX_KERNEL");
-  p.direct = !(kern && strcmp(kern, "lds") == 0);
+  constexpr int P = 16 / (int)sizeof(T);  // particles per lane of a wave tile
   const int64_t cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
   const int64_t target = (int64_t)env_int("LYNX_WGS_PER_CU", 512) * cus;
   p.mom_mode = env_int("LYNX_MOM", sizeof(T) == 4 ? 2 : 1);
-  if (sizeof(T) == 8 || p.mom_mode < 1 || p.mom_mode > 3) p.mom_mode = 1;
+  if (sizeof(T) == 8 || p.mom_mode < 2 || p.mom_mode > 3) p.mom_mode = sizeof(T) == 4 ? 2 : 1;
   p.a.n_particles = N;
   p.a.fused_build = (fused && S > 0) ? 1 : 0;
-  p.a.store = p_out ? 1 : 0;
+  p.a.store = 0;
   p.a.interleave = env_int("LYNX_INTERLEAVE", 0);
-  int64_t scratch_scalars = (4 * 29 * 8 + sizeof(T) - 1) / sizeof(T);
-  if (fused) scratch_scalars = std::max<int64_t>(scratch_scalars, kBuildScratch);
-  // direct kernel: LDS slab of the moment reduction (float32 for MOM 2, float64 for MOM 1)
-  const int64_t slab_bytes = (int64_t)kMomSlabScalars * (p.mom_mode >= 2 ? 4 : 8);
-  if (p.direct && moments) scratch_scalars = std::max<int64_t>(scratch_scalars, (slab_bytes + sizeof(T) - 1) / sizeof(T));
-  if (p.direct) {
-    int u = env_int("LYNX_UNROLL", sizeof(T) == 4 ? (S > 1 ? 2 : 4) : 1);  // multi-step programs: fewer live particles
-    if (u != 1 && u != 2 && u != 4) u = 2;
-    // small jobs: fewer particles per lane so that more workgroups exist
-    while (u > 1 && B * ((N + 256 * u - 1) / (256 * u)) < 4 * cus) u >>= 1;
-    p.unroll = u;
-    p.ppt = u;
-    p.vec = false;
-    const int64_t tile = 256 * (int64_t)u;
-    const int64_t ntiles = (N + tile - 1) / tile;
-    // A workgroup pays a fixed cost (table load, 29-value cross-lane reduction, partial
-    // record), so it gets at least `min_tpw` tiles -- unless that would leave CUs idle.
-    int64_t min_tpw = env_int("LYNX_MIN_TILES_PER_WG", sizeof(T) == 4 ? 3 : 4);
-    while (min_tpw > 1 && B * ((ntiles + min_tpw - 1) / min_tpw) < 4 * cus) --min_tpw;
-    int64_t chunks = std::max<int64_t>(1, std::min<int64_t>((ntiles + min_tpw - 1) / min_tpw, (target + B - 1) / B));
-    int64_t tpw = (ntiles + chunks - 1) / chunks;
-    chunks = (ntiles + tpw - 1) / tpw;
-    p.a.chunks = (int32_t)chunks;
-    p.a.tiles_per_wg = (int32_t)tpw;
-    // float32 lane sums for the whole workgroup are fine while a lane sees few particles
-    if (p.mom_mode == 2 && !getenv("LYNX_MOM") && tpw * u <= 32) p.mom_mode = 3;
-    if (p.mom_mode == 3 && tpw * u > 64) p.mom_mode = 2;
-    scratch_scalars = (scratch_scalars + 3) / 4 * 4;
-    p.a.lds_tile_scalars = (int32_t)scratch_scalars;
-    p.lds = ((size_t)scratch_scalars + (size_t)S * LYNX_STEP_STRIDE + S + 1) * sizeof(T);
-    p.grid = (unsigned)(B * chunks);
-    return p;
-  }
-  p.unroll = 0;
-  const int ppt_big = sizeof(T) == 4 ? 4 : 2;
-  const int64_t tiles_big = B * ((N + 256 * ppt_big - 1) / (256 * ppt_big));
-  p.ppt = tiles_big >= 4 * cus ? ppt_big : 1;  // small jobs: smaller tiles, more workgroups
-  if (env_int("LYNX_PPT", 0) == 1) p.ppt = 1;
-  const int64_t tile = 256 * p.ppt;
+  p.a.build_chunk = 1;
+  p.xpose = !p.a.fused_build && env_int("LYNX_XPOSE", 1) != 0;
+  int u = env_int("LYNX_UNROLL", p.xpose ? P : (sizeof(T) == 4 ? (S > 1 ? 2 : 4) : 1));
+  if (u != 1 && u != 2 && u != 4) u = 2;
+  if (sizeof(T) == 8 && u > 2) u = 2;
+  // small jobs: fewer particles per lane so that more workgroups exist
+  while (u > 1 && B * ((N + 256 * u - 1) / (256 * u)) < 4 * cus) u >>= 1;
+  if (u != P) p.xpose = false;
+  p.unroll = u;
+  const int64_t tile = 256 * (int64_t)u;
   const int64_t ntiles = (N + tile - 1) / tile;
-  int64_t chunks = std::max<int64_t>(1, std::min<int64_t>(ntiles, (target + B - 1) / B));
+  // A workgroup pays a fixed cost (table load, 29-value cross-lane reduction, partial
+  // record), so it gets at least `min_tpw` tiles -- unless that would leave CUs idle.
+  int64_t min_tpw = env_int("LYNX_MIN_TILES_PER_WG", sizeof(T) == 4 ? 3 : 4);
+  while (min_tpw > 1 && B * ((ntiles + min_tpw - 1) / min_tpw) < 4 * cus) --min_tpw;
+  int64_t chunks = std::max<int64_t>(1, std::min<int64_t>((ntiles + min_tpw - 1) / min_tpw, (target + B - 1) / B));
   int64_t tpw = (ntiles + chunks - 1) / chunks;
   chunks = (ntiles + tpw - 1) / tpw;
   p.a.chunks = (int32_t)chunks;
   p.a.tiles_per_wg = (int32_t)tpw;
-  int64_t tile_scalars = std::max<int64_t>(tile * 7, scratch_scalars);
-  tile_scalars = (tile_scalars + 3) / 4 * 4;
-  p.a.lds_tile_scalars = (int32_t)tile_scalars;
-  p.lds = ((size_t)tile_scalars + (size_t)S * LYNX_STEP_STRIDE + S + 1) * sizeof(T);
+  // float32 lane sums for the whole workgroup are fine while a lane sees few particles
+  if (p.mom_mode == 2 && !getenv("LYNX_MOM") && tpw * u <= 32) p.mom_mode = 3;
+  if (p.mom_mode == 3 && tpw * u > 64) p.mom_mode = 2;
+  size_t scratch = 4 * kPartialStride * sizeof(double);
+  if (moments) scratch = std::max<size_t>(scratch, (size_t)kMomSlabScalars * (p.mom_mode >= 2 ? 4 : 8));
+  if (p.xpose) scratch = std::max<size_t>(scratch, (size_t)(kTrackThreads / 64) * kWaveTileBytes);
+  if (p.a.fused_build) {
+    p.a.build_chunk = build_chunk(lat->n_elems, sizeof(T) == 4 ? 32 : 64);
+    scratch = std::max<size_t>(scratch, build_scratch_bytes(p.a.build_chunk, sizeof(T)));
+  }
+  scratch = (scratch + 15) / 16 * 16;
+  p.a.lds_scratch_bytes = (int32_t)scratch;
+  p.lds = scratch + ((size_t)S * LYNX_STEP_STRIDE + S + 1) * sizeof(T);
   p.grid = (unsigned)(B * chunks);
-  const bool aligned = ((uintptr_t)p_in % 16 == 0) && (!p_out || (uintptr_t)p_out % 16 == 0) &&
-                       ((N * 7 * (int64_t)sizeof(T)) % 16 == 0);
-  p.vec = aligned;
   return p;
 }
 
-template <typename T, int PPT, bool VEC, bool MOMENTS>
-static int launch_track_inst(lynx_ctx* ctx, const TrackPlan& p, const LatticeDev& lv, const void* d_energy_in,
-                             const void* d_p_in, void* d_p_out, void* d_energy_out, const void* d_steps,
-                             double* d_partials) {
-  int rc = allow_lds(ctx, k_track<T, PPT, VEC, MOMENTS>, p.lds);
+template <typename T, int MOM, int UNROLL, bool FUSED, bool XPOSE>
+static int launch_direct_inst(lynx_ctx* ctx, const TrackPlan& p, const LatticeDev& lv, const void* d_energy_in,
+                              const void* d_p_in, void* d_p_out, void* d_energy_out, const void* d_steps,
+                              double* d_partials) {
+  int rc = allow_lds(ctx, k_track_direct<T, MOM, UNROLL, FUSED, XPOSE>, p.lds);
   if (rc) return rc;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->profiling) {
@@ -548,8 +581,8 @@ static int launch_track_inst(lynx_ctx* ctx, const TrackPlan& p, const LatticeDev
     HIP_TRY(ctx, hipEventCreate(&e1));
     HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
   }
-  hipLaunchKernelGGL((k_track<T, PPT, VEC, MOMENTS>), dim3(p.grid), dim3(kTrackThreads), p.lds, ctx->stream, lv,
-                     p.a, (const T*)d_energy_in, (const T*)d_p_in, (T*)d_p_out, (T*)d_energy_out,
+  hipLaunchKernelGGL((k_track_direct<T, MOM, UNROLL, FUSED, XPOSE>), dim3(p.grid), dim3(kTrackThreads), p.lds,
+                     ctx->stream, lv, p.a, (const T*)d_energy_in, (const T*)d_p_in, (T*)d_p_out, (T*)d_energy_out,
                      (const T*)d_steps, d_partials);
   HIP_TRY(ctx, hipGetLastError());
   if (ctx->profiling) {
@@ -559,27 +592,32 @@ static int launch_track_inst(lynx_ctx* ctx, const TrackPlan& p, const LatticeDev
   return LYNX_OK;
 }
 
-template <typename T, int MOM, int UNROLL, bool FUSED>
-static int launch_direct_inst(lynx_ctx* ctx, const TrackPlan& p, const LatticeDev& lv, const void* d_energy_in,
-                              const void* d_p_in, void* d_p_out, void* d_energy_out, const void* d_steps,
-                              double* d_partials) {
-  int rc = allow_lds(ctx, k_track_direct<T, MOM, UNROLL, FUSED>, p.lds);
-  if (rc) return rc;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (ctx->profiling) {
-    HIP_TRY(ctx, hipEventCreate(&e0));
-    HIP_TRY(ctx, hipEventCreate(&e1));
-    HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+template <typename T, int MOM, int U>
+static int launch_direct_mu(lynx_ctx* ctx, const TrackPlan& p, const LatticeDev& lv, const void* d_energy_in,
+                            const void* d_p_in, void* d_p_out, void* d_energy_out, const void* d_steps,
+                            double* d_partials) {
+  if (p.a.fused_build)
+    return launch_direct_inst<T, MOM, U, true, false>(ctx, p, lv, d_energy_in, d_p_in, d_p_out, d_energy_out, d_steps, d_partials);
+  if constexpr (U * 7 * sizeof(T) == 112) {
+    if (p.xpose)
+      return launch_direct_inst<T, MOM, U, false, true>(ctx, p, lv, d_energy_in, d_p_in, d_p_out, d_energy_out, d_steps, d_partials);
   }
-  hipLaunchKernelGGL((k_track_direct<T, MOM, UNROLL, FUSED>), dim3(p.grid), dim3(kTrackThreads), p.lds, ctx->stream, lv,
-                     p.a, (const T*)d_energy_in, (const T*)d_p_in, (T*)d_p_out, (T*)d_energy_out,
-                     (const T*)d_steps, d_partials);
-  HIP_TRY(ctx, hipGetLastError());
-  if (ctx->profiling) {
-    HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
-    ctx->prof_events.emplace_back(e0, e1);
+  return launch_direct_inst<T, MOM, U, false, false>(ctx, p, lv, d_energy_in, d_p_in, d_p_out, d_energy_out, d_steps, d_partials);
+}
+
+template <typename T, int MOM>
+static int launch_direct_m(lynx_ctx* ctx, const TrackPlan& p, const LatticeDev& lv, const void* d_energy_in,
+                           const void* d_p_in, void* d_p_out, void* d_energy_out, const void* d_steps,
+                           double* d_partials) {
+  switch (p.unroll) {
+    case 1: return launch_direct_mu<T, MOM, 1>(ctx, p, lv, d_energy_in, d_p_in, d_p_out, d_energy_out, d_steps, d_partials);
+    case 2: return launch_direct_mu<T, MOM, 2>(ctx, p, lv, d_energy_in, d_p_in, d_p_out, d_energy_out, d_steps, d_partials);
+    default:
+      if constexpr (sizeof(T) == 4)
+        return launch_direct_mu<T, MOM, 4>(ctx, p, lv, d_energy_in, d_p_in, d_p_out, d_energy_out, d_steps, d_partials);
+      else
+        return fail(ctx, LYNX_ERR_INVALID, "float64: at most 2 particles per lane");
   }
-  return LYNX_OK;
 }
 
 template <typename T>
@@ -587,39 +625,13 @@ static int launch_direct(lynx_ctx* ctx, const TrackPlan& p, const LatticeDev& lv
                          const void* d_p_in, void* d_p_out, void* d_energy_out, const void* d_steps,
                          double* d_partials, bool moments) {
   const int mom = moments ? p.mom_mode : 0;
-#define LYNX_D(MOM, U)                                                                                   \
-  return p.a.fused_build ? launch_direct_inst<T, MOM, U, true>(ctx, p, lv, d_energy_in, d_p_in, d_p_out,   \
-                                                               d_energy_out, d_steps, d_partials)          \
-                         : launch_direct_inst<T, MOM, U, false>(ctx, p, lv, d_energy_in, d_p_in, d_p_out,  \
-                                                                d_energy_out, d_steps, d_partials)
-#define LYNX_DU(MOM)                   \
-  switch (p.unroll) {                  \
-    case 1: LYNX_D(MOM, 1);            \
-    case 2: LYNX_D(MOM, 2);            \
-    default: LYNX_D(MOM, 4);           \
-  }
-  if (mom == 0) { LYNX_DU(0) }
-  if (mom == 2) { LYNX_DU(2) }
-  if (mom == 3) { LYNX_DU(3) }
-  LYNX_DU(1)
-#undef LYNX_DU
-#undef LYNX_D
-}
-
-template <typename T, int PPT_BIG>
-static int launch_track(lynx_ctx* ctx, const TrackPlan& p, const LatticeDev& lv, const void* d_energy_in,
-                        const void* d_p_in, void* d_p_out, void* d_energy_out, const void* d_steps,
-                        double* d_partials, bool moments) {
-#define LYNX_DISPATCH(PPT, VEC, MOM) \
-  return launch_track_inst<T, PPT, VEC, MOM>(ctx, p, lv, d_energy_in, d_p_in, d_p_out, d_energy_out, d_steps, d_partials)
-  if (p.ppt == 1) {
-    if (p.vec) { if (moments) LYNX_DISPATCH(1, true, true); else LYNX_DISPATCH(1, true, false); }
-    else       { if (moments) LYNX_DISPATCH(1, false, true); else LYNX_DISPATCH(1, false, false); }
+  if (mom == 0) return launch_direct_m<T, 0>(ctx, p, lv, d_energy_in, d_p_in, d_p_out, d_energy_out, d_steps, d_partials);
+  if constexpr (sizeof(T) == 4) {
+    if (mom == 3) return launch_direct_m<T, 3>(ctx, p, lv, d_energy_in, d_p_in, d_p_out, d_energy_out, d_steps, d_partials);
+    return launch_direct_m<T, 2>(ctx, p, lv, d_energy_in, d_p_in, d_p_out, d_energy_out, d_steps, d_partials);
   } else {
-    if (p.vec) { if (moments) LYNX_DISPATCH(PPT_BIG, true, true); else LYNX_DISPATCH(PPT_BIG, true, false); }
-    else       { if (moments) LYNX_DISPATCH(PPT_BIG, false, true); else LYNX_DISPATCH(PPT_BIG, false, false); }
+    return launch_direct_m<T, 1>(ctx, p, lv, d_energy_in, d_p_in, d_p_out, d_energy_out, d_steps, d_partials);
   }
-#undef LYNX_DISPATCH
 }
 
 template <typename T>
@@ -634,28 +646,46 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
   // ~15 % slower than many small ones, and it forces the step table
   // through LDS instead of scalar loads.  Set LYNX_FUSE_MAX_CHUNKS=<n> to fuse whenever a
   // sample is covered by <= n workgroups.
-  TrackPlan p = plan_track<T>(ctx, B, N, S, true, d_p_in, d_p_out, moments);
+  TrackPlan p = plan_track<T>(ctx, lat, B, N, S, true, moments);
   bool fused = S > 0 && !(flags & LYNX_TRACK_TWO_KERNEL) && p.a.chunks <= env_int("LYNX_FUSE_MAX_CHUNKS", 0);
-  if (!fused) p = plan_track<T>(ctx, B, N, S, false, d_p_in, d_p_out, moments);
+  if (!fused) p = plan_track<T>(ctx, lat, B, N, S, false, moments);
+  p.a.store = d_p_out ? 1 : 0;
   const bool shared_in = (flags & LYNX_TRACK_SHARED_INPUT) != 0;
   p.a.in_stride = shared_in ? 0 : N * 7;
   p.a.merged_pairs = 0;
   const void* d_steps = nullptr;
   int rc;
+  int slot = -1;
   if (S > 0 && !fused) {
+    slot = (int)(ctx->seq++ & 1u);
     const size_t need = (size_t)B * S * LYNX_STEP_STRIDE * sizeof(T);
-    if ((rc = ensure_scratch(ctx, &ctx->scratch_steps, &ctx->scratch_steps_bytes, need))) return rc;
+    if ((rc = ensure_scratch(ctx, &ctx->scratch_steps[slot], &ctx->scratch_steps_bytes[slot], need))) return rc;
     // [run, cavity] pairs in merged form for the packed float32 step loop (one 7x7 application
     // per pair); LYNX_TRACK_SEQUENTIAL_STEPS keeps every step on its own
     bool has_pair = false;
     for (int32_t s = 1; s < S; ++s)
       has_pair |= lat->h_steps[s].kind == LYNX_STEP_CAVITY && lat->h_steps[s - 1].kind == LYNX_STEP_RUN;
-    p.a.merged_pairs = has_pair && p.direct && sizeof(T) == 4 && p.unroll % 2 == 0 &&
+    p.a.merged_pairs = has_pair && sizeof(T) == 4 && p.unroll % 2 == 0 &&
                        !(flags & LYNX_TRACK_SEQUENTIAL_STEPS) && env_int("LYNX_MERGE_STEPS", 1);
-    if ((rc = launch_build<T>(ctx, lat, d_energy_in, ctx->scratch_steps, d_energy_out, moments ? d_p_in : nullptr,
-                              p.a.in_stride, p.a.merged_pairs)))
-      return rc;
-    d_steps = ctx->scratch_steps;
+    const bool async = env_int("LYNX_ASYNC_BUILD", 1) != 0;
+    hipStream_t bs = async ? ctx->s_build : ctx->stream;
+    if (async) {
+      // the table slot was last read by the streaming kernel two calls ago
+      if (ctx->streamed_valid[slot]) HIP_TRY(ctx, hipStreamWaitEvent(bs, ctx->ev_streamed[slot], 0));
+      // what the build reads (energy, lattice pool) may have been written on the main stream
+      if (ctx->main_dirty || (ctx->main_wrote && ctx->main_wrote == d_energy_in)) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_mark, ctx->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(bs, ctx->ev_mark, 0));
+        ctx->main_dirty = false;
+        ctx->main_wrote = nullptr;
+      }
+    }
+    if ((rc = launch_build<T>(ctx, lat, bs, d_energy_in, ctx->scratch_steps[slot], nullptr, p.a.merged_pairs))) return rc;
+    if (async) {
+      HIP_TRY(ctx, hipEventRecord(ctx->ev_built[slot], bs));
+      HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_built[slot], 0));
+    }
+    d_steps = ctx->scratch_steps[slot];
   }
   if ((int64_t)B * p.a.chunks > 0x7fffffffLL) return fail(ctx, LYNX_ERR_INVALID, "grid too large");
   double* d_partials = nullptr;
@@ -664,16 +694,16 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
     if ((rc = ensure_scratch(ctx, &ctx->scratch_partials, &ctx->scratch_partials_bytes, need))) return rc;
     d_partials = (double*)ctx->scratch_partials;
   }
-  if (p.direct)
-    rc = launch_direct<T>(ctx, p, lv, d_energy_in, d_p_in, d_p_out, fused ? d_energy_out : nullptr, d_steps,
-                          d_partials, moments);
-  else
-    rc = launch_track<T, (sizeof(T) == 4 ? 4 : 2)>(ctx, p, lv, d_energy_in, d_p_in, d_p_out,
-                                                   fused ? d_energy_out : nullptr, d_steps, d_partials, moments);
+  rc = launch_direct<T>(ctx, p, lv, d_energy_in, d_p_in, d_p_out, d_energy_out, d_steps, d_partials, moments);
   if (rc) return rc;
+  if (slot >= 0) {
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_streamed[slot], ctx->stream));
+    ctx->streamed_valid[slot] = true;
+  }
+  if (d_energy_out) ctx->main_wrote = d_energy_out;  // a later build that reads it must wait for this kernel
   if (moments) {
     if (p.a.chunks <= 64)
-      hipLaunchKernelGGL(k_finalize_moments_small, dim3((unsigned)B), dim3(64), 0, ctx->stream, d_partials,
+      hipLaunchKernelGGL(k_finalize_moments_small, dim3((unsigned)B), dim3(256), 0, ctx->stream, d_partials,
                          p.a.chunks, d_moments_out);
     else
       hipLaunchKernelGGL(k_finalize_moments, dim3((unsigned)B), dim3(1024), 0, ctx->stream, d_partials, p.a.chunks,
@@ -713,8 +743,9 @@ static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const v
   int rc;
   // forward step tables
   const size_t steps_bytes = (size_t)B * S * LYNX_STEP_STRIDE * sizeof(T);
-  if ((rc = ensure_scratch(ctx, &ctx->scratch_steps, &ctx->scratch_steps_bytes, steps_bytes))) return rc;
-  if ((rc = launch_build<T>(ctx, lat, d_energy_in, ctx->scratch_steps, nullptr))) return rc;
+  if ((rc = ensure_scratch(ctx, &ctx->scratch_steps[2], &ctx->scratch_steps_bytes[2], steps_bytes))) return rc;
+  if ((rc = launch_build<T>(ctx, lat, ctx->stream, d_energy_in, ctx->scratch_steps[2], nullptr))) return rc;
+  ctx->main_dirty = true;
 
   // Z: what a lane carries -- one particle, or (float32) two as a packed pair
   constexpr int W = LaneOf<Z>::W;
@@ -746,7 +777,7 @@ static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const v
     return rc;
   LatticeDev lv = dev_view(lat);
   hipLaunchKernelGGL((k_track_bwd<T, Z>), dim3((unsigned)(B * chunks)), dim3(kTrackThreads), lds, ctx->stream, lv, a,
-                     (const T*)d_p_in, (const T*)ctx->scratch_steps, d_moments_fwd, d_grad_moments,
+                     (const T*)d_p_in, (const T*)ctx->scratch_steps[2], d_moments_fwd, d_grad_moments,
                      (T*)ctx->scratch_grad[0], (T*)d_grad_p_in);
   HIP_TRY(ctx, hipGetLastError());
   hipLaunchKernelGGL(k_reduce_tbar<T>, dim3((unsigned)(B * S)), dim3(64), 0, ctx->stream, (const T*)ctx->scratch_grad[0],
@@ -785,9 +816,10 @@ static int moments_backward_t(lynx_ctx* ctx, lynx_lattice* lat, const void* d_en
   const int64_t B = lat->batch;
   const int32_t S = lat->n_steps, E = lat->n_elems;
   int rc;
-  if ((rc = ensure_scratch(ctx, &ctx->scratch_steps, &ctx->scratch_steps_bytes, (size_t)B * S * LYNX_STEP_STRIDE * sizeof(T))))
+  if ((rc = ensure_scratch(ctx, &ctx->scratch_steps[2], &ctx->scratch_steps_bytes[2], (size_t)B * S * LYNX_STEP_STRIDE * sizeof(T))))
     return rc;
-  if ((rc = launch_build<T>(ctx, lat, d_energy_in, ctx->scratch_steps, nullptr))) return rc;
+  if ((rc = launch_build<T>(ctx, lat, ctx->stream, d_energy_in, ctx->scratch_steps[2], nullptr))) return rc;
+  ctx->main_dirty = true;
   if ((rc = ensure_scratch(ctx, &ctx->scratch_grad[0], &ctx->scratch_grad_bytes[0], (size_t)B * (S + 1) * 56 * sizeof(T))))
     return rc;
   if ((rc = ensure_scratch(ctx, &ctx->scratch_grad[1], &ctx->scratch_grad_bytes[1], (size_t)B * S * kGradStride * sizeof(T))))
@@ -796,7 +828,7 @@ static int moments_backward_t(lynx_ctx* ctx, lynx_lattice* lat, const void* d_en
                            (size_t)B * (2 * E + S + 1) * 49 * sizeof(T))))
     return rc;
   LatticeDev lv = dev_view(lat);
-  hipLaunchKernelGGL(k_moments_bwd<T>, dim3((unsigned)B), dim3(64), 0, ctx->stream, lv, (const T*)ctx->scratch_steps,
+  hipLaunchKernelGGL(k_moments_bwd<T>, dim3((unsigned)B), dim3(64), 0, ctx->stream, lv, (const T*)ctx->scratch_steps[2],
                      (const T*)d_mu_in, (const T*)d_cov_in, (const T*)d_mu_bar, (const T*)d_cov_bar,
                      (T*)ctx->scratch_grad[0], (T*)ctx->scratch_grad[1], (T*)d_grad_mu_in, (T*)d_grad_cov_in);
   HIP_TRY(ctx, hipGetLastError());
@@ -846,8 +878,8 @@ int lynx_moments(lynx_ctx* ctx, int dtype, int64_t batch, int64_t n_particles, c
 template <typename T>
 static int launch_track_moments(lynx_ctx* ctx, lynx_lattice* lat, const void* d_energy_in, const void* d_mu_in,
                                 const void* d_cov_in, void* d_mu_out, void* d_cov_out, void* d_energy_out) {
-  const size_t lds =
-      ((size_t)build_scratch_scalars(build_chunk(lat->n_elems)) + (size_t)lat->n_steps * LYNX_STEP_STRIDE + lat->n_steps + 1 + 8 + 49 + 49 + 16) * sizeof(T);
+  const size_t lds = build_scratch_bytes(build_chunk(lat->n_elems), sizeof(T)) +
+                     ((size_t)lat->n_steps * LYNX_STEP_STRIDE + lat->n_steps + 1 + 8 + 49 + 49 + 16) * sizeof(T);
   int rc = allow_lds(ctx, k_track_moments<T>, lds);
   if (rc) return rc;
   const unsigned threads = lat->batch <= 4096 ? 256u : 64u;
@@ -864,6 +896,7 @@ int lynx_track_moments(lynx_ctx* ctx, lynx_lattice* lat, const void* d_energy_in
     return fail(ctx, LYNX_ERR_INVALID, "null argument");
   if (lat->batch > 0x7fffffffLL) return fail(ctx, LYNX_ERR_INVALID, "batch too large");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ctx->main_dirty = true;
   return lat->dtype == LYNX_F64
              ? launch_track_moments<double>(ctx, lat, d_energy_in, d_mu_in, d_cov_in, d_mu_out, d_cov_out, d_energy_out)
              : launch_track_moments<float>(ctx, lat, d_energy_in, d_mu_in, d_cov_in, d_mu_out, d_cov_out, d_energy_out);

@@ -48,8 +48,8 @@ namespace lynx {
 // 49 map entries + 8 cavity coefficients, padded to 64
 #define LYNX_STEP_STRIDE 64
 #define LYNX_COEF_OFFSET 49
-// step 0, slots 57..63: reference point of the moment sums (first particle, tracked)
-#define LYNX_SHIFT_OFFSET 57
+// last step, slot 63: the beam energy behind the last step (published by the streaming kernel)
+#define LYNX_ENERGY_OFFSET 63
 // cavity coefficient slots (lynx/accelerator/cavity.py:141-226)
 #define LYNX_C_DSCALE 0   // E*beta0 / (E_out*beta1)
 #define LYNX_C_DKICK 1    // V*beta0 / (E_out*beta1)

@@ -163,7 +163,7 @@ def test_segment_transfer_map_batched_fodo(lx, dtype):
     energy = np.full(B, 1e8, dtype=dtype)
     got = lx.Segment(elements).transfer_map(energy)
     ref = o.segment_transfer_map(specs, energy, dtype)
-    assert map_err(got, ref) < (5e-4 if dtype == np.float32 else 1e-10)
+    assert map_err(got, ref) < (5e-5 if dtype == np.float32 else 1e-10)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -198,9 +198,9 @@ def test_fodo_scan_particles(lx, dtype, n):
         desc += [("quadrupole", dict(length=f(0.2), k1=4.2 * scale)), ("drift", dict(length=f(0.5))),
                  ("quadrupole", dict(length=f(0.2), k1=-4.2 * scale)), ("drift", dict(length=f(0.5)))]
     out, ref = _particle_case(lx, desc, dtype, (B,), n, seed=2)
-    # the composed fp32 map of 128 elements carries ~1e-5; scale-relative particle tolerance
     got = np.asarray(out.particles)
-    tol = 1e-3 if dtype == np.float32 else 1e-9
+    tol = 1e-4 if dtype == np.float32 else 1e-9
+    _assert_moments(out, ref, dtype)
     for c in range(7):
         assert rel_err(got[..., c], ref["particles"][..., c]) < tol, c
     # and exactly consistent with the GPU's own composed map (isolates the streaming kernel)
@@ -257,6 +257,149 @@ def test_c5_cavity_lattice_particles(lx, dtype):
         assert rel_err(got[..., c], ref["particles"][..., c]) < tol[c], (c, rel_err(got[..., c], ref["particles"][..., c]))
     assert rel_err(out.energy, ref["energy"]) < 1e-6
     assert np.all(out.energy > 6e6)
+
+
+def _fodo_scan(B, cells=32):
+    scale = 0.5 + np.arange(B) / (B - 1)
+    f = lambda v: np.full(B, v)  # noqa: E731
+    desc = []
+    for _ in range(cells):
+        desc += [("quadrupole", dict(length=f(0.2), k1=4.2 * scale)), ("drift", dict(length=f(0.5))),
+                 ("quadrupole", dict(length=f(0.2), k1=-4.2 * scale)), ("drift", dict(length=f(0.5)))]
+    return desc
+
+
+def _moment_distance(out, m):
+    """Largest deviation of the product's moments from the moments `m`, in units of the tolerance
+    scale `_assert_moments` uses (sigma for means and sigmas, sigma_a sigma_b for the correlations)."""
+    worst = 0.0
+    for key in ("x", "xp", "y", "yp", "s", "p"):
+        sig = m["sigma_" + key]
+        worst = max(worst, float(np.max(np.abs(getattr(out, "mu_" + key) - m["mu_" + key]) / (np.abs(m["mu_" + key]) + sig))))
+        if np.all(sig > 0):
+            worst = max(worst, float(np.max(np.abs(getattr(out, "sigma_" + key) - sig) / sig)))
+    for key, a, b in (("sigma_xxp", "sigma_x", "sigma_xp"), ("sigma_yyp", "sigma_y", "sigma_yp")):
+        worst = max(worst, float(np.max(np.abs(getattr(out, key) - m[key]) / (m[a] * m[b]))))
+    return worst
+
+
+def test_c4_shape_moments_match_the_reference_chain(lx):
+    """
+    BASELINE config 4's shape (128-element FODO, k1 scan over the batch, 100 000 particles, float32):
+    the beam MOMENTS against the float32 oracle, which composes left to right like the reference
+    (segment.py:334-335), at north_star's 1e-4 -- and, for the record, their distance to the float64
+    oracle on the same float32 inputs.  Measured on MI355X (this test prints it): 6e-6 from the
+    float32 chain, 3.6e-5 from float64; the float32 chain itself is 3.5e-5 from float64 -- what is
+    left is the rounding of the element maps (float32 sin / cos / sqrt arguments), not the order of
+    the products: the build multiplies in float64.
+    """
+    B, N = 16, 100_000
+    out, ref = _particle_case(lx, _fodo_scan(B), np.float32, (B,), N, seed=2)
+    _assert_moments(out, ref, np.float32)
+    _, specs64 = make_lattice(_fodo_scan(B), np.float64)
+    P = o.gaussian_particles((B,), N, seed=2, dtype=np.float32, sigma=[1e-4, 1e-5, 1e-4, 1e-5, 1e-5, 1e-3])
+    ref64 = o.segment_track(specs64, o.particle_beam(P.astype(np.float64), np.full(B, 1e8), np.float64), np.float64)
+    d32 = _moment_distance(out, o.beam_moments(ref, ddof=1))
+    d64 = _moment_distance(out, o.beam_moments(ref64, ddof=1))
+    print(f"C4 shape: moments {d32:.2e} from the float32 reference chain, {d64:.2e} from float64")
+    assert d32 < 1e-4 and d64 < 2e-4
+    # the particles themselves, relative to the scale of each coordinate
+    got = np.asarray(out.particles)
+    for c in range(7):
+        assert rel_err(got[..., c], ref["particles"][..., c]) < 1e-4, c
+
+
+def test_c4_shape_composed_map_is_the_exact_product_of_its_float32_element_maps(lx):
+    """The float32 build multiplies in float64: the composed map equals the float64 product of the
+    GPU's own float32 element maps to float32 rounding, whatever the association.  (Against the
+    oracle's chain the distance is set by the element maps -- float32 sin / cos of the device vs
+    NumPy's, amplified over 128 elements -- not by the products.)"""
+    B = 16
+    desc = _fodo_scan(B)
+    elements, specs = make_lattice(desc, np.float32, lx)
+    energy = np.full(B, 1e8, dtype=np.float32)
+    got = lx.Segment(elements).transfer_map(energy).astype(np.float64)
+    exact = np.broadcast_to(np.eye(7), (B, 7, 7)).copy()
+    for el in elements[:4]:  # one FODO cell; the lattice repeats it 32 times
+        exact = np.matmul(el.transfer_map(energy).astype(np.float64), exact)
+    cell = exact.copy()
+    for _ in range(31):
+        exact = np.matmul(cell, exact)
+    assert map_err(got, exact) < 2e-7
+    chain = o.segment_transfer_map(specs, energy, np.float32)
+    print(f"C4 shape: composed map {map_err(got, chain):.2e} from the float32 reference chain")
+    assert map_err(got, chain) < 5e-4
+
+
+def test_c5_shape_moments(lx):
+    """
+    BASELINE config 5's shape ([Drift, misaligned Quad, Drift, Cavity] x 8 at 6 MeV, 10 000 particles,
+    float32): beam moments against the float32 oracle at north_star's 1e-4.  sigma_s and sigma_p pass
+    through eight cavity kicks cos(phi + eps) - cos(phi) evaluated in float32 (cavity.py:150-160) -- in
+    the oracle as in the kernel; the test prints the distance to the float64 oracle as well.
+    """
+    B, N = 16, 10_000
+    rng = np.random.default_rng(3)
+    f = lambda v: np.full(B, v)  # noqa: E731
+    desc = []
+    for _ in range(8):
+        desc += [("drift", dict(length=f(0.3))),
+                 ("quadrupole", dict(length=f(0.1), k1=rng.uniform(-5, 5, B), misalignment=rng.normal(0, 1e-4, (B, 2)))),
+                 ("drift", dict(length=f(0.3))),
+                 ("cavity", dict(length=f(1.0377), voltage=rng.uniform(5e6, 2e7, B), phase=rng.uniform(-10, 10, B),
+                                 frequency=f(1.3e9)))]
+    sigma = [1e-4, 1e-5, 1e-4, 1e-5, 1e-4, 1e-3]
+    out, ref = _particle_case(lx, desc, np.float32, (B,), N, seed=3, energy=6e6, sigma=sigma)
+    _assert_moments(out, ref, np.float32)
+    _, specs64 = make_lattice([(k, {a: np.asarray(v, dtype=np.float32).astype(np.float64) for a, v in kw.items()})
+                               for k, kw in desc], np.float64)
+    P = o.gaussian_particles((B,), N, seed=3, dtype=np.float32, sigma=sigma)
+    ref64 = o.segment_track(specs64, o.particle_beam(P.astype(np.float64), np.full(B, 6e6), np.float64), np.float64)
+    d32 = _moment_distance(out, o.beam_moments(ref, ddof=1))
+    d64 = _moment_distance(out, o.beam_moments(ref64, ddof=1))
+    print(f"C5 shape: moments {d32:.2e} from the float32 reference, {d64:.2e} from float64")
+    assert d32 < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_c1_ares_segment_parameter_beam(lx, dtype):
+    """
+    BASELINE config 1: the 11-element README segment (README.md:34-48, angles of docs/examples/simple.ipynb)
+    x `ParameterBeam.from_parameters()` defaults (parameter_beam.py:97-113), batch 1 -- mu and cov
+    against `Segment.track` of the oracle (segment.py:340-356, element.py:71-82) at north_star's
+    tolerances, entry by entry relative to sigma_i sigma_j.
+    """
+    f = lambda v: np.array([v], dtype=dtype)  # noqa: E731
+    segment = lx.Segment([
+        lx.BPM(name="BPM1SMATCH"), lx.Drift(f(1.0), dtype=dtype), lx.BPM(name="BPM6SMATCH"), lx.Drift(f(1.0), dtype=dtype),
+        lx.VerticalCorrector(f(0.3), angle=f(3.142e-3), name="V7SMATCH", dtype=dtype), lx.Drift(f(0.2), dtype=dtype),
+        lx.HorizontalCorrector(f(0.3), angle=f(1e-4), name="H10SMATCH", dtype=dtype), lx.Drift(f(7.0), dtype=dtype),
+        lx.HorizontalCorrector(f(0.3), angle=f(-1e-4), name="H12SMATCH", dtype=dtype), lx.Drift(f(0.05), dtype=dtype),
+        lx.BPM(name="BPM13SMATCH")])
+    specs = [o.BPM(), o.Drift(f(1.0)), o.BPM(), o.Drift(f(1.0)), o.VerticalCorrector(f(0.3), f(3.142e-3)), o.Drift(f(0.2)),
+             o.HorizontalCorrector(f(0.3), f(1e-4)), o.Drift(f(7.0)), o.HorizontalCorrector(f(0.3), f(-1e-4)),
+             o.Drift(f(0.05)), o.BPM()]
+    assert len(segment.elements) == 11 and segment.is_skippable
+    beam = lx.ParameterBeam.from_parameters(dtype=dtype)
+    assert beam._mu.shape == (1, 7) and beam.energy.shape == (1,) and beam.energy[0] == 1e8
+    out = segment.track(beam)
+    ref = o.segment_track(specs, o.parameter_beam_from_parameters(dtype=dtype), dtype)
+    tol = TOL_MOM[dtype]
+    sig = np.sqrt(np.diagonal(ref["cov"], axis1=-2, axis2=-1)[..., :6].astype(np.float64))
+    assert np.all(np.abs(out._mu[..., :6] - ref["mu"][..., :6]) <= tol * (np.abs(ref["mu"][..., :6]) + sig))
+    assert np.array_equal(out._mu[..., 6], ref["mu"][..., 6])
+    for i in range(6):
+        for j in range(6):
+            assert np.all(np.abs(out._cov[..., i, j] - ref["cov"][..., i, j]) <= tol * sig[..., i] * sig[..., j]), (i, j)
+    assert np.array_equal(out._cov[..., 6, :], ref["cov"][..., 6, :])
+    m = o.beam_moments(ref)
+    for key in ("sigma_x", "sigma_xp", "sigma_y", "sigma_yp", "sigma_s", "sigma_p"):
+        assert np.allclose(getattr(out, key), m[key], rtol=tol, atol=0), key
+    assert np.allclose(out.mu_y, m["mu_y"], rtol=tol) and np.allclose(out.mu_x, m["mu_x"], rtol=tol, atol=tol * 1e-6)
+    assert np.array_equal(out.energy, beam.energy) and np.array_equal(out.total_charge, beam.total_charge)
+    # the same lattice as one map: transfer_map(energy) agrees with what track applied
+    tm = segment.transfer_map(beam.energy)
+    assert map_err(tm, o.segment_transfer_map(specs, beam.energy, dtype)) < TOL_MAP[dtype]
 
 
 def test_cavity_mixed_zero_voltage_batch_matches_reference_nan(lx):
