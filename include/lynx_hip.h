@@ -102,10 +102,16 @@ typedef struct lynx_step {
  * of a run are) plus the two rows of T_run that give the s and delta entering the cavity --
  * the same algebra as segment.py:344-354 / cavity.py:113-161, rounded differently. */
 #define LYNX_TRACK_SEQUENTIAL_STEPS 8
+/* Like LYNX_TRACK_MOMENTS, but accumulate the whole 6x6 covariance (21 products per particle)
+ * instead of the second moments the reference's ParticleBeam exposes as properties
+ * (particle_beam.py:736-836: the six variances, sigma_xx' and sigma_yy' -- 8 products). */
+#define LYNX_TRACK_COVARIANCE 16
 
 /* Layout of one sample's moment record (float64 regardless of the particle dtype):
  * [0..6] mean of the 7 coordinates, [7..27] upper triangle (row-major, i<=j<6) of the
- * BIASED 6x6 covariance, [28..34] reserved (0), [35] number of particles. */
+ * BIASED 6x6 covariance, [28..33] reserved (0), [34] 1 if the whole triangle was accumulated,
+ * 0 if only the property set was (then every other entry of [7..27] is NaN), [35] number of
+ * particles. */
 #define LYNX_MOMENT_STRIDE 36
 
 typedef struct lynx_device_info_t {
@@ -218,9 +224,10 @@ int lynx_track_moments_backward(lynx_ctx* ctx, lynx_lattice* lat, const void* d_
                                 void* d_grad_mu_in, void* d_grad_cov_in);
 
 /* Moment read-out of an existing ParticleBeam (reference: particle_beam.py:736-836,
- * one fused pass instead of 14 separate reductions).  d_moments_out [B][36] float64.       */
+ * one fused pass instead of 14 separate reductions).  d_moments_out [B][36] float64;
+ * covariance != 0: the whole 6x6 covariance, else the property set (see LYNX_MOMENT_STRIDE). */
 int lynx_moments(lynx_ctx* ctx, int dtype, int64_t batch, int64_t n_particles, const void* d_p,
-                 double* d_moments_out);
+                 double* d_moments_out, int32_t covariance);
 
 /* Screen read-out of a ParticleBeam: per-sample 2-D histogram of (x, y) with the bin edges the
  * caller supplies (reference: screen.py:196-213, `jnp.histogramdd` with `pixel_bin_edges`

@@ -30,7 +30,7 @@ FLAG_CAV_BETA, FLAG_CAV_GAIN, FLAG_CAV_T5XX = 8, 16, 32
 STEP_RUN, STEP_CAVITY = 0, 1
 STEP_FLAG_RAW = 64
 
-TRACK_MOMENTS, TRACK_TWO_KERNEL, TRACK_SHARED_INPUT, TRACK_SEQUENTIAL_STEPS = 1, 2, 4, 8
+TRACK_MOMENTS, TRACK_TWO_KERNEL, TRACK_SHARED_INPUT, TRACK_SEQUENTIAL_STEPS, TRACK_COVARIANCE = 1, 2, 4, 8, 16
 
 
 class LynxError(RuntimeError):
@@ -85,7 +85,7 @@ SIGNATURES = {
     "lynx_track_moments": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "lynx_track_particles_backward": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "lynx_track_moments_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "lynx_moments": (_i, [_vp, _i, _i64, _i64, _vp, _vp]),
+    "lynx_moments": (_i, [_vp, _i, _i64, _i64, _vp, _vp, C.c_int32]),
     "lynx_histogram2d": (_i, [_vp, _i, _i64, _i64, _vp, _vp, _vp, C.c_int32, C.c_int32, _vp]),
     "lynx_gaussian_image": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _vp, C.c_int32, C.c_int32, _vp]),
     "lynx_diag_phase_trig": (_i, [_vp, _i64, _vp, C.c_int32, _vp, _vp]),

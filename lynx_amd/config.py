@@ -6,6 +6,12 @@ import os
 # HBM traffic).  If False, the first moment property read costs one more pass over the beam.
 fused_moments = os.environ.get("LYNX_FUSED_MOMENTS", "1") != "0"
 
+# What the fused epilogue accumulates: by default the moments the reference's ParticleBeam exposes as
+# properties (means, the six variances, sigma_xx', sigma_yy'); True adds the rest of the 6x6
+# covariance (21 products per particle instead of 8).  `beam.covariance()` gets the whole matrix of
+# any beam with one extra pass when it was not accumulated.
+fused_covariance = os.environ.get("LYNX_FUSED_COVARIANCE", "0") == "1"
+
 # Build+compose in its own launch instead of the fused prologue (A/B switch).
 two_kernel = os.environ.get("LYNX_TWO_KERNEL", "0") == "1"
 

@@ -500,15 +500,45 @@ __device__ __forceinline__ double moment_slot_moved(const double* row, const dou
   return row[j] + ei * row[jj] + row[i] * ej + n * ei * ej;
 }
 
-template <typename T> struct MomentAcc {
-  double d[6], dd[21], one, cnt;
+// Which second moments a pass accumulates.
+//   FULL = false  the ones the reference's ParticleBeam exposes as properties (particle_beam.py:736-836):
+//                 the six variances, sigma_xx' and sigma_yy' -- 8 sums;
+//   FULL = true   the whole upper triangle of the 6x6 covariance -- 21 sums.
+// Slot of sum k inside a record's [7, 28) block (row-major upper triangle, include/lynx_hip.h):
+template <bool FULL> struct MomentSet {
+  static constexpr int N = FULL ? 21 : 8;
+  __host__ __device__ static constexpr int row(int k) { return FULL ? tri_row(k) : (k < 6 ? k : (k == 6 ? 0 : 2)); }
+  __host__ __device__ static constexpr int col(int k) { return FULL ? tri_col(k) : (k < 6 ? k : (k == 6 ? 1 : 3)); }
+  __host__ __device__ static constexpr int slot(int k) { return 7 + tri_index(row(k), col(k)); }
+  __host__ __device__ static constexpr int tri_index(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }
+  __host__ __device__ static constexpr int tri_row(int k) {
+    int i = 0, len = 6;
+    while (k >= len) { k -= len; --len; ++i; }
+    return i;
+  }
+  __host__ __device__ static constexpr int tri_col(int k) {
+    int i = 0, len = 6;
+    while (k >= len) { k -= len; --len; ++i; }
+    return i + k;
+  }
+};
+
+template <typename T, bool FULL> struct MomentAcc {
+  using Set = MomentSet<FULL>;
+  double d[6], dd[Set::N], one, cnt;
   __device__ __forceinline__ void clear() {
 #pragma unroll
     for (int i = 0; i < 6; ++i) d[i] = 0.0;
 #pragma unroll
-    for (int i = 0; i < 21; ++i) dd[i] = 0.0;
+    for (int i = 0; i < Set::N; ++i) dd[i] = 0.0;
     one = 0.0;
     cnt = 0.0;
+  }
+  template <int K> __device__ __forceinline__ void products(const double (&e)[6]) {
+    if constexpr (K < Set::N) {
+      dd[K] = fma(e[Set::row(K)], e[Set::col(K)], dd[K]);
+      products<K + 1>(e);
+    }
   }
   __device__ __forceinline__ void add(const T (&z)[7], const T (&shift)[6]) {
     double e[6];
@@ -519,14 +549,7 @@ template <typename T> struct MomentAcc {
     }
     one += (double)z[6];
     cnt += 1.0;
-    int k = 0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-      for (int j = i; j < 6; ++j) {
-        dd[k] = fma(e[i], e[j], dd[k]);
-        ++k;
-      }
+    products<0>(e);
   }
 };
 
@@ -666,18 +689,21 @@ __device__ __forceinline__ void wave_tile_from_particles(const T (&z)[P][7], uns
 template <int MOM> struct MomScratch { using type = double; };
 template <> struct MomScratch<2> { using type = float; };  // float32 partial sums
 template <> struct MomScratch<3> { using type = float; };
-constexpr int kMomSlabScalars = 4 * 29 * 65;  // per workgroup, in units of MomScratch<MOM>::type
+constexpr int kMomSlabScalars = 4 * 29 * 65;  // per workgroup (whole covariance), in units of MomScratch<MOM>::type
+constexpr int kMomSlabScalarsCompact = 4 * 16 * 65;
 
 // Per-lane moment sums of the streaming kernel (see the MOM modes above).
-template <typename T, int MOM>
+template <typename T, int MOM, bool FULL>
 struct LaneSums {
-  MomentAcc<T> acc;                                // MOM 1, 2
-  float f_d[6], f_dd[21], f_one = 0.f, f_cnt = 0.f;  // MOM 2: per iteration, MOM 3: per workgroup
+  using Set = MomentSet<FULL>;
+  static constexpr int kRows = 8 + Set::N;  // slab rows: 6 d, one, the products, count
+  MomentAcc<T, FULL> acc;                            // MOM 1, 2
+  float f_d[6], f_dd[Set::N], f_one = 0.f, f_cnt = 0.f;  // MOM 2: per iteration, MOM 3: per workgroup
   __device__ __forceinline__ void clear_f() {
 #pragma unroll
     for (int k = 0; k < 6; ++k) f_d[k] = 0.f;
 #pragma unroll
-    for (int k = 0; k < 21; ++k) f_dd[k] = 0.f;
+    for (int k = 0; k < Set::N; ++k) f_dd[k] = 0.f;
     f_one = 0.f;
   }
   __device__ __forceinline__ void init() {
@@ -686,6 +712,14 @@ struct LaneSums {
   }
   __device__ __forceinline__ void begin_iteration() {
     if (MOM == 2) clear_f();
+  }
+  // spelled out by recursion: as nested loops with a running index the compiler once left `e` in
+  // scratch memory
+  template <int K> __device__ __forceinline__ void products(const float (&e)[6]) {
+    if constexpr (K < Set::N) {
+      f_dd[K] = fmaf(e[Set::row(K)], e[Set::col(K)], f_dd[K]);
+      products<K + 1>(e);
+    }
   }
   __device__ __forceinline__ void add(const T (&z)[7], const T (&shift)[6]) {
     if (MOM == 1) acc.add(z, shift);
@@ -697,16 +731,7 @@ struct LaneSums {
         f_d[k] += e[k];
       }
       f_one += (float)z[6];
-      // the 21 products of the upper triangle, spelled out (as nested loops with a running index the
-      // compiler left `e` in scratch memory once this moved into a member function)
-#define LYNX_DD(K, R, C) f_dd[K] = fmaf(e[R], e[C], f_dd[K]);
-      LYNX_DD(0, 0, 0) LYNX_DD(1, 0, 1) LYNX_DD(2, 0, 2) LYNX_DD(3, 0, 3) LYNX_DD(4, 0, 4) LYNX_DD(5, 0, 5)
-      LYNX_DD(6, 1, 1) LYNX_DD(7, 1, 2) LYNX_DD(8, 1, 3) LYNX_DD(9, 1, 4) LYNX_DD(10, 1, 5)
-      LYNX_DD(11, 2, 2) LYNX_DD(12, 2, 3) LYNX_DD(13, 2, 4) LYNX_DD(14, 2, 5)
-      LYNX_DD(15, 3, 3) LYNX_DD(16, 3, 4) LYNX_DD(17, 3, 5)
-      LYNX_DD(18, 4, 4) LYNX_DD(19, 4, 5)
-      LYNX_DD(20, 5, 5)
-#undef LYNX_DD
+      products<0>(e);
       if (MOM == 2) acc.cnt += 1.0;
       else f_cnt += 1.f;
     }
@@ -716,27 +741,37 @@ struct LaneSums {
 #pragma unroll
       for (int k = 0; k < 6; ++k) acc.d[k] += (double)f_d[k];
 #pragma unroll
-      for (int k = 0; k < 21; ++k) acc.dd[k] += (double)f_dd[k];
+      for (int k = 0; k < Set::N; ++k) acc.dd[k] += (double)f_dd[k];
       acc.one += (double)f_one;
     }
   }
-  // value of slot i (0..5 d, 6 one, 7..27 dd, 28 count) as parked in the reduction slab
+  // rows of the reduction slab: 0..5 d, 6 one, 7.. the products, last the count
   template <typename R> __device__ __forceinline__ void park(R* slab, int lane) const {
     if (MOM == 3) {
 #pragma unroll
       for (int i = 0; i < 6; ++i) slab[i * 65 + lane] = (R)f_d[i];
       slab[6 * 65 + lane] = (R)f_one;
 #pragma unroll
-      for (int i = 0; i < 21; ++i) slab[(7 + i) * 65 + lane] = (R)f_dd[i];
-      slab[28 * 65 + lane] = (R)f_cnt;
+      for (int i = 0; i < Set::N; ++i) slab[(7 + i) * 65 + lane] = (R)f_dd[i];
+      slab[(7 + Set::N) * 65 + lane] = (R)f_cnt;
     } else {
 #pragma unroll
       for (int i = 0; i < 6; ++i) slab[i * 65 + lane] = (R)acc.d[i];
       slab[6 * 65 + lane] = (R)acc.one;
 #pragma unroll
-      for (int i = 0; i < 21; ++i) slab[(7 + i) * 65 + lane] = (R)acc.dd[i];
-      slab[28 * 65 + lane] = (R)acc.cnt;
+      for (int i = 0; i < Set::N; ++i) slab[(7 + i) * 65 + lane] = (R)acc.dd[i];
+      slab[(7 + Set::N) * 65 + lane] = (R)acc.cnt;
     }
+  }
+  // record slot of slab row r
+  __device__ static __forceinline__ int slot_of_row(int r) {
+    if (r < 7) return r;
+    if (r == 7 + Set::N) return 35;
+    int sl = 0;
+#pragma unroll
+    for (int k = 0; k < Set::N; ++k)
+      if (r == 7 + k) sl = Set::slot(k);
+    return sl;
   }
 };
 
@@ -817,7 +852,7 @@ __device__ __forceinline__ void apply_program_lane(const LatticeDev& lat, int S,
   }
 }
 
-template <typename T, int MOM, int UNROLL, bool FUSED, bool XPOSE>
+template <typename T, int MOM, bool FULL, int UNROLL, bool FUSED, bool XPOSE>
 __global__ __launch_bounds__(kTrackThreads, (XPOSE ? 3 : 1)) void k_track_direct(
     LatticeDev lat, TrackArgs a, const T* __restrict__ energy_in, const T* p_in, T* p_out,
     T* __restrict__ energy_out, const T* __restrict__ steps_in, double* __restrict__ partials) {
@@ -894,7 +929,7 @@ __global__ __launch_bounds__(kTrackThreads, (XPOSE ? 3 : 1)) void k_track_direct
     }
   }
 
-  LaneSums<T, MOM> sums;
+  LaneSums<T, MOM, FULL> sums;
   sums.init();
   T shift[6];  // this wave's reference point: its first tracked particle (wave-uniform)
 #pragma unroll
@@ -1027,12 +1062,14 @@ __global__ __launch_bounds__(kTrackThreads, (XPOSE ? 3 : 1)) void k_track_direct
     // ds_bpermute per wave; this costs 29 stores and 64 loads per lane and is the larger part
     // of a workgroup's fixed cost when it only owns a few thousand particles.
     using R = typename MomScratch<MOM>::type;
+    using Sums = LaneSums<T, MOM, FULL>;
+    constexpr int kRows = Sums::kRows;  // 29 with the whole covariance, 16 with the property set
     __syncthreads();  // the scratch (build scratch / wave tiles) is reused
-    R* slab = reinterpret_cast<R*>(s_scratch) + wave * (29 * 65);
+    R* slab = reinterpret_cast<R*>(s_scratch) + wave * (kRows * 65);
     sums.park(slab, lane);
     __syncthreads();
     double tot = 0.0;
-    if (lane < 29) {
+    if (lane < kRows) {
       const R* row = slab + lane * 65;
 #pragma unroll 8
       for (int k = 0; k < 64; ++k) tot += (double)row[k];
@@ -1041,14 +1078,15 @@ __global__ __launch_bounds__(kTrackThreads, (XPOSE ? 3 : 1)) void k_track_direct
     // one record per wave (layout of moment_slot_moved), then the four are moved to wave 0's
     // reference point and added in wave order
     double* s_red = reinterpret_cast<double*>(s_scratch);  // [4][36]
-    if (lane < 28) s_red[wave * kPartialStride + lane] = tot;
-    if (lane == 28) s_red[wave * kPartialStride + 35] = tot;
+    if (lane < kPartialStride) s_red[wave * kPartialStride + lane] = 0.0;
+    __syncthreads();
+    if (lane < kRows) s_red[wave * kPartialStride + Sums::slot_of_row(lane)] = tot;
     // lane 0 publishes the reference point: it was assigned inside the loop, where lanes beyond the
     // end of the sample are no longer active and so never received it
     if (lane == 0) {
 #pragma unroll
       for (int k = 0; k < 6; ++k) s_red[wave * kPartialStride + 28 + k] = (double)shift[k];
-      s_red[wave * kPartialStride + 34] = 0.0;
+      s_red[wave * kPartialStride + 34] = FULL ? 1.0 : 0.0;  // which second moments the record carries
     }
     __syncthreads();
     double* out = partials + ((int64_t)b * a.chunks + chunk) * kPartialStride;
@@ -1067,15 +1105,19 @@ __global__ __launch_bounds__(kTrackThreads, (XPOSE ? 3 : 1)) void k_track_direct
 }
 
 // ---------------------------------------------------------------------------------------
-// k_finalize_moments: partials [B][chunks][36] -> moment records [B][36].
-// One workgroup per sample: 28 groups of 36 threads; thread (g, j) adds value j of the chunks
-// g, g + 28, ... (a group reads 36 consecutive doubles per chunk: coalesced), each moved to the
-// reference point of chunk 0 (moment_slot_moved); the 28 group sums are then added in group
-// order -- fixed assignment and order, no float atomics.
-// (The first version gave every thread whole rows and finished with 29 x 6 64-lane shuffles:
-// 12.6 us for the 131 chunks of BASELINE config 2, more than its streaming kernel.)
+// k_reduce_moments: adds up partial records in a fixed order -- no float atomics.
+//   grid = B x groups, 256 threads.  Workgroup (b, g) owns the rows [g * rows_per_group, ...) of
+//   sample b's `rows` input records; it stages up to 70 rows at a time in LDS with coalesced loads,
+//   thread (q, j) (7 sets of 36 threads) moves value j of staged rows q, q + 7, ... to the reference
+//   point of the group's first row (moment_slot_moved) and adds them in row order, the 7 set sums are
+//   then added in set order.
+//   FINAL = false: writes one partial record per group (same layout) -- the level of a reduction tree
+//                  when a sample has more rows than one workgroup should walk (a B = 1 beam of 8 M
+//                  particles has ~8000 of them);
+//   FINAL = true : writes the moment record of the sample (include/lynx_hip.h); groups must be 1.
 // ---------------------------------------------------------------------------------------
-constexpr int kFinalGroups = 28;
+constexpr int kReduceSets = 7;
+constexpr int kReduceStage = 70;  // rows staged per pass: 10 per set
 
 __device__ __forceinline__ void write_moment_record(const double* s, double* dst, int tid) {
   const double n = s[35];
@@ -1087,102 +1129,60 @@ __device__ __forceinline__ void write_moment_record(const double* s, double* dst
     int k = tid - 7, i = 0, row = 6;  // upper-triangle index -> (i, j)
     while (k >= row) { k -= row; --row; ++i; }
     const int j = i + k;
-    dst[tid] = (s[tid] - s[i] * s[j] / n) / n;
-  } else if (tid < 35) {
+    // a property-set record (s[34] == 0) carries the variances, cov(x, x') and cov(y, y') only
+    const bool have = s[34] != 0.0 || i == j || (i == 0 && j == 1) || (i == 2 && j == 3);
+    dst[tid] = have ? (s[tid] - s[i] * s[j] / n) / n : __longlong_as_double(0x7ff8000000000000ll);
+  } else if (tid < 34) {
     dst[tid] = 0.0;
+  } else if (tid == 34) {
+    dst[34] = s[34];
   } else if (tid == 35) {
     dst[35] = n;
   }
 }
 
-__global__ __launch_bounds__(1024) void k_finalize_moments(const double* __restrict__ partials,
-                                                            int chunks, double* __restrict__ out) {
-  __shared__ double s_g[kFinalGroups][kPartialStride];
+template <bool FINAL>
+__global__ __launch_bounds__(256) void k_reduce_moments(const double* __restrict__ in, int rows, int rows_per_group,
+                                                         int groups, double* __restrict__ out) {
+  __shared__ double s_rows[kReduceStage * kPartialStride];
+  __shared__ double s_set[kReduceSets][kPartialStride];
   __shared__ double s[kPartialStride];
-  __shared__ double s_c0[8];
-  const int64_t b = blockIdx.x;
+  const int64_t b = blockIdx.x / groups;
+  const int g = blockIdx.x % groups;
   const int tid = threadIdx.x;
-  const int g = tid / kPartialStride, j = tid - g * kPartialStride;
-  const double* src = partials + b * (int64_t)chunks * kPartialStride;
-  if (tid < 7) s_c0[tid] = src[28 + tid];  // reference point of chunk 0
-  __syncthreads();
-  if (g < kFinalGroups) {
-    double v = 0.0;
-    if (j < 28 || j == 35) {
-      // 4 independent rows in flight, added in chunk order (a B = 1 beam of 8 M particles has
-      // ~8000 chunks: one load per latency made this kernel as long as half the streaming pass)
-      int c = g;
-      for (; c + 3 * kFinalGroups < chunks; c += 4 * kFinalGroups) {
-        double t[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          t[q] = moment_slot_moved(src + (int64_t)(c + q * kFinalGroups) * kPartialStride, s_c0, j);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v += t[q];
-      }
-      for (; c < chunks; c += kFinalGroups) v += moment_slot_moved(src + (int64_t)c * kPartialStride, s_c0, j);
+  const int q = tid / kPartialStride, j = tid - q * kPartialStride;
+  const int lo = g * rows_per_group;
+  const int hi = (lo + rows_per_group) < rows ? (lo + rows_per_group) : rows;
+  const double* src = in + (b * (int64_t)rows + lo) * kPartialStride;
+  double v = 0.0;
+  double c0 = 0.0;  // thread j < 6 keeps component j of the reference point in a register too
+  for (int base = 0; base < hi - lo; base += kReduceStage) {
+    const int n_stage = (hi - lo - base) < kReduceStage ? (hi - lo - base) : kReduceStage;
+    __syncthreads();  // the previous pass is done with the staging area
+    for (int i = tid; i < n_stage * kPartialStride; i += 256) s_rows[i] = src[(int64_t)base * kPartialStride + i];
+    __syncthreads();
+    if (base == 0 && tid < 8) s[28 + tid] = tid < 7 ? s_rows[28 + tid] : 0.0;  // the group's reference point (s[35] set below)
+    __syncthreads();
+    if (q < kReduceSets && (j < 28 || j == 35)) {
+#pragma unroll 2
+      for (int r = q; r < n_stage; r += kReduceSets) v += moment_slot_moved(s_rows + r * kPartialStride, s + 28, j);
     }
-    s_g[g][j] = v;
+    (void)c0;
+  }
+  if (q < kReduceSets) s_set[q][j] = v;
+  __syncthreads();
+  if (tid < kPartialStride && (tid < 28 || tid == 35)) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < kReduceSets; ++k) t += s_set[k][tid];
+    s[tid] = t;
   }
   __syncthreads();
-  if (tid < kPartialStride) {
-    double v;
-    if (tid >= 28 && tid < 35) {
-      v = s_c0[tid - 28];
-    } else {
-      v = 0.0;
-#pragma unroll
-      for (int q = 0; q < kFinalGroups; ++q) v += s_g[q][tid];
-    }
-    s[tid] = v;
+  if (FINAL) {
+    write_moment_record(s, out + b * LYNX_MOMENT_STRIDE, tid);
+  } else if (tid < kPartialStride) {
+    out[(b * (int64_t)groups + g) * kPartialStride + tid] = s[tid];
   }
-  __syncthreads();
-  write_moment_record(s, out + b * LYNX_MOMENT_STRIDE, tid);
-}
-
-// Few chunks per sample (<= 64): 256 threads per sample = 7 groups of 36; thread (g, j) adds value j of
-// chunks g, g + 7, ... with all its loads in flight at once (<= 10 rows), the group sums are added in
-// group order.  (One wave per sample with the chunks in sequence took 7-18 us on BASELINE config 4.)
-constexpr int kFinalSmallGroups = 7;
-__global__ __launch_bounds__(256) void k_finalize_moments_small(const double* __restrict__ partials,
-                                                                 int chunks, double* __restrict__ out) {
-  __shared__ double s_g[kFinalSmallGroups][kPartialStride];
-  __shared__ double s[kPartialStride];
-  __shared__ double s_c0[8];
-  const int64_t b = blockIdx.x;
-  const int tid = threadIdx.x;
-  const int g = tid / kPartialStride, j = tid - g * kPartialStride;
-  const double* src = partials + b * (int64_t)chunks * kPartialStride;
-  if (tid < 7) s_c0[tid] = src[28 + tid];
-  __syncthreads();
-  if (g < kFinalSmallGroups) {
-    double v = 0.0;
-    if (j < 28 || j == 35) {
-      double t[10];
-#pragma unroll
-      for (int q = 0; q < 10; ++q) {
-        const int c = g + q * kFinalSmallGroups;
-        t[q] = c < chunks ? moment_slot_moved(src + (int64_t)c * kPartialStride, s_c0, j) : 0.0;
-      }
-#pragma unroll
-      for (int q = 0; q < 10; ++q) v += t[q];
-    }
-    s_g[g][j] = v;
-  }
-  __syncthreads();
-  if (tid < kPartialStride) {
-    double v;
-    if (tid >= 28 && tid < 35) {
-      v = s_c0[tid - 28];
-    } else {
-      v = 0.0;
-#pragma unroll
-      for (int q = 0; q < kFinalSmallGroups; ++q) v += s_g[q][tid];
-    }
-    s[tid] = v;
-  }
-  __syncthreads();
-  write_moment_record(s, out + b * LYNX_MOMENT_STRIDE, tid);
 }
 
 // ---------------------------------------------------------------------------------------

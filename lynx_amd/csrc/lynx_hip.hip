@@ -48,6 +48,8 @@ struct lynx_ctx {
   // internal scratch (grown on demand, stream-ordered reuse)
   void* scratch_partials = nullptr;
   size_t scratch_partials_bytes = 0;
+  void* scratch_level = nullptr;  // second level of the moment reduction (long beams)
+  size_t scratch_level_bytes = 0;
   void* scratch_steps[3] = {nullptr, nullptr, nullptr};  // two alternating step tables + the reverse pass's own
   size_t scratch_steps_bytes[3] = {0, 0, 0};
   void* scratch_grad[3] = {nullptr, nullptr, nullptr};  // backward: partials, T_bar, build scratch
@@ -181,7 +183,12 @@ int lynx_ctx_create(int device, lynx_ctx** out) {
   HIP_TRY(nullptr, hipSetDevice(device));
   HIP_TRY(nullptr, hipGetDeviceProperties(&ctx->prop, device));
   HIP_TRY(nullptr, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-  HIP_TRY(nullptr, hipStreamCreateWithFlags(&ctx->s_build, hipStreamNonBlocking));
+  {
+    // the build is short and the next streaming kernel waits for it: let its workgroups go first
+    int prio_low = 0, prio_high = 0;
+    HIP_TRY(nullptr, hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+    HIP_TRY(nullptr, hipStreamCreateWithPriority(&ctx->s_build, hipStreamNonBlocking, prio_high));
+  }
   for (int i = 0; i < 2; ++i) {
     HIP_TRY(nullptr, hipEventCreateWithFlags(&ctx->ev_built[i], hipEventDisableTiming));
     HIP_TRY(nullptr, hipEventCreateWithFlags(&ctx->ev_streamed[i], hipEventDisableTiming));
@@ -202,6 +209,7 @@ int lynx_ctx_destroy(lynx_ctx* ctx) {
   for (auto& kv : ctx->free_blocks) (void)hipFree(kv.second);
   for (auto& kv : ctx->live) (void)hipFree(kv.first);
   if (ctx->scratch_partials) (void)hipFree(ctx->scratch_partials);
+  if (ctx->scratch_level) (void)hipFree(ctx->scratch_level);
   for (int i = 0; i < 3; ++i) {
     if (ctx->scratch_steps[i]) (void)hipFree(ctx->scratch_steps[i]);
     if (ctx->scratch_grad[i]) (void)hipFree(ctx->scratch_grad[i]);
@@ -508,6 +516,7 @@ int lynx_build_compose(lynx_ctx* ctx, lynx_lattice* lat, const void* d_energy_in
 // ---- particle tracking -----------------------------------------------------------------
 
 struct TrackPlan {
+  bool full_cov; // accumulate the whole covariance (21 products) instead of the property set (8)
   int unroll;    // particles per lane and iteration
   int mom_mode;  // 1 = float64 per particle, 2 = float32 partial sums per iteration, 3 = float32 lane sums
   bool xpose;    // wave tiles through LDS (full-width accesses) instead of per-particle accesses
@@ -521,8 +530,9 @@ struct TrackPlan {
 //   LYNX_WGS_PER_CU=<n>      workgroups per CU over the whole launch
 template <typename T>
 static TrackPlan plan_track(lynx_ctx* ctx, const lynx_lattice* lat, int64_t B, int64_t N, int32_t S, bool fused,
-                            bool moments) {
+                            bool moments, bool full_cov) {
   TrackPlan p;
+  p.full_cov = full_cov;
   constexpr int P = 16 / (int)sizeof(T);  // particles per lane of a wave tile
   const int64_t cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
   const int64_t target = (int64_t)env_int("LYNX_WGS_PER_CU", 512) * cus;
@@ -533,7 +543,9 @@ static TrackPlan plan_track(lynx_ctx* ctx, const lynx_lattice* lat, int64_t B, i
   p.a.store = 0;
   p.a.interleave = env_int("LYNX_INTERLEAVE", 0);
   p.a.build_chunk = 1;
-  p.xpose = !p.a.fused_build && env_int("LYNX_XPOSE", 1) != 0;
+  // wave tiles: measured +10 % on float64 (BASELINE config 3 at 8 M particles), -3..8 % on float32, and
+  // slower on multi-step float32 programs, which want two particles per lane, not four
+  p.xpose = !p.a.fused_build && env_int("LYNX_XPOSE", sizeof(T) == 8 ? 1 : 0) != 0;
   int u = env_int("LYNX_UNROLL", p.xpose ? P : (sizeof(T) == 4 ? (S > 1 ? 2 : 4) : 1));
   if (u != 1 && u != 2 && u != 4) u = 2;
   if (sizeof(T) == 8 && u > 2) u = 2;
@@ -556,7 +568,8 @@ static TrackPlan plan_track(lynx_ctx* ctx, const lynx_lattice* lat, int64_t B, i
   if (p.mom_mode == 2 && !getenv("LYNX_MOM") && tpw * u <= 32) p.mom_mode = 3;
   if (p.mom_mode == 3 && tpw * u > 64) p.mom_mode = 2;
   size_t scratch = 4 * kPartialStride * sizeof(double);
-  if (moments) scratch = std::max<size_t>(scratch, (size_t)kMomSlabScalars * (p.mom_mode >= 2 ? 4 : 8));
+  if (moments)
+    scratch = std::max<size_t>(scratch, (size_t)(full_cov ? kMomSlabScalars : kMomSlabScalarsCompact) * (p.mom_mode >= 2 ? 4 : 8));
   if (p.xpose) scratch = std::max<size_t>(scratch, (size_t)(kTrackThreads / 64) * kWaveTileBytes);
   if (p.a.fused_build) {
     p.a.build_chunk = build_chunk(lat->n_elems, sizeof(T) == 4 ? 32 : 64);
@@ -569,11 +582,11 @@ static TrackPlan plan_track(lynx_ctx* ctx, const lynx_lattice* lat, int64_t B, i
   return p;
 }
 
-template <typename T, int MOM, int UNROLL, bool FUSED, bool XPOSE>
+template <typename T, int MOM, bool FULL, int UNROLL, bool FUSED, bool XPOSE>
 static int launch_direct_inst(lynx_ctx* ctx, const TrackPlan& p, const LatticeDev& lv, const void* d_energy_in,
                               const void* d_p_in, void* d_p_out, void* d_energy_out, const void* d_steps,
                               double* d_partials) {
-  int rc = allow_lds(ctx, k_track_direct<T, MOM, UNROLL, FUSED, XPOSE>, p.lds);
+  int rc = allow_lds(ctx, k_track_direct<T, MOM, FULL, UNROLL, FUSED, XPOSE>, p.lds);
   if (rc) return rc;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->profiling) {
@@ -581,7 +594,7 @@ static int launch_direct_inst(lynx_ctx* ctx, const TrackPlan& p, const LatticeDe
     HIP_TRY(ctx, hipEventCreate(&e1));
     HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
   }
-  hipLaunchKernelGGL((k_track_direct<T, MOM, UNROLL, FUSED, XPOSE>), dim3(p.grid), dim3(kTrackThreads), p.lds,
+  hipLaunchKernelGGL((k_track_direct<T, MOM, FULL, UNROLL, FUSED, XPOSE>), dim3(p.grid), dim3(kTrackThreads), p.lds,
                      ctx->stream, lv, p.a, (const T*)d_energy_in, (const T*)d_p_in, (T*)d_p_out, (T*)d_energy_out,
                      (const T*)d_steps, d_partials);
   HIP_TRY(ctx, hipGetLastError());
@@ -592,63 +605,65 @@ static int launch_direct_inst(lynx_ctx* ctx, const TrackPlan& p, const LatticeDe
   return LYNX_OK;
 }
 
-template <typename T, int MOM, int U>
-static int launch_direct_mu(lynx_ctx* ctx, const TrackPlan& p, const LatticeDev& lv, const void* d_energy_in,
-                            const void* d_p_in, void* d_p_out, void* d_energy_out, const void* d_steps,
-                            double* d_partials) {
-  if (p.a.fused_build)
-    return launch_direct_inst<T, MOM, U, true, false>(ctx, p, lv, d_energy_in, d_p_in, d_p_out, d_energy_out, d_steps, d_partials);
-  if constexpr (U * 7 * sizeof(T) == 112) {
-    if (p.xpose)
-      return launch_direct_inst<T, MOM, U, false, true>(ctx, p, lv, d_energy_in, d_p_in, d_p_out, d_energy_out, d_steps, d_partials);
+#define LYNX_LAUNCH_ARGS ctx, p, lv, d_energy_in, d_p_in, d_p_out, d_energy_out, d_steps, d_partials
+#define LYNX_LAUNCH_PARAMS                                                                                     \
+  lynx_ctx *ctx, const TrackPlan &p, const LatticeDev &lv, const void *d_energy_in, const void *d_p_in,        \
+      void *d_p_out, void *d_energy_out, const void *d_steps, double *d_partials
+
+template <typename T, int MOM, bool FULL, int U>
+static int launch_direct_mu(LYNX_LAUNCH_PARAMS) {
+  if (p.a.fused_build) {
+    // the fused prologue is an option for jobs of a few workgroups: one particle per lane only
+    if constexpr (U == 1) return launch_direct_inst<T, MOM, FULL, 1, true, false>(LYNX_LAUNCH_ARGS);
+    else return fail(ctx, LYNX_ERR_INVALID, "fused build: one particle per lane");
   }
-  return launch_direct_inst<T, MOM, U, false, false>(ctx, p, lv, d_energy_in, d_p_in, d_p_out, d_energy_out, d_steps, d_partials);
+  if constexpr (U * 7 * sizeof(T) == 112) {
+    if (p.xpose) return launch_direct_inst<T, MOM, FULL, U, false, true>(LYNX_LAUNCH_ARGS);
+  }
+  return launch_direct_inst<T, MOM, FULL, U, false, false>(LYNX_LAUNCH_ARGS);
 }
 
-template <typename T, int MOM>
-static int launch_direct_m(lynx_ctx* ctx, const TrackPlan& p, const LatticeDev& lv, const void* d_energy_in,
-                           const void* d_p_in, void* d_p_out, void* d_energy_out, const void* d_steps,
-                           double* d_partials) {
+template <typename T, int MOM, bool FULL>
+static int launch_direct_m(LYNX_LAUNCH_PARAMS) {
   switch (p.unroll) {
-    case 1: return launch_direct_mu<T, MOM, 1>(ctx, p, lv, d_energy_in, d_p_in, d_p_out, d_energy_out, d_steps, d_partials);
-    case 2: return launch_direct_mu<T, MOM, 2>(ctx, p, lv, d_energy_in, d_p_in, d_p_out, d_energy_out, d_steps, d_partials);
+    case 1: return launch_direct_mu<T, MOM, FULL, 1>(LYNX_LAUNCH_ARGS);
+    case 2: return launch_direct_mu<T, MOM, FULL, 2>(LYNX_LAUNCH_ARGS);
     default:
-      if constexpr (sizeof(T) == 4)
-        return launch_direct_mu<T, MOM, 4>(ctx, p, lv, d_energy_in, d_p_in, d_p_out, d_energy_out, d_steps, d_partials);
-      else
-        return fail(ctx, LYNX_ERR_INVALID, "float64: at most 2 particles per lane");
+      if constexpr (sizeof(T) == 4) return launch_direct_mu<T, MOM, FULL, 4>(LYNX_LAUNCH_ARGS);
+      else return fail(ctx, LYNX_ERR_INVALID, "float64: at most 2 particles per lane");
   }
 }
 
 template <typename T>
-static int launch_direct(lynx_ctx* ctx, const TrackPlan& p, const LatticeDev& lv, const void* d_energy_in,
-                         const void* d_p_in, void* d_p_out, void* d_energy_out, const void* d_steps,
-                         double* d_partials, bool moments) {
+static int launch_direct(LYNX_LAUNCH_PARAMS, bool moments) {
   const int mom = moments ? p.mom_mode : 0;
-  if (mom == 0) return launch_direct_m<T, 0>(ctx, p, lv, d_energy_in, d_p_in, d_p_out, d_energy_out, d_steps, d_partials);
+  if (mom == 0) return launch_direct_m<T, 0, false>(LYNX_LAUNCH_ARGS);
   if constexpr (sizeof(T) == 4) {
-    if (mom == 3) return launch_direct_m<T, 3>(ctx, p, lv, d_energy_in, d_p_in, d_p_out, d_energy_out, d_steps, d_partials);
-    return launch_direct_m<T, 2>(ctx, p, lv, d_energy_in, d_p_in, d_p_out, d_energy_out, d_steps, d_partials);
+    if (mom == 3) return p.full_cov ? launch_direct_m<T, 3, true>(LYNX_LAUNCH_ARGS) : launch_direct_m<T, 3, false>(LYNX_LAUNCH_ARGS);
+    return p.full_cov ? launch_direct_m<T, 2, true>(LYNX_LAUNCH_ARGS) : launch_direct_m<T, 2, false>(LYNX_LAUNCH_ARGS);
   } else {
-    return launch_direct_m<T, 1>(ctx, p, lv, d_energy_in, d_p_in, d_p_out, d_energy_out, d_steps, d_partials);
+    return p.full_cov ? launch_direct_m<T, 1, true>(LYNX_LAUNCH_ARGS) : launch_direct_m<T, 1, false>(LYNX_LAUNCH_ARGS);
   }
 }
+#undef LYNX_LAUNCH_ARGS
+#undef LYNX_LAUNCH_PARAMS
 
 template <typename T>
 static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev& lv, int64_t B, int64_t N,
                              const void* d_energy_in, const void* d_p_in, void* d_p_out, void* d_energy_out,
                              double* d_moments_out, int flags) {
   const int32_t S = lv.n_steps;
-  const bool moments = (flags & LYNX_TRACK_MOMENTS) != 0;
+  const bool moments = (flags & (LYNX_TRACK_MOMENTS | LYNX_TRACK_COVARIANCE)) != 0;
   // Fused prologue vs separate build launch.  Default: separate launch (LYNX_FUSE_MAX_CHUNKS
   // = 0).  In the fused variant every workgroup of a sample rebuilds that sample's maps in
   // its prologue; that only pays with few, long-lived workgroups per sample, which stream
   // ~15 % slower than many small ones, and it forces the step table
   // through LDS instead of scalar loads.  Set LYNX_FUSE_MAX_CHUNKS=<n> to fuse whenever a
   // sample is covered by <= n workgroups.
-  TrackPlan p = plan_track<T>(ctx, lat, B, N, S, true, moments);
-  bool fused = S > 0 && !(flags & LYNX_TRACK_TWO_KERNEL) && p.a.chunks <= env_int("LYNX_FUSE_MAX_CHUNKS", 0);
-  if (!fused) p = plan_track<T>(ctx, lat, B, N, S, false, moments);
+  const bool full_cov = (flags & LYNX_TRACK_COVARIANCE) != 0;
+  TrackPlan p = plan_track<T>(ctx, lat, B, N, S, true, moments, full_cov);
+  bool fused = S > 0 && !(flags & LYNX_TRACK_TWO_KERNEL) && p.a.chunks <= env_int("LYNX_FUSE_MAX_CHUNKS", 0) && p.unroll == 1;
+  if (!fused) p = plan_track<T>(ctx, lat, B, N, S, false, moments, full_cov);
   p.a.store = d_p_out ? 1 : 0;
   const bool shared_in = (flags & LYNX_TRACK_SHARED_INPUT) != 0;
   p.a.in_stride = shared_in ? 0 : N * 7;
@@ -667,7 +682,10 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
       has_pair |= lat->h_steps[s].kind == LYNX_STEP_CAVITY && lat->h_steps[s - 1].kind == LYNX_STEP_RUN;
     p.a.merged_pairs = has_pair && sizeof(T) == 4 && p.unroll % 2 == 0 &&
                        !(flags & LYNX_TRACK_SEQUENTIAL_STEPS) && env_int("LYNX_MERGE_STEPS", 1);
-    const bool async = env_int("LYNX_ASYNC_BUILD", 1) != 0;
+    // The second stream pays once the streaming kernel is long enough to hide a build under; below a few
+    // million particles per call the extra event traffic costs more host time than the overlap returns
+    // (BASELINE config 2: 31 -> 46 us per call with it).
+    const bool async = env_int("LYNX_ASYNC_BUILD", B * N >= (int64_t)4 << 20 ? 1 : 0) != 0;
     hipStream_t bs = async ? ctx->s_build : ctx->stream;
     if (async) {
       // the table slot was last read by the streaming kernel two calls ago
@@ -702,12 +720,23 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
   }
   if (d_energy_out) ctx->main_wrote = d_energy_out;  // a later build that reads it must wait for this kernel
   if (moments) {
-    if (p.a.chunks <= 64)
-      hipLaunchKernelGGL(k_finalize_moments_small, dim3((unsigned)B), dim3(256), 0, ctx->stream, d_partials,
-                         p.a.chunks, d_moments_out);
-    else
-      hipLaunchKernelGGL(k_finalize_moments, dim3((unsigned)B), dim3(1024), 0, ctx->stream, d_partials, p.a.chunks,
-                         d_moments_out);
+    // records of the workgroups -> record of the sample: one pass for up to 70 rows, otherwise a level of
+    // <= 64 groups in between (rows_per_group grows with the beam, the walk stays short)
+    int rows = p.a.chunks;
+    const double* level_in = d_partials;
+    if (rows > kReduceStage) {
+      const int rpg = (rows + 63) / 64;
+      const int groups = (rows + rpg - 1) / rpg;
+      const size_t need = (size_t)B * groups * kPartialStride * sizeof(double);
+      if ((rc = ensure_scratch(ctx, &ctx->scratch_level, &ctx->scratch_level_bytes, need))) return rc;
+      hipLaunchKernelGGL(k_reduce_moments<false>, dim3((unsigned)(B * groups)), dim3(256), 0, ctx->stream, level_in, rows,
+                         rpg, groups, (double*)ctx->scratch_level);
+      HIP_TRY(ctx, hipGetLastError());
+      level_in = (const double*)ctx->scratch_level;
+      rows = groups;
+    }
+    hipLaunchKernelGGL(k_reduce_moments<true>, dim3((unsigned)B), dim3(256), 0, ctx->stream, level_in, rows, rows, 1,
+                       d_moments_out);
     HIP_TRY(ctx, hipGetLastError());
   }
   return LYNX_OK;
@@ -719,8 +748,8 @@ int lynx_track_particles(lynx_ctx* ctx, lynx_lattice* lat, int64_t n_particles, 
   if (!ctx || !lat || !d_p_in) return fail(ctx, LYNX_ERR_INVALID, "null argument");
   if (n_particles <= 0) return fail(ctx, LYNX_ERR_INVALID, "n_particles must be > 0");
   if (lat->n_steps > 0 && !d_energy_in) return fail(ctx, LYNX_ERR_INVALID, "energy_in required");
-  if ((flags & LYNX_TRACK_MOMENTS) && !d_moments_out)
-    return fail(ctx, LYNX_ERR_INVALID, "LYNX_TRACK_MOMENTS needs d_moments_out");
+  if ((flags & (LYNX_TRACK_MOMENTS | LYNX_TRACK_COVARIANCE)) && !d_moments_out)
+    return fail(ctx, LYNX_ERR_INVALID, "LYNX_TRACK_MOMENTS / LYNX_TRACK_COVARIANCE need d_moments_out");
   if ((flags & LYNX_TRACK_SHARED_INPUT) && d_p_in == d_p_out)
     return fail(ctx, LYNX_ERR_INVALID, "a shared incoming beam cannot be tracked in place");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -859,7 +888,7 @@ int lynx_track_moments_backward(lynx_ctx* ctx, lynx_lattice* lat, const void* d_
 }
 
 int lynx_moments(lynx_ctx* ctx, int dtype, int64_t batch, int64_t n_particles, const void* d_p,
-                 double* d_moments_out) {
+                 double* d_moments_out, int32_t covariance) {
   if (!ctx || !d_p || !d_moments_out) return fail(ctx, LYNX_ERR_INVALID, "null argument");
   if (batch <= 0 || n_particles <= 0) return fail(ctx, LYNX_ERR_INVALID, "bad shape");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -868,9 +897,9 @@ int lynx_moments(lynx_ctx* ctx, int dtype, int64_t batch, int64_t n_particles, c
   lv.batch = batch;
   return dtype == LYNX_F64
              ? track_particles_t<double>(ctx, nullptr, lv, batch, n_particles, nullptr, d_p, nullptr, nullptr,
-                                         d_moments_out, LYNX_TRACK_MOMENTS)
+                                         d_moments_out, covariance ? LYNX_TRACK_COVARIANCE : LYNX_TRACK_MOMENTS)
              : track_particles_t<float>(ctx, nullptr, lv, batch, n_particles, nullptr, d_p, nullptr, nullptr,
-                                        d_moments_out, LYNX_TRACK_MOMENTS);
+                                        d_moments_out, covariance ? LYNX_TRACK_COVARIANCE : LYNX_TRACK_MOMENTS);
 }
 
 // ---- ParameterBeam ---------------------------------------------------------------------

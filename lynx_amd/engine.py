@@ -351,7 +351,8 @@ def run_program_particles(cache, program: Program, beam, moments: bool | None = 
     e_out = rt.empty(batch_shape, dtype) if lat.has_cavity_step else None
     want_moments = config.fused_moments if moments is None else moments
     mom = rt.empty((*batch_shape, _ffi.MOMENT_STRIDE), np.float64) if want_moments else None
-    flags = ((_ffi.TRACK_MOMENTS if want_moments else 0) | (_ffi.TRACK_TWO_KERNEL if config.two_kernel else 0)
+    flags = ((0 if not want_moments else _ffi.TRACK_COVARIANCE if config.fused_covariance else _ffi.TRACK_MOMENTS)
+             | (_ffi.TRACK_TWO_KERNEL if config.two_kernel else 0)
              | (_ffi.TRACK_SHARED_INPUT if beam.is_shared else 0)
              | (0 if config.merge_steps else _ffi.TRACK_SEQUENTIAL_STEPS))
     rt.check(rt.lib.lynx_track_particles(rt.ctx, lat.handle, beam.num_particles, _ptr(e_in), _ptr(p_in),

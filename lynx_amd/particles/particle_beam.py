@@ -343,18 +343,35 @@ class ParticleBeam(Beam):
     ps = property(lambda self: self._coordinate(5), lambda self, v: self._set_coordinate(5, v))
 
     # -- moments: one fused GPU pass (particle_beam.py:736-836) ---------------------------------
-    def moment_record(self) -> np.ndarray:
-        """(*batch, 36) float64 record, layout in include/lynx_hip.h."""
-        if self._moments is None:
+    def moment_record(self, covariance: bool = False) -> np.ndarray:
+        """
+        (*batch, 36) float64 record, layout in include/lynx_hip.h.  By default it holds what the
+        reference's properties need (means, the six variances, cov(x, x'), cov(y, y'); the other
+        covariance entries are NaN); `covariance=True` makes sure the whole 6x6 triangle is there,
+        at the price of one more pass over the beam if it was not accumulated before.
+        """
+        have = self._moments
+        if have is not None and covariance and not np.all(have.host()[..., 34] == 1.0):
+            have = None
+        if have is None:
             rt = get_runtime()
             p = self._particles.device(rt)
             stored = tuple(self._particles.shape[:-2])  # a shared beam has one stored sample
             B = int(np.prod(stored, dtype=np.int64))
             rec = rt.empty((*stored, _ffi.MOMENT_STRIDE), np.float64)
             rt.check(rt.lib.lynx_moments(rt.ctx, dtype_code(self.dtype), B, self.num_particles,
-                                         C.c_void_p(p.ptr), C.c_void_p(rec.ptr)))
+                                         C.c_void_p(p.ptr), C.c_void_p(rec.ptr), 1 if covariance else 0))
             self._moments = Dual(dev=rec)
         return self._full(self._moments.host(), 1)
+
+    def covariance(self) -> np.ndarray:
+        """Biased 6x6 covariance matrix of the particles, (*batch, 6, 6) float64 (one pass on the GPU)."""
+        rec = self.moment_record(covariance=True)
+        out = np.empty((*rec.shape[:-1], 6, 6))
+        for i in range(6):
+            for j in range(i, 6):
+                out[..., i, j] = out[..., j, i] = rec[..., _tri(i, j)]
+        return out
 
     def _mean(self, c: int) -> np.ndarray:
         return self.moment_record()[..., c].astype(self.dtype)

@@ -509,9 +509,38 @@ def test_moment_readout_of_existing_beam(lx, dtype):
 def test_fused_moments_equal_separate_pass(lx):
     out, _ = _particle_case(lx, ARES, np.float32, (1,), 50_000, seed=0)
     fused = out.moment_record().copy()
-    again = lx.ParticleBeam(np.asarray(out.particles), out.energy, dtype=np.float32).moment_record()
-    assert np.allclose(fused[..., :28], again[..., :28], rtol=1e-9, atol=1e-30)
+    fresh = lx.ParticleBeam(np.asarray(out.particles), out.energy, dtype=np.float32)
+    again = fresh.moment_record()
+    assert np.allclose(fused[..., :28], again[..., :28], rtol=1e-9, atol=1e-30, equal_nan=True)
     assert fused[..., 35] == again[..., 35] == 50_000
+    # the fused record carries what the reference's properties need; the rest of the covariance is NaN ...
+    have = [7, 8, 13, 18, 19, 22, 25, 27]
+    assert not np.isnan(fused[..., :7]).any() and not np.isnan(fused[..., have]).any()
+    assert np.isnan(np.delete(fused[..., 7:28], [h - 7 for h in have], axis=-1)).all() and fused[0, 34] == 0.0
+    # ... until somebody asks for it: one more pass, whole 6x6 matrix, same values where both exist
+    cov = out.covariance()
+    P = np.asarray(out.particles)[0, :, :6].astype(np.float64)
+    want = np.cov(P.T, bias=True)
+    s = np.sqrt(np.outer(np.diag(want), np.diag(want)))
+    assert np.max(np.abs(cov[0] - want) / s) < 1e-6
+    full = out.moment_record()
+    assert full[0, 34] == 1.0 and np.allclose(full[..., have], fused[..., have], rtol=1e-6)
+
+
+def test_fused_covariance_switch(lx):
+    """`config.fused_covariance`: the tracking kernel's epilogue accumulates all 21 products."""
+    lx.config.fused_covariance = True
+    try:
+        out, ref = _particle_case(lx, ARES, np.float64, (1,), 20_000, seed=5)
+    finally:
+        lx.config.fused_covariance = False
+    rec = out.moment_record()
+    assert np.all(rec[..., 34] == 1.0) and not np.isnan(rec).any()
+    P = ref["particles"][..., :6]
+    for b in range(1):
+        want = np.cov(P[b].T, bias=True)
+        s = np.sqrt(np.outer(np.diag(want), np.diag(want)))
+        assert np.max(np.abs(out.covariance()[b] - want) / s) < 1e-9
 
 
 def test_two_kernel_path_is_bit_identical_to_fused(lx):
@@ -660,7 +689,7 @@ def test_c3_size_round_trip_and_map_consistency(lx):
     back = inv.track(out)
     a, b = np.asarray(beam.particles), np.asarray(back.particles)
     assert np.max(np.abs(a - b) / (np.abs(a).max(axis=(0, 1)) + 1e-300)) < 1e-9
-    rec_in, rec_out = beam.moment_record()[0], out.moment_record()[0]
+    rec_in, rec_out = beam.moment_record(covariance=True)[0], out.moment_record(covariance=True)[0]
     cov_in = np.zeros((6, 6))
     cov_out = np.zeros((6, 6))
     k = 7
@@ -804,7 +833,7 @@ def test_lazily_broadcast_beam_tracks_like_the_repeated_one(lx, dtype):
     a, b = seg.track(shared), seg.track(repeated)
     assert not a.is_shared
     assert np.array_equal(np.asarray(a.particles), np.asarray(b.particles))
-    assert np.array_equal(a.moment_record(), b.moment_record())
+    assert np.array_equal(a.moment_record(), b.moment_record(), equal_nan=True)
     assert np.array_equal(a.particle_charges, b.particle_charges) and np.array_equal(a.energy, b.energy)
     # a single element, a write to a coordinate, the reverse pass and the screen all accept it
     assert np.array_equal(np.asarray(seg.elements[1].track(shared).particles), np.asarray(seg.elements[1].track(repeated).particles))
