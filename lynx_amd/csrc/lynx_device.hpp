@@ -22,6 +22,13 @@
 
 namespace lynx {
 
+// clang native vectors (HIP's float4/double2 structs defeat SROA and land in scratch)
+typedef float lynx_f32x4 __attribute__((ext_vector_type(4)));
+typedef double lynx_f64x2 __attribute__((ext_vector_type(2)));
+template <typename T, bool VEC> struct VecOf { using type = T; static constexpr int width = 1; };
+template <> struct VecOf<float, true> { using type = lynx_f32x4; static constexpr int width = 4; };
+template <> struct VecOf<double, true> { using type = lynx_f64x2; static constexpr int width = 2; };
+
 struct LatticeDev {
   const lynx_elem* elems;
   const lynx_step* steps;
@@ -206,6 +213,262 @@ __device__ void build_compose_sample(const LatticeDev& lat, int64_t b, T energy_
       }
     }
     __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Build + compose with LANES = SAMPLES (large batches).
+//
+// The per-sample workgroup above keeps one element per lane busy in phase 1 and seven lanes per
+// product in phase 2: for a batch of thousands of samples that is ~10x more wave-instructions than
+// the arithmetic needs, and a build that runs underneath the previous call's streaming kernel
+// takes exactly that share of the GPU away from it.  Here a wave owns 64 consecutive samples and
+// every lane does ITS sample's arithmetic in registers -- no divergence (all lanes build the same
+// element), no LDS, no barrier:
+//
+//   k_build_pieces   task (64 samples, piece): a piece is a stretch of <= L consecutive elements of one
+//                    step.  The lane builds each element's map in T (the reference's precision), widens
+//                    it to float64 and left-multiplies it onto the piece's running product, column by
+//                    column in place.  Result: slot `piece` of the product buffer, [slot][49][Bp]
+//                    float64 with the sample index fastest (coalesced), plus the cavity coefficients.
+//   k_pair_products  one level of the pairwise tree over the pieces of a step: dst = X[later] . X[earlier].
+//                    The levels are planned on the host from the lattice structure (who multiplies whom
+//                    into which slot) and launched one after the other on the build stream.
+//   k_emit_steps     task (64 samples, step): the step's product times eye(7) unless raw (segment.py:331,
+//                    explicit so that NaN / Inf spread as in the reference), the merged [run, cavity] form,
+//                    rounding to T and the row-major step table the streaming kernel reads.
+//
+// Same mathematics and the same float64 accumulation as build_compose_sample; only the association of
+// the products can differ (pieces instead of chunks), i.e. differences at the 1e-16 level before the
+// final rounding to T.
+// ---------------------------------------------------------------------------------------
+struct BuildPiece {
+  int32_t first, last;  // elements [first, last)
+  int32_t step;
+  int32_t pad;
+};
+struct PairTask {
+  int32_t a, b, dst;  // dst = X[b] . X[a]  (b is the later stretch)
+  int32_t pad;
+};
+
+// beam energy in front of step `s_target` for sample b: incoming energy plus the gain of every active
+// cavity before it (cavity.py:130)
+template <typename T>
+__device__ __forceinline__ T energy_before_step(const LatticeDev& lat, int64_t b, T energy_in, int s_target) {
+  const T* pool = static_cast<const T*>(lat.pool);
+  T e = energy_in;
+  for (int s = 0; s < s_target; ++s) {
+    const lynx_step st = lat.steps[s];
+    if (st.kind == LYNX_STEP_CAVITY && (st.flags & LYNX_FLAG_CAV_GAIN)) {
+      const lynx_elem el = lat.elems[st.first];
+      const T* p = pool + el.param_offset + b * (int64_t)el.batch_stride;
+      e = e + p[1] * t_cos(p[2] * T(LYNX_PI / 180.0));
+    }
+  }
+  return e;
+}
+
+// LDS of k_build_pieces: the running product [49][64] float64 (sample index fastest: conflict-free) and
+// every lane's element map [64][49] T (49 is odd: conflict-free); a lane only ever touches its own cells,
+// so the wave needs no barrier.  Registers hold one element map and one column of the product -- the
+// kernel has to fit next to the streaming kernel's waves to run underneath it.
+template <typename T> constexpr size_t build_pieces_lds() { return 49 * 64 * sizeof(double) + 64 * 49 * sizeof(T); }
+
+template <typename T>
+__global__ __launch_bounds__(64) void k_build_pieces(LatticeDev lat, const BuildPiece* __restrict__ pieces,
+                                                     const T* __restrict__ energy_in, int64_t Bp,
+                                                     double* __restrict__ products, T* __restrict__ coefs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* P = reinterpret_cast<double*>(smem_raw) + threadIdx.x;                       // P[q * 64]
+  T* M = reinterpret_cast<T*>(smem_raw + 49 * 64 * sizeof(double)) + threadIdx.x * 49;  // M[q]
+  const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const bool live = b_raw < lat.batch;
+  const int64_t b = live ? b_raw : lat.batch - 1;  // idle lanes shadow the last sample, write nothing
+  const BuildPiece pc = pieces[blockIdx.y];
+  const T* pool = static_cast<const T*>(lat.pool);
+  const lynx_step st = lat.steps[pc.step];
+  const T energy = energy_before_step<T>(lat, b, energy_in[b], pc.step);
+  T coef[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) coef[q] = T(0);
+  for (int e = pc.first; e < pc.last; ++e) {
+    const lynx_elem el = lat.elems[e];
+    const T* p = pool + el.param_offset + b * (int64_t)el.batch_stride;
+    build_element<T>(el.kind, el.flags, p, energy, M, st.kind == LYNX_STEP_CAVITY ? coef : nullptr);
+    LYNX_FORGET();
+    if (e == pc.first) {
+#pragma unroll 7
+      for (int q = 0; q < 49; ++q) P[q * 64] = (double)M[q];
+    } else {
+      T m[49];
+#pragma unroll
+      for (int q = 0; q < 49; ++q) m[q] = M[q];
+      // P <- M . P, one column of P at a time (a column of the product needs only that column of P)
+#pragma unroll 1
+      for (int j = 0; j < 7; ++j) {
+        double col[7], out[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) col[k] = P[(k * 7 + j) * 64];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+          double acc = (double)m[i * 7] * col[0];
+#pragma unroll
+          for (int k = 1; k < 7; ++k) acc = fma((double)m[i * 7 + k], col[k], acc);
+          out[i] = acc;
+        }
+#pragma unroll
+        for (int i = 0; i < 7; ++i) P[(i * 7 + j) * 64] = out[i];
+      }
+    }
+    LYNX_FORGET();
+  }
+  if (live) {
+    double* dst = products + (int64_t)blockIdx.y * 49 * Bp + b;
+#pragma unroll 7
+    for (int q = 0; q < 49; ++q) dst[q * Bp] = P[q * 64];
+    if (st.kind == LYNX_STEP_CAVITY) {
+      T* cd = coefs + (int64_t)pc.step * 8 * Bp + b;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) cd[q * Bp] = coef[q];
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void k_pair_products(const PairTask* __restrict__ tasks, int64_t B, int64_t Bp,
+                                                      double* products) {
+  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  const PairTask t = tasks[blockIdx.y];
+  const double* xa = products + (int64_t)t.a * 49 * Bp + b;
+  const double* xb = products + (int64_t)t.b * 49 * Bp + b;
+  double* xd = products + (int64_t)t.dst * 49 * Bp + b;
+  double A[49];  // the earlier stretch: right factor, resident
+#pragma unroll
+  for (int q = 0; q < 49; ++q) A[q] = xa[q * Bp];
+#pragma unroll 1
+  for (int i = 0; i < 7; ++i) {
+    double r[7], out[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) r[k] = xb[(i * 7 + k) * Bp];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      double acc = r[0] * A[j];
+#pragma unroll
+      for (int k = 1; k < 7; ++k) acc = fma(r[k], A[k * 7 + j], acc);
+      out[j] = acc;
+    }
+#pragma unroll
+    for (int j = 0; j < 7; ++j) xd[(i * 7 + j) * Bp] = out[j];
+  }
+}
+
+// LDS of k_emit_steps: every lane's table row [64][68] T (pitch 68: 16-byte aligned rows, conflict-free
+// 16-byte reads).  Maps are streamed row by row from the product buffer; only the run's map of a merged
+// [run, cavity] pair is held in registers, already rounded to T.
+template <typename T> constexpr size_t emit_steps_lds() { return 64 * 68 * sizeof(T); }
+
+// row i of a step's final map: product . eye(7) unless raw (segment.py:331-335), multiplied out so that a
+// NaN / Inf entry spreads along its row exactly as in the reference; finite entries come back unchanged
+__device__ __forceinline__ void emit_row(const double* src, int64_t Bp, int i, bool raw, double (&out)[7]) {
+  double x[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) x[k] = src[(i * 7 + k) * Bp];
+  if (raw) {
+#pragma unroll
+    for (int j = 0; j < 7; ++j) out[j] = x[j];
+  } else {
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      double acc = x[0] * (j == 0 ? 1.0 : 0.0);
+#pragma unroll
+      for (int k = 1; k < 7; ++k) acc = fma(x[k], (j == k ? 1.0 : 0.0), acc);
+      out[j] = acc;
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void k_emit_steps(LatticeDev lat, const int32_t* __restrict__ step_slot,
+                                                   const T* __restrict__ energy_in, int64_t Bp,
+                                                   const double* __restrict__ products, const T* __restrict__ coefs,
+                                                   int merge_pairs, T* __restrict__ steps_out, T* __restrict__ energy_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* row = reinterpret_cast<T*>(smem_raw) + threadIdx.x * 68;
+  const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const bool live = b_raw < lat.batch;
+  const int64_t b = live ? b_raw : lat.batch - 1;
+  const int s = blockIdx.y, S = lat.n_steps;
+  const lynx_step st = lat.steps[s];
+  const bool raw = st.kind == LYNX_STEP_CAVITY || (st.flags & LYNX_STEP_FLAG_RAW);
+  const double* src = products + (int64_t)step_slot[s] * 49 * Bp + b;
+  const bool pair_cavity = merge_pairs && st.kind == LYNX_STEP_CAVITY && s > 0 && lat.steps[s - 1].kind == LYNX_STEP_RUN;
+  const bool pair_run = merge_pairs && st.kind == LYNX_STEP_RUN && s + 1 < S && lat.steps[s + 1].kind == LYNX_STEP_CAVITY;
+#pragma unroll
+  for (int q = 49; q < LYNX_STEP_STRIDE; ++q) row[q] = T(0);
+  if (pair_cavity) {
+    // slot of the cavity <- T_cav . T_run: the product of the two ROUNDED maps, accumulated in float64
+    const lynx_step sr = lat.steps[s - 1];
+    const double* rsrc = products + (int64_t)step_slot[s - 1] * 49 * Bp + b;
+    T R[49];
+#pragma unroll 1
+    for (int i = 0; i < 7; ++i) {
+      double o[7];
+      emit_row(rsrc, Bp, i, (sr.flags & LYNX_STEP_FLAG_RAW) != 0, o);
+#pragma unroll
+      for (int j = 0; j < 7; ++j) row[i * 7 + j] = (T)o[j];  // parked in the row buffer, then into registers
+    }
+    LYNX_FORGET();
+#pragma unroll
+    for (int q = 0; q < 49; ++q) R[q] = row[q];
+#pragma unroll 1
+    for (int i = 0; i < 7; ++i) {
+      double x[7];
+      emit_row(src, Bp, i, true, x);
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        double acc = (double)(T)x[0] * (double)R[j];
+#pragma unroll
+        for (int k = 1; k < 7; ++k) acc = fma((double)(T)x[k], (double)R[k * 7 + j], acc);
+        row[i * 7 + j] = (T)acc;
+      }
+    }
+  } else {
+#pragma unroll 1
+    for (int i = 0; i < 7; ++i) {
+      double o[7];
+      emit_row(src, Bp, i, raw, o);
+#pragma unroll
+      for (int j = 0; j < 7; ++j) row[i * 7 + j] = (T)o[j];
+    }
+    if (pair_run) {  // rows 4 and 5 in front: they give the s and delta entering the cavity
+      LYNX_FORGET();
+      T t[14];
+#pragma unroll
+      for (int q = 0; q < 14; ++q) t[q] = row[28 + q];
+#pragma unroll
+      for (int q = 0; q < 14; ++q) row[q] = t[q];
+    }
+  }
+  if (st.kind == LYNX_STEP_CAVITY) {
+    const T* cs = coefs + (int64_t)s * 8 * Bp + b;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) row[LYNX_COEF_OFFSET + q] = cs[q * Bp];
+  }
+  if (s == S - 1) {
+    const T e_out = energy_before_step<T>(lat, b, energy_in[b], S);
+    row[LYNX_ENERGY_OFFSET] = e_out;
+    if (energy_out && live) energy_out[b] = e_out;
+  }
+  LYNX_FORGET();
+  if (live) {
+    // the sample's row of the table: 64 scalars, contiguous, as 16-byte vectors
+    using V = typename VecOf<T, true>::type;
+    constexpr int W = VecOf<T, true>::width;
+    V* dst = reinterpret_cast<V*>(steps_out + (b * (int64_t)S + s) * LYNX_STEP_STRIDE);
+    const V* from = reinterpret_cast<const V*>(row);
+#pragma unroll 4
+    for (int v = 0; v < LYNX_STEP_STRIDE / W; ++v) dst[v] = from[v];
   }
 }
 
@@ -446,12 +709,6 @@ __global__ __launch_bounds__(1024) void k_build(LatticeDev lat, const T* __restr
   if (energy_out && threadIdx.x == 0) energy_out[b] = s_energy[lat.n_steps];
 }
 
-// clang native vectors (HIP's float4/double2 structs defeat SROA and land in scratch)
-typedef float lynx_f32x4 __attribute__((ext_vector_type(4)));
-typedef double lynx_f64x2 __attribute__((ext_vector_type(2)));
-template <typename T, bool VEC> struct VecOf { using type = T; static constexpr int width = 1; };
-template <> struct VecOf<float, true> { using type = lynx_f32x4; static constexpr int width = 4; };
-template <> struct VecOf<double, true> { using type = lynx_f64x2; static constexpr int width = 2; };
 
 struct TrackArgs {
   int64_t n_particles;

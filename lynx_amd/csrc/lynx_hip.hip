@@ -50,6 +50,10 @@ struct lynx_ctx {
   size_t scratch_partials_bytes = 0;
   void* scratch_level = nullptr;  // second level of the moment reduction (long beams)
   size_t scratch_level_bytes = 0;
+  void* scratch_products = nullptr;  // lanes = samples build: piece / pair products [slot][49][Bp] float64
+  size_t scratch_products_bytes = 0;
+  void* scratch_coefs = nullptr;     // ... and cavity coefficients [S][8][Bp]
+  size_t scratch_coefs_bytes = 0;
   void* scratch_steps[3] = {nullptr, nullptr, nullptr};  // two alternating step tables + the reverse pass's own
   size_t scratch_steps_bytes[3] = {0, 0, 0};
   void* scratch_grad[3] = {nullptr, nullptr, nullptr};  // backward: partials, T_bar, build scratch
@@ -73,6 +77,14 @@ struct lynx_lattice {
   lynx_step* d_steps = nullptr;
   int32_t* d_elem_step = nullptr;
   void* d_pool = nullptr;
+  // lanes = samples build (large batches): pieces, the levels of the pairwise tree over them, and
+  // where each step's product ends up -- planned once from the step structure
+  int plan_piece_len = 0;
+  int32_t n_pieces = 0, n_slots = 0;
+  std::vector<std::pair<int32_t, int32_t>> levels;  // (first task, number of tasks) per level
+  BuildPiece* d_pieces = nullptr;
+  PairTask* d_tasks = nullptr;
+  int32_t* d_step_slot = nullptr;
 };
 
 static thread_local std::string g_err;
@@ -210,6 +222,8 @@ int lynx_ctx_destroy(lynx_ctx* ctx) {
   for (auto& kv : ctx->live) (void)hipFree(kv.first);
   if (ctx->scratch_partials) (void)hipFree(ctx->scratch_partials);
   if (ctx->scratch_level) (void)hipFree(ctx->scratch_level);
+  if (ctx->scratch_products) (void)hipFree(ctx->scratch_products);
+  if (ctx->scratch_coefs) (void)hipFree(ctx->scratch_coefs);
   for (int i = 0; i < 3; ++i) {
     if (ctx->scratch_steps[i]) (void)hipFree(ctx->scratch_steps[i]);
     if (ctx->scratch_grad[i]) (void)hipFree(ctx->scratch_grad[i]);
@@ -439,6 +453,9 @@ int lynx_lattice_destroy(lynx_lattice* lat) {
   ctx_free(ctx, lat->d_steps);
   ctx_free(ctx, lat->d_elem_step);
   ctx_free(ctx, lat->d_pool);
+  if (lat->d_pieces) ctx_free(ctx, lat->d_pieces);
+  if (lat->d_tasks) ctx_free(ctx, lat->d_tasks);
+  if (lat->d_step_slot) ctx_free(ctx, lat->d_step_slot);
   delete lat;
   return LYNX_OK;
 }
@@ -488,9 +505,94 @@ static void build_shape(lynx_ctx* ctx, const lynx_lattice* lat, int* threads, in
   *chunk = build_chunk(lat->n_elems, limit);
 }
 
+// Plan of the lanes = samples build for this lattice: pieces of <= L elements inside each step, then
+// levels of pair products until every step is one slot.
+static int plan_lanes_build(lynx_ctx* ctx, lynx_lattice* lat, int L) {
+  if (lat->plan_piece_len == L && lat->d_pieces) return LYNX_OK;
+  std::vector<BuildPiece> pieces;
+  std::vector<std::vector<int32_t>> live(lat->n_steps);
+  for (int32_t s = 0; s < lat->n_steps; ++s) {
+    const lynx_step& st = lat->h_steps[s];
+    for (int32_t e = st.first; e < st.last; e += L) {
+      live[s].push_back((int32_t)pieces.size());
+      pieces.push_back(BuildPiece{e, std::min<int32_t>(e + L, st.last), s, 0});
+    }
+  }
+  int32_t next = (int32_t)pieces.size();
+  std::vector<PairTask> tasks;
+  std::vector<std::pair<int32_t, int32_t>> levels;
+  for (;;) {
+    const int32_t first = (int32_t)tasks.size();
+    for (auto& slots : live) {
+      if (slots.size() < 2) continue;
+      std::vector<int32_t> merged;
+      for (size_t k = 0; k + 1 < slots.size(); k += 2) {
+        tasks.push_back(PairTask{slots[k], slots[k + 1], next, 0});
+        merged.push_back(next++);
+      }
+      if (slots.size() & 1) merged.push_back(slots.back());
+      slots.swap(merged);
+    }
+    if ((int32_t)tasks.size() == first) break;
+    levels.emplace_back(first, (int32_t)tasks.size() - first);
+  }
+  std::vector<int32_t> step_slot(std::max<int32_t>(1, lat->n_steps), 0);
+  for (int32_t s = 0; s < lat->n_steps; ++s) step_slot[s] = live[s][0];
+  if (lat->d_pieces) ctx_free(ctx, lat->d_pieces);
+  if (lat->d_tasks) ctx_free(ctx, lat->d_tasks);
+  if (lat->d_step_slot) ctx_free(ctx, lat->d_step_slot);
+  lat->d_pieces = nullptr; lat->d_tasks = nullptr; lat->d_step_slot = nullptr;
+  int rc;
+  if ((rc = ctx_alloc(ctx, std::max<size_t>(1, pieces.size()) * sizeof(BuildPiece), (void**)&lat->d_pieces)) ||
+      (rc = ctx_alloc(ctx, std::max<size_t>(1, tasks.size()) * sizeof(PairTask), (void**)&lat->d_tasks)) ||
+      (rc = ctx_alloc(ctx, step_slot.size() * sizeof(int32_t), (void**)&lat->d_step_slot)))
+    return rc;
+  // plain synchronous copies: planning happens once per lattice structure
+  HIP_TRY(ctx, hipMemcpy(lat->d_pieces, pieces.data(), pieces.size() * sizeof(BuildPiece), hipMemcpyHostToDevice));
+  if (!tasks.empty()) HIP_TRY(ctx, hipMemcpy(lat->d_tasks, tasks.data(), tasks.size() * sizeof(PairTask), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(lat->d_step_slot, step_slot.data(), step_slot.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  lat->plan_piece_len = L;
+  lat->n_pieces = (int32_t)pieces.size();
+  lat->n_slots = next;
+  lat->levels.swap(levels);
+  return LYNX_OK;
+}
+
+template <typename T>
+static int launch_build_lanes(lynx_ctx* ctx, lynx_lattice* lat, hipStream_t stream, const void* d_energy_in,
+                              void* d_steps_out, void* d_energy_out, int merge_pairs) {
+  int rc;
+  if ((rc = plan_lanes_build(ctx, lat, std::max(1, env_int("LYNX_PIECE", 8))))) return rc;
+  const int64_t groups = (lat->batch + 63) / 64, Bp = groups * 64;
+  if (lat->n_pieces > 65535 || lat->n_steps > 65535) return fail(ctx, LYNX_ERR_INVALID, "lattice too long for the lanes build");
+  if ((rc = ensure_scratch(ctx, &ctx->scratch_products, &ctx->scratch_products_bytes, (size_t)lat->n_slots * 49 * Bp * sizeof(double))))
+    return rc;
+  if ((rc = ensure_scratch(ctx, &ctx->scratch_coefs, &ctx->scratch_coefs_bytes, (size_t)std::max(1, lat->n_steps) * 8 * Bp * sizeof(T))))
+    return rc;
+  const LatticeDev lv = dev_view(lat);
+  if ((rc = allow_lds(ctx, k_build_pieces<T>, build_pieces_lds<T>()))) return rc;
+  hipLaunchKernelGGL(k_build_pieces<T>, dim3((unsigned)groups, (unsigned)lat->n_pieces), dim3(64), build_pieces_lds<T>(), stream, lv,
+                     lat->d_pieces, (const T*)d_energy_in, Bp, (double*)ctx->scratch_products, (T*)ctx->scratch_coefs);
+  HIP_TRY(ctx, hipGetLastError());
+  for (const auto& level : lat->levels) {
+    hipLaunchKernelGGL(k_pair_products, dim3((unsigned)groups, (unsigned)level.second), dim3(64), 0, stream,
+                       lat->d_tasks + level.first, lat->batch, Bp, (double*)ctx->scratch_products);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  hipLaunchKernelGGL(k_emit_steps<T>, dim3((unsigned)groups, (unsigned)lat->n_steps), dim3(64), emit_steps_lds<T>(), stream, lv,
+                     lat->d_step_slot, (const T*)d_energy_in, Bp, (const double*)ctx->scratch_products,
+                     (const T*)ctx->scratch_coefs, merge_pairs, (T*)d_steps_out, (T*)d_energy_out);
+  HIP_TRY(ctx, hipGetLastError());
+  return LYNX_OK;
+}
+
 template <typename T>
 static int launch_build(lynx_ctx* ctx, lynx_lattice* lat, hipStream_t stream, const void* d_energy_in,
                         void* d_steps_out, void* d_energy_out, int merge_pairs = 0) {
+  // large batches: lanes = samples (an order of magnitude fewer wave-instructions); small ones: one
+  // workgroup per sample, whose tree is shallower than a chain of launches
+  if (lat->n_steps > 0 && lat->batch >= env_int("LYNX_LANES_BUILD_MIN_BATCH", 256))
+    return launch_build_lanes<T>(ctx, lat, stream, d_energy_in, d_steps_out, d_energy_out, merge_pairs);
   int threads, chunk;
   build_shape<T>(ctx, lat, &threads, &chunk);
   const size_t lds = build_scratch_bytes(chunk, sizeof(T)) +

@@ -402,6 +402,73 @@ def test_c1_ares_segment_parameter_beam(lx, dtype):
     assert map_err(tm, o.segment_transfer_map(specs, beam.energy, dtype)) < TOL_MAP[dtype]
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("B", [1, 70, 300])
+def test_lanes_build_agrees_with_the_workgroup_build(lx, dtype, B, monkeypatch):
+    """
+    The two builders of the step table -- one workgroup per sample (small batches) and lanes = samples
+    (large batches: k_build_pieces / k_pair_products / k_emit_steps) -- on the same lattice: every element
+    kind, tilt, misalignment, cavities between runs, a run longer than a piece, a batch that is not a
+    multiple of 64.  Same float64 accumulation, different association: float32 results agree to the
+    last bit or two, float64 to ~1e-15; both agree with the oracle.
+    """
+    rng = np.random.default_rng(17)
+    f = lambda v: np.full(B, v)  # noqa: E731
+    desc = [("drift", dict(length=f(0.6))),
+            ("quadrupole", dict(length=f(0.2), k1=rng.uniform(-5, 5, B), tilt=rng.uniform(-1, 1, B),
+                                misalignment=rng.normal(0, 1e-4, (B, 2)))),
+            ("marker", {}),
+            ("dipole", dict(length=f(0.5), angle=rng.uniform(-0.2, 0.2, B), e1=f(0.05), e2=f(0.02),
+                            fringe_integral=f(0.4), gap=f(0.02), tilt=f(0.1))),
+            ("cavity", dict(length=f(1.0377), voltage=rng.uniform(5e6, 2e7, B), phase=rng.uniform(-10, 10, B),
+                            frequency=f(1.3e9)))]
+    for _ in range(5):  # a 20-element run: three pieces of 8, 8, 4
+        desc += [("quadrupole", dict(length=f(0.2), k1=rng.uniform(-5, 5, B))), ("drift", dict(length=f(0.5))),
+                 ("hcor", dict(length=f(0.1), angle=rng.normal(0, 1e-4, B))), ("solenoid", dict(length=f(0.1), k=f(0.5)))]
+    desc += [("cavity", dict(length=f(1.0377), voltage=rng.uniform(5e6, 2e7, B), phase=f(2.0), frequency=f(1.3e9))),
+             ("rbend", dict(length=f(0.3), angle=f(0.05))), ("vcor", dict(length=f(0.1), angle=rng.normal(0, 1e-4, B)))]
+    results = {}
+    for name, min_batch in (("workgroup", "1000000"), ("lanes", "1")):
+        monkeypatch.setenv("LYNX_LANES_BUILD_MIN_BATCH", min_batch)
+        out, ref = _particle_case(lx, desc, dtype, (B,), 700, seed=8, energy=6e6, sigma=[1e-4, 1e-5, 1e-4, 1e-5, 1e-4, 1e-3])
+        results[name] = (np.asarray(out.particles), np.asarray(out.energy), out.moment_record().copy())
+        got = np.asarray(out.particles)
+        tol = {np.float32: [3e-4] * 4 + [3e-3, 3e-3, 1e-6], np.float64: [1e-9] * 7}[dtype]
+        for c in range(7):
+            assert rel_err(got[..., c], ref["particles"][..., c]) < tol[c], (name, c)
+        assert rel_err(out.energy, ref["energy"]) < 1e-6
+    a, b = results["workgroup"], results["lanes"]
+    close = 2e-6 if dtype == np.float32 else 1e-12
+    for c in range(7):
+        assert rel_err(b[0][..., c], a[0][..., c]) < close, c
+    assert np.array_equal(a[1], b[1])
+    # a skippable lattice as ONE composed map, through both builders
+    skippable = [d for d in desc if d[0] != "cavity"]
+    energy = np.full(B, 1e8, dtype=dtype)
+    maps = {}
+    for name, min_batch in (("workgroup", "1000000"), ("lanes", "1")):
+        monkeypatch.setenv("LYNX_LANES_BUILD_MIN_BATCH", min_batch)
+        maps[name] = lx.Segment(make_lattice(skippable, dtype, lx)[0]).transfer_map(energy)
+    assert map_err(maps["lanes"], maps["workgroup"]) < (1e-6 if dtype == np.float32 else 1e-13)
+
+
+def test_lanes_build_spreads_nan_like_the_reference(lx, monkeypatch):
+    """A switched-off cavity inside a run carries the reference's NaN (cavity.py:269); the product with the
+    rest of the run and with eye(7) must spread it the same way in both builders."""
+    desc = [("drift", dict(length=[0.5] * 3)),
+            ("cavity", dict(length=[1.0] * 3, voltage=[0.0, 0.0, 0.0], phase=[0.0] * 3, frequency=[1.3e9] * 3)),
+            ("quadrupole", dict(length=[0.2] * 3, k1=[1.0, -2.0, 3.0]))]
+    energy = np.array([1e8, 6e6, 1.0732e8], dtype=np.float32)
+    maps = {}
+    for name, min_batch in (("workgroup", "1000000"), ("lanes", "1")):
+        monkeypatch.setenv("LYNX_LANES_BUILD_MIN_BATCH", min_batch)
+        elements, specs = make_lattice(desc, np.float32, lx)
+        maps[name] = lx.Segment(elements).transfer_map(energy)
+    ref = o.segment_transfer_map(specs, energy, np.float32)
+    assert np.array_equal(np.isnan(maps["lanes"]), np.isnan(ref)) and np.array_equal(np.isnan(maps["workgroup"]), np.isnan(ref))
+    assert np.isnan(ref).any()
+
+
 def test_cavity_mixed_zero_voltage_batch_matches_reference_nan(lx):
     """reference tests/test_vectorized.py:423-439: no error; V = 0 rows carry the reference's NaN."""
     desc = [("cavity", dict(length=[3.0441] * 3, voltage=[0.0, 48198468.0, 0.0], phase=[48198468.0] * 3,
