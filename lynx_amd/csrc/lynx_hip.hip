@@ -784,10 +784,10 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
       has_pair |= lat->h_steps[s].kind == LYNX_STEP_CAVITY && lat->h_steps[s - 1].kind == LYNX_STEP_RUN;
     p.a.merged_pairs = has_pair && sizeof(T) == 4 && p.unroll % 2 == 0 &&
                        !(flags & LYNX_TRACK_SEQUENTIAL_STEPS) && env_int("LYNX_MERGE_STEPS", 1);
-    // The second stream pays once the streaming kernel is long enough to hide a build under; below a few
+    // The second stream pays once the streaming kernel is long enough to hide a build under; below half a
     // million particles per call the extra event traffic costs more host time than the overlap returns
     // (BASELINE config 2: 31 -> 46 us per call with it).
-    const bool async = env_int("LYNX_ASYNC_BUILD", B * N >= (int64_t)4 << 20 ? 1 : 0) != 0;
+    const bool async = env_int("LYNX_ASYNC_BUILD", B * N >= (int64_t)512 << 10 ? 1 : 0) != 0;
     hipStream_t bs = async ? ctx->s_build : ctx->stream;
     if (async) {
       // the table slot was last read by the streaming kernel two calls ago
