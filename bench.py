@@ -240,6 +240,9 @@ def main():
     ap.add_argument("--allow-host-gather", action="store_true",
                     help="N > 1 only: if the RCCL communicator cannot be built, gather the moment records through the "
                          "rendezvous sockets instead of failing (config.gather says so); without it the run exits 3")
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="do not bracket the streaming kernel with HIP events (then `roofline.achieved` is null): "
+                         "shows what the per-launch time stamps themselves cost a step")
     ap.add_argument("--sync-every-step", action="store_true",
                     help="latency mode: wait for the GPU after every step (no overlap between consecutive calls)")
     args = ap.parse_args()
@@ -347,14 +350,15 @@ def main():
     rt.sync()
     rdzv.barrier()
     rt.sync()
-    rt.profile_begin()
+    if not args.no_kernel_timing:
+        rt.profile_begin()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         last = step()
     rt.sync()
     elapsed = time.perf_counter() - t0  # this rank's K steps, GPU drained
     rdzv.barrier()
-    kern_ms, launches = rt.profile_end()
+    kern_ms, launches = rt.profile_end() if not args.no_kernel_timing else (0.0, 0)
     elapsed = rdzv.max(elapsed)  # the slowest rank's clock between the two barriers
 
     # sanity on the last result (outside the timed region): finite moments, right count

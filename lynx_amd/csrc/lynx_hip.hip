@@ -3,6 +3,7 @@
 // device allocator (so that `track()` never pays hipMalloc on the hot path), the
 // moment-reduction scratch and, optionally, an RCCL communicator.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
@@ -33,7 +34,8 @@ struct lynx_ctx {
   // build stream in turn waits for the main stream when (a) it reuses a table slot (ev_streamed) or
   // (b) the main stream may have written what the build reads (`main_dirty`, `main_wrote`).
   hipStream_t s_build = nullptr;
-  hipEvent_t ev_built[2] = {nullptr, nullptr}, ev_streamed[2] = {nullptr, nullptr}, ev_mark = nullptr;
+  hipEvent_t ev_built[2] = {nullptr, nullptr}, ev_streamed_own[2] = {nullptr, nullptr}, ev_mark = nullptr;
+  hipEvent_t ev_streamed[2] = {nullptr, nullptr};  // the slot's current "streamed" event: its own, or a profiled launch's
   bool streamed_valid[2] = {false, false};
   unsigned seq = 0;
   bool main_dirty = false;            // unsynchronised device writes on the main stream (any buffer)
@@ -63,6 +65,7 @@ struct lynx_ctx {
   // per-launch profiling of k_track (lynx_profile_begin / _end)
   bool profiling = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  hipEvent_t last_stream_stop = nullptr;
 };
 
 struct lynx_lattice {
@@ -203,7 +206,7 @@ int lynx_ctx_create(int device, lynx_ctx** out) {
   }
   for (int i = 0; i < 2; ++i) {
     HIP_TRY(nullptr, hipEventCreateWithFlags(&ctx->ev_built[i], hipEventDisableTiming));
-    HIP_TRY(nullptr, hipEventCreateWithFlags(&ctx->ev_streamed[i], hipEventDisableTiming));
+    HIP_TRY(nullptr, hipEventCreateWithFlags(&ctx->ev_streamed_own[i], hipEventDisableTiming));
   }
   HIP_TRY(nullptr, hipEventCreateWithFlags(&ctx->ev_mark, hipEventDisableTiming));
   HIP_TRY(nullptr, hipEventCreate(&ctx->ev_start));
@@ -230,7 +233,7 @@ int lynx_ctx_destroy(lynx_ctx* ctx) {
   }
   for (int i = 0; i < 2; ++i) {
     (void)hipEventDestroy(ctx->ev_built[i]);
-    (void)hipEventDestroy(ctx->ev_streamed[i]);
+    (void)hipEventDestroy(ctx->ev_streamed_own[i]);
   }
   (void)hipEventDestroy(ctx->ev_mark);
   (void)hipEventDestroy(ctx->ev_start);
@@ -284,6 +287,9 @@ int lynx_profile_begin(lynx_ctx* ctx) {
 int lynx_profile_end(lynx_ctx* ctx, double* total_ms, int64_t* launches) {
   ctx->profiling = false;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  // every build is followed by its streaming kernel on the main stream, so both streams are idle now;
+  // the per-launch stop events stood in for the step-table slots' "streamed" events and go away here
+  ctx->streamed_valid[0] = ctx->streamed_valid[1] = false;
   double total = 0.0;
   for (auto& pr : ctx->prof_events) {
     float ms = 0.f;
@@ -618,6 +624,7 @@ int lynx_build_compose(lynx_ctx* ctx, lynx_lattice* lat, const void* d_energy_in
 // ---- particle tracking -----------------------------------------------------------------
 
 struct TrackPlan {
+  hipEvent_t done = nullptr;  // recorded when the streaming kernel has finished (may be null)
   bool full_cov; // accumulate the whole covariance (21 products) instead of the property set (8)
   int unroll;    // particles per lane and iteration
   int mom_mode;  // 1 = float64 per particle, 2 = float32 partial sums per iteration, 3 = float32 lane sums
@@ -690,20 +697,21 @@ static int launch_direct_inst(lynx_ctx* ctx, const TrackPlan& p, const LatticeDe
                               double* d_partials) {
   int rc = allow_lds(ctx, k_track_direct<T, MOM, FULL, UNROLL, FUSED, XPOSE>, p.lds);
   if (rc) return rc;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (ctx->profiling) {
+  // Events ride on the dispatch itself (hipExtLaunchKernelGGL: start / stop timestamps of this kernel)
+  // instead of separate marker packets in front of and behind it: `done` is what the build stream waits
+  // for before it reuses the step-table slot, and with profiling on (bench.py) the pair is also the
+  // kernel's duration.
+  hipEvent_t e0 = nullptr, e1 = p.done;
+  if (ctx->profiling) {  // every profiled launch needs time stamps of its own
     HIP_TRY(ctx, hipEventCreate(&e0));
     HIP_TRY(ctx, hipEventCreate(&e1));
-    HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
   }
-  hipLaunchKernelGGL((k_track_direct<T, MOM, FULL, UNROLL, FUSED, XPOSE>), dim3(p.grid), dim3(kTrackThreads), p.lds,
-                     ctx->stream, lv, p.a, (const T*)d_energy_in, (const T*)d_p_in, (T*)d_p_out, (T*)d_energy_out,
-                     (const T*)d_steps, d_partials);
+  hipExtLaunchKernelGGL((k_track_direct<T, MOM, FULL, UNROLL, FUSED, XPOSE>), dim3(p.grid), dim3(kTrackThreads),
+                        (std::uint32_t)p.lds, ctx->stream, e0, e1, 0u, lv, p.a, (const T*)d_energy_in, (const T*)d_p_in,
+                        (T*)d_p_out, (T*)d_energy_out, (const T*)d_steps, d_partials);
   HIP_TRY(ctx, hipGetLastError());
-  if (ctx->profiling) {
-    HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
-    ctx->prof_events.emplace_back(e0, e1);
-  }
+  if (ctx->profiling) ctx->prof_events.emplace_back(e0, e1);
+  ctx->last_stream_stop = e1;  // what "this streaming kernel has finished" is, for the build stream
   return LYNX_OK;
 }
 
@@ -814,10 +822,11 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
     if ((rc = ensure_scratch(ctx, &ctx->scratch_partials, &ctx->scratch_partials_bytes, need))) return rc;
     d_partials = (double*)ctx->scratch_partials;
   }
+  p.done = (slot >= 0) ? ctx->ev_streamed_own[slot] : nullptr;
   rc = launch_direct<T>(ctx, p, lv, d_energy_in, d_p_in, d_p_out, d_energy_out, d_steps, d_partials, moments);
   if (rc) return rc;
   if (slot >= 0) {
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_streamed[slot], ctx->stream));
+    ctx->ev_streamed[slot] = ctx->last_stream_stop;
     ctx->streamed_valid[slot] = true;
   }
   if (d_energy_out) ctx->main_wrote = d_energy_out;  // a later build that reads it must wait for this kernel
