@@ -88,6 +88,12 @@ typedef struct lynx_step {
  * signed zeros and in how a NaN entry spreads (NaN * 0).  Cavity steps are always raw
  * (cavity.py:113-121). */
 #define LYNX_STEP_FLAG_RAW 64
+/* Run step that holds exactly one identity element (an active BPM, bpm.py:48-58): while the particles
+ * pass it, the streaming kernel adds up their x and y -- the BPM's reading, `stack([mu_x, mu_y])` of
+ * the beam that ENTERS it -- without splitting the pass there.  At most LYNX_MAX_OBSERVERS per
+ * program; their sums come back through `d_observations` of lynx_track_particles. */
+#define LYNX_STEP_FLAG_OBSERVE 128
+#define LYNX_MAX_OBSERVERS 8
 
 /* flags of lynx_track_particles */
 #define LYNX_TRACK_MOMENTS 1     /* also accumulate the output-beam moments (fused epilogue) */
@@ -181,10 +187,13 @@ int lynx_build_compose(lynx_ctx* ctx, lynx_lattice* lat, const void* d_energy_in
 /* Segment.track on a ParticleBeam (reference: segment.py:340-356 -> element.py:83-92
  * `particles @ tm^T`, cavity.py:141-161,219-226).
  *   d_p_in / d_p_out [B][N][7]  (may alias; d_p_in [N][7] with LYNX_TRACK_SHARED_INPUT)
- *   d_moments_out    [B][36] float64 or NULL (needs LYNX_TRACK_MOMENTS)                    */
+ *   d_moments_out    [B][36] float64 or NULL (needs LYNX_TRACK_MOMENTS)
+ *   d_observations   [B][n_observers][2] float64 or NULL: mean x and mean y of the beam entering
+ *                    each LYNX_STEP_FLAG_OBSERVE step, in lattice order (BPM.reading, bpm.py:48-54);
+ *                    required when the program has such steps                                 */
 int lynx_track_particles(lynx_ctx* ctx, lynx_lattice* lat, int64_t n_particles,
                          const void* d_energy_in, const void* d_p_in, void* d_p_out,
-                         void* d_energy_out, double* d_moments_out, int flags);
+                         void* d_energy_out, double* d_moments_out, int flags, double* d_observations);
 
 /* Segment.track on a ParameterBeam (reference: element.py:71-82 mu'=T mu, cov'=T cov T^T;
  * cavity.py:134-140,202-218).  d_mu [B][7], d_cov [B][7][7] (in/out may alias).            */

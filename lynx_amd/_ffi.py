@@ -29,6 +29,8 @@ FLAG_CAV_BETA, FLAG_CAV_GAIN, FLAG_CAV_T5XX = 8, 16, 32
 
 STEP_RUN, STEP_CAVITY = 0, 1
 STEP_FLAG_RAW = 64
+STEP_FLAG_OBSERVE = 128
+MAX_OBSERVERS = 8
 
 TRACK_MOMENTS, TRACK_TWO_KERNEL, TRACK_SHARED_INPUT, TRACK_SEQUENTIAL_STEPS, TRACK_COVARIANCE = 1, 2, 4, 8, 16
 
@@ -81,7 +83,7 @@ SIGNATURES = {
     "lynx_lattice_set_flags": (_i, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "lynx_lattice_destroy": (_i, [_vp]),
     "lynx_build_compose": (_i, [_vp, _vp, _vp, _vp, _vp]),
-    "lynx_track_particles": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i]),
+    "lynx_track_particles": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "lynx_track_moments": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "lynx_track_particles_backward": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "lynx_track_moments_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -48,13 +48,39 @@ class BPM(Element):
     :param name: Unique identifier of the element.
     """
 
-    _transient = Element._transient + ("reading",)
-    reading = None
+    _transient = Element._transient + ("_reading", "_pending_reading")
+    _reading = None
+    _pending_reading = None
 
     def __init__(self, is_active: bool = False, name: Optional[str] = None) -> None:
         super().__init__(name=name)
         self.is_active = is_active
         self.reading = None
+
+    @property
+    def reading(self):
+        """`stack([mu_x, mu_y])` of the last beam that entered the active BPM (bpm.py:50-54), shape (2, *batch).
+        After a ParticleBeam pass it still sits in HBM (the streaming kernel summed x and y on the way) and
+        is copied to the host here, on first look."""
+        pending = self.__dict__.get("_pending_reading")
+        if pending is not None:
+            obs, k, batch_shape, dtype = pending
+            host = obs.numpy()[:, k, :].reshape(*batch_shape, 2)
+            object.__setattr__(self, "_reading", np.stack([host[..., 0], host[..., 1]]).astype(dtype))
+            object.__setattr__(self, "_pending_reading", None)
+        return self._reading
+
+    @reading.setter
+    def reading(self, value):
+        object.__setattr__(self, "_pending_reading", None)
+        object.__setattr__(self, "_reading", value)
+
+    def _reading_from(self, obs, k, batch_shape, dtype) -> None:
+        object.__setattr__(self, "_pending_reading", (obs, k, tuple(batch_shape), np.dtype(dtype)))
+
+    @property
+    def _fusable_observer(self) -> bool:
+        return bool(self.is_active)
 
     @property
     def is_skippable(self) -> bool:

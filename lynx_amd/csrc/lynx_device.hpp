@@ -39,6 +39,12 @@ struct LatticeDev {
   int32_t n_steps;
 };
 
+// a run directly in front of an active cavity can be applied together with it -- unless it is an
+// observer (its step must stay visible to the streaming kernel)
+__device__ __forceinline__ bool steps_pair_up(const lynx_step& run, const lynx_step& cav) {
+  return run.kind == LYNX_STEP_RUN && cav.kind == LYNX_STEP_CAVITY && !(run.flags & LYNX_STEP_FLAG_OBSERVE);
+}
+
 constexpr int kBuildChunk = 64;   // elements built in parallel per compose round (k_build may use up to 128)
 constexpr int kTrackThreads = 256;
 constexpr int kPartialStride = 36;
@@ -402,8 +408,8 @@ __global__ __launch_bounds__(64) void k_emit_steps(LatticeDev lat, const int32_t
   const lynx_step st = lat.steps[s];
   const bool raw = st.kind == LYNX_STEP_CAVITY || (st.flags & LYNX_STEP_FLAG_RAW);
   const double* src = products + (int64_t)step_slot[s] * 49 * Bp + b;
-  const bool pair_cavity = merge_pairs && st.kind == LYNX_STEP_CAVITY && s > 0 && lat.steps[s - 1].kind == LYNX_STEP_RUN;
-  const bool pair_run = merge_pairs && st.kind == LYNX_STEP_RUN && s + 1 < S && lat.steps[s + 1].kind == LYNX_STEP_CAVITY;
+  const bool pair_cavity = merge_pairs && s > 0 && steps_pair_up(lat.steps[s - 1], st);
+  const bool pair_run = merge_pairs && s + 1 < S && steps_pair_up(st, lat.steps[s + 1]);
 #pragma unroll
   for (int q = 49; q < LYNX_STEP_STRIDE; ++q) row[q] = T(0);
   if (pair_cavity) {
@@ -684,7 +690,7 @@ __global__ __launch_bounds__(1024) void k_build(LatticeDev lat, const T* __restr
     // 7x7 application per pair instead of two), slot of the run <- rows 4 and 5 of T_run, which
     // give the s and delta that ENTER the cavity and drive its non-linear kick
     for (int s = 1; s < lat.n_steps; ++s) {
-      if (lat.steps[s].kind != LYNX_STEP_CAVITY || lat.steps[s - 1].kind != LYNX_STEP_RUN) continue;  // uniform
+      if (!steps_pair_up(lat.steps[s - 1], lat.steps[s])) continue;  // uniform
       T* run = s_steps + (s - 1) * LYNX_STEP_STRIDE;
       T* cav = s_steps + s * LYNX_STEP_STRIDE;
       T v = T(0);
@@ -721,6 +727,7 @@ struct TrackArgs {
   int32_t interleave;    // 1 = a workgroup takes every `chunks`-th tile
   int64_t in_stride;     // scalars between the samples of p_in: N*7, or 0 for one shared incoming beam
   int32_t merged_pairs;  // the step table holds [run, cavity] pairs in merged form (see k_build)
+  int32_t n_observers;   // LYNX_STEP_FLAG_OBSERVE steps of the program (their sums live behind the step table in LDS)
 };
 
 __device__ __forceinline__ float uniform_value(float v) {
@@ -1037,7 +1044,9 @@ struct LaneSums {
 // all of them; fp32 with an even UNROLL runs the particles as packed pairs
 template <typename T, int UNROLL, bool SCALAR_TABLE>
 __device__ __forceinline__ void apply_program_lane(const LatticeDev& lat, int S, const T* g_steps, const T* s_steps,
-                                                   int merged_pairs, T (&z)[UNROLL][7]) {
+                                                   int merged_pairs, T (&z)[UNROLL][7],
+                                                   double* s_obs = nullptr /* this lane's [observer][x, y] sums, pitch 256 */,
+                                                   const bool (*live)[UNROLL] = nullptr) {
   constexpr bool kMapInRegs = sizeof(T) == 4;
   constexpr bool kPairs = kMapInRegs && UNROLL % 2 == 0;
   lynx_f32x2 zp[kPairs ? UNROLL / 2 : 1][7];
@@ -1050,6 +1059,7 @@ __device__ __forceinline__ void apply_program_lane(const LatticeDev& lat, int S,
         zp[u / 2][c].y = (float)z[u + 1][c];
       }
   }
+  int n_obs = 0;
   for (int sidx = 0; sidx < S; ++sidx) {
     // merged [run, cavity] pair (see k_build): the run's slot holds the two rows that give the
     // s and delta entering the cavity; they are formed first (their 14 scalars are dead before
@@ -1058,9 +1068,28 @@ __device__ __forceinline__ void apply_program_lane(const LatticeDev& lat, int S,
     bool merged = false;
     lynx_f32x2 s_entry[kPairs ? UNROLL / 2 : 1], d_entry[kPairs ? UNROLL / 2 : 1];
     lynx_step st = lat.steps[sidx];
+    if (s_obs && (st.flags & LYNX_STEP_FLAG_OBSERVE) && st.kind == LYNX_STEP_RUN) {  // uniform
+      // an active BPM: x and y of the particles that enter it, added up per lane in float64 (LDS cells of
+      // this lane only: no barrier); bpm.py:48-54 reads mu_x, mu_y of the incoming beam
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        double x, y;
+        if constexpr (kPairs) {
+          x = (u & 1) ? (double)zp[u / 2][0].y : (double)zp[u / 2][0].x;
+          y = (u & 1) ? (double)zp[u / 2][2].y : (double)zp[u / 2][2].x;
+        } else {
+          x = (double)z[u][0];
+          y = (double)z[u][2];
+        }
+        if (!live || (*live)[u]) {
+          s_obs[(2 * n_obs + 0) * 256] += x;
+          s_obs[(2 * n_obs + 1) * 256] += y;
+        }
+      }
+      ++n_obs;
+    }
     if constexpr (kPairs && SCALAR_TABLE) {
-      if (merged_pairs && st.kind == LYNX_STEP_RUN && sidx + 1 < S &&
-          lat.steps[sidx + 1].kind == LYNX_STEP_CAVITY) {  // uniform
+      if (merged_pairs && sidx + 1 < S && steps_pair_up(st, lat.steps[sidx + 1])) {  // uniform
         const float* tab = reinterpret_cast<const float*>(g_steps) + sidx * LYNX_STEP_STRIDE;
         float pre[14];
 #pragma unroll
@@ -1112,12 +1141,15 @@ __device__ __forceinline__ void apply_program_lane(const LatticeDev& lat, int S,
 template <typename T, int MOM, bool FULL, int UNROLL, bool FUSED, bool XPOSE>
 __global__ __launch_bounds__(kTrackThreads, (XPOSE ? 3 : 1)) void k_track_direct(
     LatticeDev lat, TrackArgs a, const T* __restrict__ energy_in, const T* p_in, T* p_out,
-    T* __restrict__ energy_out, const T* __restrict__ steps_in, double* __restrict__ partials) {
+    T* __restrict__ energy_out, const T* __restrict__ steps_in, double* __restrict__ partials,
+    double* __restrict__ obs_partials) {
   static_assert(!XPOSE || (UNROLL * 7 * sizeof(T) == 112 && !FUSED), "XPOSE: a lane owns 112 bytes");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned char* s_scratch = smem_raw;                                 // build scratch / wave tiles / reduction
   T* s_steps = reinterpret_cast<T*>(smem_raw + a.lds_scratch_bytes);    // [S][64]
   T* s_energy = s_steps + (size_t)lat.n_steps * LYNX_STEP_STRIDE;       // [S+1]
+  // observers (active BPMs): every lane's float64 sums of x and y at each of them, [2 * n_observers][256]
+  double* s_obs = reinterpret_cast<double*>(smem_raw + ((a.lds_scratch_bytes + ((size_t)lat.n_steps * (LYNX_STEP_STRIDE + 1) + 1) * sizeof(T) + 7) / 8 * 8)) + threadIdx.x;
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
@@ -1158,7 +1190,8 @@ __global__ __launch_bounds__(kTrackThreads, (XPOSE ? 3 : 1)) void k_track_direct
     }
   }
 
-  const bool one_run = (S == 1) && (lat.steps[0].kind == LYNX_STEP_RUN);
+  const bool one_run = (S == 1) && (lat.steps[0].kind == LYNX_STEP_RUN) && a.n_observers == 0;
+  for (int k = 0; k < 2 * a.n_observers; ++k) s_obs[k * 256] = 0.0;
   constexpr bool kMapInRegs = sizeof(T) == 4;
   // Pre-built single-run fp32 program: the map comes straight from the step table with
   // wave-uniform (scalar) loads -- no LDS staging, no barrier.
@@ -1227,8 +1260,12 @@ __global__ __launch_bounds__(kTrackThreads, (XPOSE ? 3 : 1)) void k_track_direct
         } else {
           load_particle(src + (i < end ? i : end - 1) * 7, z[0]);
         }
-        if (one_run) apply_step<T>(s_steps, LYNX_STEP_RUN, 0, z[0]);
-        else apply_program_lane<T, 1, false>(lat, S, g_steps, s_steps, 0, z);
+        if (one_run) {
+          apply_step<T>(s_steps, LYNX_STEP_RUN, 0, z[0]);
+        } else {
+          const bool alive[1] = {i < end};
+          apply_program_lane<T, 1, false>(lat, S, g_steps, s_steps, 0, z, a.n_observers ? s_obs : nullptr, &alive);
+        }
         if (MOM && it == 0 && u == 0) {
 #pragma unroll
           for (int k = 0; k < 6; ++k) shift[k] = wave_first(z[0][k]);
@@ -1280,7 +1317,13 @@ __global__ __launch_bounds__(kTrackThreads, (XPOSE ? 3 : 1)) void k_track_direct
           }
         }
       }
-      if (!one_run) apply_program_lane<T, UNROLL, kScalarTable>(lat, S, g_steps, s_steps, a.merged_pairs, z);
+      if (!one_run) {
+        bool alive[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) alive[u] = i0 + (int64_t)u * kLaneStep < end;
+        apply_program_lane<T, UNROLL, kScalarTable>(lat, S, g_steps, s_steps, a.merged_pairs, z,
+                                                    a.n_observers ? s_obs : nullptr, &alive);
+      }
 #pragma unroll
       for (int u = 0; u < UNROLL; ++u) {
         const int64_t i = i0 + (int64_t)u * kLaneStep;
@@ -1311,6 +1354,17 @@ __global__ __launch_bounds__(kTrackThreads, (XPOSE ? 3 : 1)) void k_track_direct
   }
 #undef LYNX_TILE_OF
 #undef LYNX_WAVE_BASE
+
+  if (a.n_observers) {
+    // this workgroup's sums of x and y at every observer: lanes in lane order, float64 -- deterministic
+    __syncthreads();
+    if (tid < 2 * a.n_observers) {
+      const double* row = s_obs - threadIdx.x + tid * 256;
+      double tot = 0.0;
+      for (int k = 0; k < 256; ++k) tot += row[k];
+      obs_partials[((int64_t)b * a.chunks + chunk) * (2 * LYNX_MAX_OBSERVERS) + tid] = tot;
+    }
+  }
 
   if (MOM) {
     // Workgroup reduction of the 29 sums through LDS: every lane parks its values in a
@@ -1440,6 +1494,19 @@ __global__ __launch_bounds__(256) void k_reduce_moments(const double* __restrict
   } else if (tid < kPartialStride) {
     out[(b * (int64_t)groups + g) * kPartialStride + tid] = s[tid];
   }
+}
+
+// k_reduce_observers: per-workgroup sums of x and y at the observers -> BPM readings [B][n_observers][2]
+// (mean x, mean y of the beam entering each active BPM), chunks added in chunk order.
+__global__ __launch_bounds__(64) void k_reduce_observers(const double* __restrict__ obs_partials, int chunks,
+                                                         int n_observers, double n_particles, double* __restrict__ out) {
+  const int64_t b = blockIdx.x;
+  const int t = threadIdx.x;
+  if (t >= 2 * n_observers) return;
+  const double* src = obs_partials + b * (int64_t)chunks * (2 * LYNX_MAX_OBSERVERS) + t;
+  double tot = 0.0;
+  for (int c = 0; c < chunks; ++c) tot += src[(int64_t)c * (2 * LYNX_MAX_OBSERVERS)];
+  out[b * 2 * n_observers + t] = tot / n_particles;
 }
 
 // ---------------------------------------------------------------------------------------

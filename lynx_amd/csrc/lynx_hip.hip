@@ -52,6 +52,8 @@ struct lynx_ctx {
   size_t scratch_partials_bytes = 0;
   void* scratch_level = nullptr;  // second level of the moment reduction (long beams)
   size_t scratch_level_bytes = 0;
+  void* scratch_obs = nullptr;  // per-workgroup sums of x, y at the observers [B][chunks][2 * LYNX_MAX_OBSERVERS]
+  size_t scratch_obs_bytes = 0;
   void* scratch_products = nullptr;  // lanes = samples build: piece / pair products [slot][49][Bp] float64
   size_t scratch_products_bytes = 0;
   void* scratch_coefs = nullptr;     // ... and cavity coefficients [S][8][Bp]
@@ -73,6 +75,7 @@ struct lynx_lattice {
   int dtype = LYNX_F32;
   int64_t batch = 0;
   int32_t n_elems = 0, n_steps = 0;
+  int32_t n_observers = 0;  // steps with LYNX_STEP_FLAG_OBSERVE (kept current by lynx_lattice_set_flags)
   int64_t pool_count = 0;
   std::vector<lynx_elem> h_elems;
   std::vector<lynx_step> h_steps;
@@ -225,6 +228,7 @@ int lynx_ctx_destroy(lynx_ctx* ctx) {
   for (auto& kv : ctx->live) (void)hipFree(kv.first);
   if (ctx->scratch_partials) (void)hipFree(ctx->scratch_partials);
   if (ctx->scratch_level) (void)hipFree(ctx->scratch_level);
+  if (ctx->scratch_obs) (void)hipFree(ctx->scratch_obs);
   if (ctx->scratch_products) (void)hipFree(ctx->scratch_products);
   if (ctx->scratch_coefs) (void)hipFree(ctx->scratch_coefs);
   for (int i = 0; i < 3; ++i) {
@@ -350,6 +354,21 @@ int lynx_pool_trim(lynx_ctx* ctx) {
 
 // ---- lattice ---------------------------------------------------------------------------
 
+// observers must be single-identity-element run steps, at most LYNX_MAX_OBSERVERS of them
+static int count_observers(lynx_ctx* ctx, lynx_lattice* lat) {
+  int32_t n = 0;
+  for (int32_t s = 0; s < lat->n_steps; ++s) {
+    const lynx_step& st = lat->h_steps[s];
+    if (!(st.flags & LYNX_STEP_FLAG_OBSERVE)) continue;
+    if (st.kind != LYNX_STEP_RUN || st.last != st.first + 1 || lat->h_elems[st.first].kind != LYNX_KIND_IDENTITY)
+      return fail(ctx, LYNX_ERR_INVALID, "an observer step must be a run of exactly one identity element");
+    ++n;
+  }
+  if (n > LYNX_MAX_OBSERVERS) return fail(ctx, LYNX_ERR_INVALID, "too many observer steps in one program");
+  lat->n_observers = n;
+  return LYNX_OK;
+}
+
 static int params_of_kind(int kind) {
   switch (kind) {
     case LYNX_KIND_IDENTITY: return 0;
@@ -416,6 +435,10 @@ int lynx_lattice_create(lynx_ctx* ctx, int dtype, int64_t batch, int32_t n_elems
   lat->h_steps.assign(steps, steps + n_steps);
   const size_t es = dtype_size(dtype);
   int rc;
+  if ((rc = count_observers(ctx, lat))) {
+    delete lat;
+    return rc;
+  }
   if ((rc = ctx_alloc(ctx, std::max<size_t>(1, n_elems) * sizeof(lynx_elem), (void**)&lat->d_elems)) ||
       (rc = ctx_alloc(ctx, std::max<size_t>(1, n_steps) * sizeof(lynx_step), (void**)&lat->d_steps)) ||
       (rc = ctx_alloc(ctx, std::max<size_t>(1, n_elems) * sizeof(int32_t), (void**)&lat->d_elem_step)) ||
@@ -446,6 +469,10 @@ int lynx_lattice_set_flags(lynx_lattice* lat, const int32_t* elem_flags, const i
   lynx_ctx* ctx = lat->ctx;
   for (int32_t e = 0; e < lat->n_elems; ++e) lat->h_elems[e].flags = elem_flags[e];
   for (int32_t s = 0; s < lat->n_steps; ++s) lat->h_steps[s].flags = step_flags[s];
+  {
+    const int rc = count_observers(ctx, lat);
+    if (rc) return rc;
+  }
   HIP_TRY(ctx, hipMemcpyAsync(lat->d_elems, lat->h_elems.data(), lat->n_elems * sizeof(lynx_elem), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(lat->d_steps, lat->h_steps.data(), lat->n_steps * sizeof(lynx_step), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -686,7 +713,8 @@ static TrackPlan plan_track(lynx_ctx* ctx, const lynx_lattice* lat, int64_t B, i
   }
   scratch = (scratch + 15) / 16 * 16;
   p.a.lds_scratch_bytes = (int32_t)scratch;
-  p.lds = scratch + ((size_t)S * LYNX_STEP_STRIDE + S + 1) * sizeof(T);
+  p.a.n_observers = lat ? lat->n_observers : 0;
+  p.lds = (scratch + ((size_t)S * LYNX_STEP_STRIDE + S + 1) * sizeof(T) + 7) / 8 * 8 + (size_t)2 * p.a.n_observers * 256 * sizeof(double);
   p.grid = (unsigned)(B * chunks);
   return p;
 }
@@ -694,7 +722,7 @@ static TrackPlan plan_track(lynx_ctx* ctx, const lynx_lattice* lat, int64_t B, i
 template <typename T, int MOM, bool FULL, int UNROLL, bool FUSED, bool XPOSE>
 static int launch_direct_inst(lynx_ctx* ctx, const TrackPlan& p, const LatticeDev& lv, const void* d_energy_in,
                               const void* d_p_in, void* d_p_out, void* d_energy_out, const void* d_steps,
-                              double* d_partials) {
+                              double* d_partials, double* d_obs) {
   int rc = allow_lds(ctx, k_track_direct<T, MOM, FULL, UNROLL, FUSED, XPOSE>, p.lds);
   if (rc) return rc;
   // Events ride on the dispatch itself (hipExtLaunchKernelGGL: start / stop timestamps of this kernel)
@@ -708,17 +736,17 @@ static int launch_direct_inst(lynx_ctx* ctx, const TrackPlan& p, const LatticeDe
   }
   hipExtLaunchKernelGGL((k_track_direct<T, MOM, FULL, UNROLL, FUSED, XPOSE>), dim3(p.grid), dim3(kTrackThreads),
                         (std::uint32_t)p.lds, ctx->stream, e0, e1, 0u, lv, p.a, (const T*)d_energy_in, (const T*)d_p_in,
-                        (T*)d_p_out, (T*)d_energy_out, (const T*)d_steps, d_partials);
+                        (T*)d_p_out, (T*)d_energy_out, (const T*)d_steps, d_partials, d_obs);
   HIP_TRY(ctx, hipGetLastError());
   if (ctx->profiling) ctx->prof_events.emplace_back(e0, e1);
   ctx->last_stream_stop = e1;  // what "this streaming kernel has finished" is, for the build stream
   return LYNX_OK;
 }
 
-#define LYNX_LAUNCH_ARGS ctx, p, lv, d_energy_in, d_p_in, d_p_out, d_energy_out, d_steps, d_partials
+#define LYNX_LAUNCH_ARGS ctx, p, lv, d_energy_in, d_p_in, d_p_out, d_energy_out, d_steps, d_partials, d_obs
 #define LYNX_LAUNCH_PARAMS                                                                                     \
   lynx_ctx *ctx, const TrackPlan &p, const LatticeDev &lv, const void *d_energy_in, const void *d_p_in,        \
-      void *d_p_out, void *d_energy_out, const void *d_steps, double *d_partials
+      void *d_p_out, void *d_energy_out, const void *d_steps, double *d_partials, double *d_obs
 
 template <typename T, int MOM, bool FULL, int U>
 static int launch_direct_mu(LYNX_LAUNCH_PARAMS) {
@@ -761,7 +789,7 @@ static int launch_direct(LYNX_LAUNCH_PARAMS, bool moments) {
 template <typename T>
 static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev& lv, int64_t B, int64_t N,
                              const void* d_energy_in, const void* d_p_in, void* d_p_out, void* d_energy_out,
-                             double* d_moments_out, int flags) {
+                             double* d_moments_out, int flags, double* d_observations = nullptr) {
   const int32_t S = lv.n_steps;
   const bool moments = (flags & (LYNX_TRACK_MOMENTS | LYNX_TRACK_COVARIANCE)) != 0;
   // Fused prologue vs separate build launch.  Default: separate launch (LYNX_FUSE_MAX_CHUNKS
@@ -789,7 +817,8 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
     // per pair); LYNX_TRACK_SEQUENTIAL_STEPS keeps every step on its own
     bool has_pair = false;
     for (int32_t s = 1; s < S; ++s)
-      has_pair |= lat->h_steps[s].kind == LYNX_STEP_CAVITY && lat->h_steps[s - 1].kind == LYNX_STEP_RUN;
+      has_pair |= lat->h_steps[s].kind == LYNX_STEP_CAVITY && lat->h_steps[s - 1].kind == LYNX_STEP_RUN &&
+                  !(lat->h_steps[s - 1].flags & LYNX_STEP_FLAG_OBSERVE);
     p.a.merged_pairs = has_pair && sizeof(T) == 4 && p.unroll % 2 == 0 &&
                        !(flags & LYNX_TRACK_SEQUENTIAL_STEPS) && env_int("LYNX_MERGE_STEPS", 1);
     // The second stream pays once the streaming kernel is long enough to hide a build under; below half a
@@ -822,9 +851,21 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
     if ((rc = ensure_scratch(ctx, &ctx->scratch_partials, &ctx->scratch_partials_bytes, need))) return rc;
     d_partials = (double*)ctx->scratch_partials;
   }
+  double* d_obs = nullptr;
+  if (p.a.n_observers) {
+    if (!d_observations) return fail(ctx, LYNX_ERR_INVALID, "the program has observer steps: d_observations required");
+    const size_t need = (size_t)B * p.a.chunks * 2 * LYNX_MAX_OBSERVERS * sizeof(double);
+    if ((rc = ensure_scratch(ctx, &ctx->scratch_obs, &ctx->scratch_obs_bytes, need))) return rc;
+    d_obs = (double*)ctx->scratch_obs;
+  }
   p.done = (slot >= 0) ? ctx->ev_streamed_own[slot] : nullptr;
-  rc = launch_direct<T>(ctx, p, lv, d_energy_in, d_p_in, d_p_out, d_energy_out, d_steps, d_partials, moments);
+  rc = launch_direct<T>(ctx, p, lv, d_energy_in, d_p_in, d_p_out, d_energy_out, d_steps, d_partials, d_obs, moments);
   if (rc) return rc;
+  if (p.a.n_observers) {
+    hipLaunchKernelGGL(k_reduce_observers, dim3((unsigned)B), dim3(64), 0, ctx->stream, d_obs, p.a.chunks,
+                       p.a.n_observers, (double)N, d_observations);
+    HIP_TRY(ctx, hipGetLastError());
+  }
   if (slot >= 0) {
     ctx->ev_streamed[slot] = ctx->last_stream_stop;
     ctx->streamed_valid[slot] = true;
@@ -855,7 +896,7 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
 
 int lynx_track_particles(lynx_ctx* ctx, lynx_lattice* lat, int64_t n_particles, const void* d_energy_in,
                          const void* d_p_in, void* d_p_out, void* d_energy_out, double* d_moments_out,
-                         int flags) {
+                         int flags, double* d_observations) {
   if (!ctx || !lat || !d_p_in) return fail(ctx, LYNX_ERR_INVALID, "null argument");
   if (n_particles <= 0) return fail(ctx, LYNX_ERR_INVALID, "n_particles must be > 0");
   if (lat->n_steps > 0 && !d_energy_in) return fail(ctx, LYNX_ERR_INVALID, "energy_in required");
@@ -867,9 +908,9 @@ int lynx_track_particles(lynx_ctx* ctx, lynx_lattice* lat, int64_t n_particles, 
   LatticeDev lv = dev_view(lat);
   return lat->dtype == LYNX_F64
              ? track_particles_t<double>(ctx, lat, lv, lat->batch, n_particles, d_energy_in, d_p_in, d_p_out,
-                                         d_energy_out, d_moments_out, flags)
+                                         d_energy_out, d_moments_out, flags, d_observations)
              : track_particles_t<float>(ctx, lat, lv, lat->batch, n_particles, d_energy_in, d_p_in, d_p_out,
-                                        d_energy_out, d_moments_out, flags);
+                                        d_energy_out, d_moments_out, flags, d_observations);
 }
 
 // ---- reverse pass -----------------------------------------------------------------------

@@ -35,6 +35,7 @@ class Program:
     leaves: list = field(default_factory=list)  # leaf elements in lattice order
     steps: list = field(default_factory=list)   # (kind, first, last) over `leaves`
     raw: bool = False  # runs take their first map as is (Element.track), see LYNX_STEP_FLAG_RAW
+    observers: list = field(default_factory=list)  # (step index, element): active BPMs read inside the pass
 
     def add_run_element(self, element, new_run: bool):
         idx = len(self.leaves)
@@ -49,11 +50,22 @@ class Program:
         self.leaves.append(element)
         self.steps.append([_ffi.STEP_CAVITY, idx, idx + 1])
 
+    def add_observer(self, element):
+        """An active BPM as a one-element run step of its own (LYNX_STEP_FLAG_OBSERVE): the streaming kernel
+        adds up x and y of the particles entering it -- `reading = stack([mu_x, mu_y])`, bpm.py:48-54 --
+        instead of the pass being cut in two there."""
+        idx = len(self.leaves)
+        self.leaves.append(element)
+        self.observers.append((len(self.steps), element))
+        self.steps.append([_ffi.STEP_RUN, idx, idx + 1])
 
-def partition(elements) -> list:
+
+def partition(elements, fuse_observers: bool = False) -> list:
     """
     Mirror of the `todos` loop in segment.py:344-351, flattened over nested segments:
-    returns a list of `Program` objects and host-side barrier elements (active BPMs), in
+    returns a list of `Program` objects and host-side barrier elements (active screens and
+    apertures; active BPMs too unless `fuse_observers`, the ParticleBeam case, where up to
+    `_ffi.MAX_OBSERVERS` of them per program are read inside the streaming pass), in
     order.  A nested non-skippable Segment is tracked on its own by the reference, so it
     starts and ends a run; a nested skippable Segment's elements join the current run (the
     reference multiplies its pre-composed product instead: same map up to rounding).
@@ -84,6 +96,10 @@ def partition(elements) -> list:
             elif el._kind == _ffi.KIND_CAVITY:
                 current().add_cavity(el)
                 state["new_run"] = True
+            elif (fuse_observers and getattr(el, "_fusable_observer", False)
+                  and sum(1 for item in out[-1:] if isinstance(item, Program) for _ in item.observers) < _ffi.MAX_OBSERVERS):
+                current().add_observer(el)
+                state["new_run"] = True
             elif getattr(el, "_host_barrier", False):
                 out.append(el)
                 state["new_run"] = True
@@ -94,7 +110,7 @@ def partition(elements) -> list:
     return out
 
 
-def plan(owner, elements, raw: bool) -> list:
+def plan(owner, elements, raw: bool, fuse_observers: bool = False) -> list:
     """
     `partition(elements)` remembered on `owner` for as long as no attribute that can change the
     partition has been written (global STRUCTURE counter) and the element list holds the same
@@ -112,14 +128,14 @@ def plan(owner, elements, raw: bool) -> list:
 
     ids = identities(elements)
     token = (STRUCTURE[0], raw, ids)
-    remembered = owner.__dict__.get("_plan")
+    remembered = owner.__dict__.setdefault("_plan", {}).get(fuse_observers)
     if remembered is not None and remembered[0] == token:
         return remembered[1]
-    items = partition(elements)
+    items = partition(elements, fuse_observers)
     for item in items:
         if isinstance(item, Program):
             item.raw = raw
-    owner.__dict__["_plan"] = (token, items)
+    owner.__dict__["_plan"][fuse_observers] = (token, items)
     return items
 
 
@@ -220,10 +236,12 @@ class PackedLattice:
             self._static = [el._static_flags() for el in leaves]
             self._has_cavity = any(el._kind == _ffi.KIND_CAVITY for el in leaves)
         base = _ffi.STEP_FLAG_RAW if self.program.raw else 0
+        observed = {s for s, _ in self.program.observers}
+        plain = [base | (_ffi.STEP_FLAG_OBSERVE if s in observed else 0) for s in range(self.S)]
         if not self._has_cavity:
-            return self._static, [base] * self.S
+            return self._static, plain
         elem_flags = list(self._static)
-        step_flags = [base] * self.S
+        step_flags = list(plain)
         energy = np.broadcast_to(np.asarray(energy_host, dtype=self.dtype), self.batch_shape)
         for s, (kind, first, last) in enumerate(self.program.steps):
             for e in range(first, last):
@@ -355,8 +373,11 @@ def run_program_particles(cache, program: Program, beam, moments: bool | None = 
              | (_ffi.TRACK_TWO_KERNEL if config.two_kernel else 0)
              | (_ffi.TRACK_SHARED_INPUT if beam.is_shared else 0)
              | (0 if config.merge_steps else _ffi.TRACK_SEQUENTIAL_STEPS))
+    obs = rt.empty((lat.B, len(program.observers), 2), np.float64) if program.observers else None
     rt.check(rt.lib.lynx_track_particles(rt.ctx, lat.handle, beam.num_particles, _ptr(e_in), _ptr(p_in),
-                                         _ptr(p_out), _ptr(e_out), _ptr(mom), flags))
+                                         _ptr(p_out), _ptr(e_out), _ptr(mom), flags, _ptr(obs)))
+    for k, (_, element) in enumerate(program.observers):
+        element._reading_from(obs, k, batch_shape, dtype)  # read back only if somebody looks at it
     out = ParticleBeam.__new__(ParticleBeam)
     charges = beam._charges
     if beam.is_shared and charges is not None:
@@ -403,7 +424,7 @@ def track(owner, elements, incoming, raw: bool = False):
         raise TypeError(f"Parameter incoming is of invalid type {type(incoming)}")
     cache = owner.__dict__.setdefault("_lattice_cache", LatticeCache())
     beam = incoming
-    for item in plan(owner, elements, raw):
+    for item in plan(owner, elements, raw, fuse_observers=isinstance(incoming, ParticleBeam)):
         if isinstance(item, Program):
             if isinstance(beam, ParticleBeam):
                 beam = run_program_particles(cache, item, beam)

@@ -713,6 +713,76 @@ def test_active_bpm_reads_the_beam_position(lx):
         seg.my_bpm.reading = None
 
 
+@pytest.mark.parametrize("dtype,n", [(np.float32, 5000), (np.float32, 4097), (np.float64, 6000), (np.float64, 1001)])
+def test_active_bpms_are_read_inside_the_streaming_pass(lx, dtype, n):
+    """
+    bpm.py:48-58 -- `reading = stack([mu_x, mu_y])` of the beam entering an active BPM.  For a ParticleBeam
+    the BPMs are steps of ONE program (LYNX_STEP_FLAG_OBSERVE): no split of the pass, no host round trip;
+    readings against the oracle's, for BPMs behind linear runs and behind a cavity, ragged particle counts,
+    both dtypes (float64 takes the wave-tile kernel).
+    """
+    from lynx_amd import engine
+
+    B = 3
+    rng = np.random.default_rng(31)
+    f = lambda v: np.full(B, v, dtype=dtype)  # noqa: E731
+    k1 = rng.uniform(-4, 4, B).astype(dtype)
+    ang = rng.normal(0, 1e-3, B).astype(dtype)
+    volt = rng.uniform(5e6, 2e7, B).astype(dtype)
+    els = [lx.Drift(f(0.5), dtype=dtype), lx.HorizontalCorrector(f(0.1), angle=ang, dtype=dtype), lx.BPM(is_active=True, name="b0"),
+           lx.Quadrupole(f(0.2), k1=k1, dtype=dtype), lx.Drift(f(0.7), dtype=dtype), lx.BPM(is_active=True, name="b1"),
+           lx.Cavity(f(1.0377), voltage=volt, phase=f(3.0), frequency=f(1.3e9), dtype=dtype), lx.BPM(is_active=True, name="b2"),
+           lx.VerticalCorrector(f(0.1), angle=ang, dtype=dtype), lx.Drift(f(0.3), dtype=dtype), lx.BPM(name="idle"),
+           lx.BPM(is_active=True, name="b3")]
+    specs = [o.Drift(f(0.5)), o.HorizontalCorrector(f(0.1), ang), o.BPM(True), o.Quadrupole(f(0.2), k1=k1), o.Drift(f(0.7)), o.BPM(True),
+             o.Cavity(f(1.0377), voltage=volt, phase=f(3.0), frequency=f(1.3e9)), o.BPM(True), o.VerticalCorrector(f(0.1), ang),
+             o.Drift(f(0.3)), o.BPM(False), o.BPM(True)]
+    seg = lx.Segment(els)
+    P = o.gaussian_particles((B,), n, seed=6, dtype=dtype, mu=[2e-4, 0, -1e-4, 1e-5, 0, 0], sigma=[1e-4, 1e-5, 1e-4, 1e-5, 1e-4, 1e-3])
+    energy = np.full(B, 6e6, dtype=dtype)
+    beam = lx.ParticleBeam(P, energy, dtype=dtype)
+    items = engine.plan(seg, seg.elements, False, fuse_observers=True)
+    assert len(items) == 1 and len(items[0].observers) == 4  # one program: nothing splits the pass
+    out = seg.track(beam)
+    readings = []
+    ref = o.segment_track(specs, o.particle_beam(P, energy, dtype), dtype, bpm_readings=readings)
+    assert len(readings) == 4
+    tol = TOL_MOM[dtype]
+    sig_x = float(np.std(P[..., 0])) + 1e-4
+    for name, (_, want) in zip(("b0", "b1", "b2", "b3"), readings):
+        got = getattr(seg, name).reading
+        assert got.shape == (2, B) and got.dtype == np.dtype(dtype)
+        assert np.all(np.abs(got - want) <= tol * (np.abs(want) + 3 * sig_x)), (name, got, want)
+    assert seg.idle.reading is None
+    got = np.asarray(out.particles)
+    ptol = {np.float32: [2e-4] * 4 + [2e-3, 2e-3, 1e-6], np.float64: [1e-9] * 7}[dtype]
+    for c in range(7):
+        assert rel_err(got[..., c], ref["particles"][..., c]) < ptol[c], c
+    _assert_moments(out, ref, dtype)
+    # the same lattice seen by a ParameterBeam keeps the host-side reading (no particles to add up)
+    pb = lx.ParameterBeam.from_parameters(mu_x=np.full(B, 2e-4, dtype), energy=energy, dtype=dtype)
+    seg.track(pb)
+    assert seg.b3.reading.shape == (2, B)
+
+
+def test_more_active_bpms_than_one_program_reads(lx):
+    """Beyond LYNX_MAX_OBSERVERS (8) active BPMs the pass is split on the host, as before; every reading is still right."""
+    f = lambda v: np.array([v], dtype=np.float32)  # noqa: E731
+    els = []
+    for k in range(11):
+        els += [lx.Drift(f(0.3)), lx.HorizontalCorrector(f(0.1), angle=f(1e-4 * (k + 1))), lx.BPM(is_active=True, name=f"m{k}")]
+    seg = lx.Segment(els)
+    beam = lx.ParticleBeam.from_parameters(num_particles=30_000, sigma_x=f(1e-5), sigma_xp=f(1e-6), seed=4)
+    seg.track(beam)
+    x, xp = 0.0, 0.0
+    for k in range(11):
+        a = 1e-4 * (k + 1)
+        x += xp * 0.3  # drift
+        x += xp * 0.1 + 0.0  # corrector: drift part; the kick lands in x' only (horizontal_corrector.py:52-67)
+        xp += a
+        assert np.isclose(getattr(seg, f"m{k}").reading[0, 0], x, rtol=5e-3, atol=2e-7), (k, getattr(seg, f"m{k}").reading, x)
+
+
 def test_error_conventions(lx):
     f = lambda v: np.array([v], dtype=np.float32)  # noqa: E731
     with pytest.raises(TypeError):
