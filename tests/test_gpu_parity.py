@@ -610,6 +610,63 @@ def test_fused_covariance_switch(lx):
         assert np.max(np.abs(out.covariance()[b] - want) / s) < 1e-9
 
 
+VARIANTS = [
+    {"LYNX_XPOSE": "1"}, {"LYNX_XPOSE": "0"}, {"LYNX_ASYNC_BUILD": "1"}, {"LYNX_ASYNC_BUILD": "0"},
+    {"LYNX_LANES_BUILD_MIN_BATCH": "1"}, {"LYNX_LANES_BUILD_MIN_BATCH": "1", "LYNX_PIECE": "3"},
+    {"LYNX_UNROLL": "1"}, {"LYNX_UNROLL": "2"}, {"LYNX_UNROLL": "4"}, {"LYNX_MOM": "2"}, {"LYNX_MOM": "3"},
+    {"LYNX_FUSE_MAX_CHUNKS": "64", "LYNX_UNROLL": "1"}, {"LYNX_MIN_TILES_PER_WG": "1"}, {"LYNX_INTERLEAVE": "1"},
+    {"LYNX_BUILD_CHUNK": "5"}, {"LYNX_MERGE_STEPS": "0"},
+]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_every_kernel_variant_gives_the_default_answer(lx, dtype, monkeypatch):
+    """
+    The launch plan picks one of several forms of the same computation (wave tiles or per-particle
+    accesses, particles per lane, moment accumulation mode, build on the second stream or in line,
+    lanes or workgroup build, fused prologue, tile order ...).  Every knob, on a lattice with cavities
+    and an active BPM, a ragged particle count and a batch: particles agree with the default plan to
+    rounding (the forms differ in the association of the map products only), moments and the BPM
+    reading to the moment tolerance.
+    """
+    B, n = 5, 6151
+    rng = np.random.default_rng(23)
+    f = lambda v: np.full(B, v, dtype=dtype)  # noqa: E731
+
+    def lattice():
+        els = []
+        for k in range(3):
+            els += [lx.Drift(f(0.3), dtype=dtype), lx.Quadrupole(f(0.2), k1=(rng0.uniform(-4, 4, B)).astype(dtype), dtype=dtype),
+                    lx.HorizontalCorrector(f(0.1), angle=f(1e-4), dtype=dtype), lx.Drift(f(0.4), dtype=dtype)]
+            if k == 1:
+                els.append(lx.BPM(is_active=True, name="bpm"))
+            els.append(lx.Cavity(f(1.0377), voltage=f(1.2e7), phase=f(2.0), frequency=f(1.3e9), dtype=dtype))
+        return lx.Segment(els)
+
+    P = o.gaussian_particles((B,), n, seed=9, dtype=dtype, sigma=[1e-4, 1e-5, 1e-4, 1e-5, 1e-4, 1e-3])
+    energy = np.full(B, 6e6, dtype=dtype)
+    results = []
+    for env in [{}] + VARIANTS:
+        for key in {k for v in VARIANTS for k in v}:
+            monkeypatch.delenv(key, raising=False)
+        for key, value in env.items():
+            monkeypatch.setenv(key, value)
+        rng0 = np.random.default_rng(23)
+        seg = lattice()
+        out = seg.track(lx.ParticleBeam(P, energy, dtype=dtype))
+        results.append((env, np.asarray(out.particles), out.moment_record().copy(), seg.bpm.reading.copy(), np.asarray(out.energy)))
+    _, p0, m0, r0, e0 = results[0]
+    close = 5e-6 if dtype == np.float32 else 1e-12
+    for env, p, m, r, e in results[1:]:
+        for c in range(7):
+            assert rel_err(p[..., c], p0[..., c]) < close, (env, c)
+        assert np.array_equal(e, e0), env
+        have = ~np.isnan(m0)
+        assert np.array_equal(np.isnan(m), np.isnan(m0)), env
+        assert np.allclose(m[have], m0[have], rtol=TOL_MOM[dtype] * 0.1, atol=1e-30), env
+        assert np.allclose(r, r0, rtol=TOL_MOM[dtype], atol=1e-12), env
+
+
 def test_two_kernel_path_is_bit_identical_to_fused(lx):
     desc = [("drift", dict(length=[0.6] * 3)), ("quadrupole", dict(length=[0.2] * 3, k1=[4.2, -1.0, 0.0])),
             ("cavity", dict(length=[1.0] * 3, voltage=[1e7] * 3, phase=[5.0] * 3, frequency=[1.3e9] * 3)),
