@@ -223,6 +223,61 @@ __device__ void build_compose_sample(const LatticeDev& lat, int64_t b, T energy_
 }
 
 // ---------------------------------------------------------------------------------------
+// k_cavity_flags: the reference decides three things about a cavity for the WHOLE batch at once, in
+// Python (`if any(...)`): whether beta0/beta1 enter the map (cavity.py:290: any(V != 0 & E != 0)), whether
+// the beam gains energy there (cavity.py:128: any(E + dE > 0)) and whether the second-order path-length
+// terms apply (cavity.py:164: any(dE > 0)).  They depend on the beam energy, which for the second cavity
+// of a lattice is itself a result of the first.  One workgroup walks the cavities in lattice order,
+// OR-reduces the predicates over the batch, writes the bits into the element / step flags the builders
+// read, and carries every sample's energy forward -- so the host never needs the energy (round 1 read it
+// back and redid this bookkeeping in NumPy).
+// ---------------------------------------------------------------------------------------
+constexpr int kCavMask = LYNX_FLAG_CAV_BETA | LYNX_FLAG_CAV_GAIN | LYNX_FLAG_CAV_T5XX;
+
+template <typename T>
+__global__ __launch_bounds__(1024) void k_cavity_flags(LatticeDev lat, lynx_elem* elems, lynx_step* steps,
+                                                       const T* __restrict__ energy_in, T* __restrict__ e_run) {
+  const T* pool = static_cast<const T*>(lat.pool);
+  const int64_t B = lat.batch;
+  for (int64_t b = threadIdx.x; b < B; b += blockDim.x) e_run[b] = energy_in[b];
+  __syncthreads();
+  for (int s = 0; s < lat.n_steps; ++s) {
+    const lynx_step st = steps[s];
+    for (int e = st.first; e < st.last; ++e) {
+      const lynx_elem el = elems[e];
+      if (el.kind != LYNX_KIND_CAVITY) continue;  // uniform
+      const bool is_step = st.kind == LYNX_STEP_CAVITY;
+      int mine = 0;
+      for (int64_t b = threadIdx.x; b < B; b += blockDim.x) {
+        const T* p = pool + el.param_offset + b * (int64_t)el.batch_stride;
+        const T energy = e_run[b], voltage = p[1];
+        const T d_energy = voltage * t_cos(p[2] * T(LYNX_PI / 180.0));
+        if (voltage != T(0) && energy != T(0)) mine |= LYNX_FLAG_CAV_BETA;
+        if (is_step) {
+          if (energy + d_energy > T(0)) mine |= LYNX_FLAG_CAV_GAIN;
+          if (d_energy > T(0)) mine |= LYNX_FLAG_CAV_T5XX;
+        }
+      }
+      int f = 0;
+      if (__syncthreads_or(mine & LYNX_FLAG_CAV_BETA)) f |= LYNX_FLAG_CAV_BETA;
+      if (__syncthreads_or(mine & LYNX_FLAG_CAV_GAIN)) f |= LYNX_FLAG_CAV_GAIN;
+      if (__syncthreads_or(mine & LYNX_FLAG_CAV_T5XX)) f |= LYNX_FLAG_CAV_T5XX;
+      if (threadIdx.x == 0) {
+        elems[e].flags = (el.flags & ~kCavMask) | f;
+        if (is_step) steps[s].flags = (st.flags & ~kCavMask) | f;
+      }
+      if (is_step && (f & LYNX_FLAG_CAV_GAIN)) {  // cavity.py:130: the whole batch moves on with E + dE
+        for (int64_t b = threadIdx.x; b < B; b += blockDim.x) {
+          const T* p = pool + el.param_offset + b * (int64_t)el.batch_stride;
+          e_run[b] = e_run[b] + p[1] * t_cos(p[2] * T(LYNX_PI / 180.0));
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // Build + compose with LANES = SAMPLES (large batches).
 //
 // The per-sample workgroup above keeps one element per lane busy in phase 1 and seven lanes per
@@ -461,6 +516,7 @@ __global__ __launch_bounds__(64) void k_emit_steps(LatticeDev lat, const int32_t
 #pragma unroll
     for (int q = 0; q < 8; ++q) row[LYNX_COEF_OFFSET + q] = cs[q * Bp];
   }
+  row[LYNX_FLAGS_OFFSET] = (T)st.flags;
   if (s == S - 1) {
     const T e_out = energy_before_step<T>(lat, b, energy_in[b], S);
     row[LYNX_ENERGY_OFFSET] = e_out;
@@ -707,6 +763,8 @@ __global__ __launch_bounds__(1024) void k_build(LatticeDev lat, const T* __restr
       __syncthreads();
     }
   }
+  for (int s = threadIdx.x; s < lat.n_steps; s += blockDim.x)
+    s_steps[s * LYNX_STEP_STRIDE + LYNX_FLAGS_OFFSET] = (T)lat.steps[s].flags;
   if (lat.n_steps > 0 && threadIdx.x == 0)
     s_steps[(lat.n_steps - 1) * LYNX_STEP_STRIDE + LYNX_ENERGY_OFFSET] = s_energy[lat.n_steps];
   __syncthreads();
@@ -1113,18 +1171,22 @@ __device__ __forceinline__ void apply_program_lane(const LatticeDev& lat, int S,
 #pragma unroll
         for (int q = 0; q < 57; ++q) m[q] = uniform_value(tab[q]);
       }
+      // the cavity bits as they stood when this table was built (LYNX_FLAGS_OFFSET), not the lattice's
+      // current ones: the next call's k_cavity_flags may already be rewriting those
+      const int sflags = (int)uniform_value((SCALAR_TABLE ? g_steps : s_steps)[sidx * LYNX_STEP_STRIDE + LYNX_FLAGS_OFFSET]);
       if constexpr (kPairs) {
 #pragma unroll
         for (int h = 0; h < UNROLL / 2; ++h)
-          apply_step_pair(m, st.kind, st.flags, zp[h], merged, s_entry[h], d_entry[h]);
+          apply_step_pair(m, st.kind, sflags, zp[h], merged, s_entry[h], d_entry[h]);
       } else {
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) apply_step<T>(m, st.kind, st.flags, z[u]);
+        for (int u = 0; u < UNROLL; ++u) apply_step<T>(m, st.kind, sflags, z[u]);
       }
     } else {
       const T* tab = s_steps + sidx * LYNX_STEP_STRIDE;
+      const int sflags = (int)tab[LYNX_FLAGS_OFFSET];
 #pragma unroll
-      for (int u = 0; u < UNROLL; ++u) apply_step<T>(tab, st.kind, st.flags, z[u]);
+      for (int u = 0; u < UNROLL; ++u) apply_step<T>(tab, st.kind, sflags, z[u]);
     }
   }
   if constexpr (kPairs) {
@@ -1201,6 +1263,8 @@ __global__ __launch_bounds__(kTrackThreads, (XPOSE ? 3 : 1)) void k_track_direct
 
   if (FUSED) {
     build_compose_sample<T>(lat, b, energy_in[b], s_steps, s_energy, s_scratch, a.build_chunk);
+    for (int s = tid; s < S; s += kTrackThreads) s_steps[s * LYNX_STEP_STRIDE + LYNX_FLAGS_OFFSET] = (T)lat.steps[s].flags;
+    __syncthreads();
     if (energy_out && chunk == 0 && tid == 0) energy_out[b] = s_energy[S];
   } else if (S > 0) {
     if (!scalar_table) load_steps_sample<T>(g_steps, S, s_steps);

@@ -54,6 +54,8 @@ struct lynx_ctx {
   size_t scratch_level_bytes = 0;
   void* scratch_obs = nullptr;  // per-workgroup sums of x, y at the observers [B][chunks][2 * LYNX_MAX_OBSERVERS]
   size_t scratch_obs_bytes = 0;
+  void* scratch_erun = nullptr;      // k_cavity_flags: every sample's energy on its way through the cavities
+  size_t scratch_erun_bytes = 0;
   void* scratch_products = nullptr;  // lanes = samples build: piece / pair products [slot][49][Bp] float64
   size_t scratch_products_bytes = 0;
   void* scratch_coefs = nullptr;     // ... and cavity coefficients [S][8][Bp]
@@ -76,6 +78,7 @@ struct lynx_lattice {
   int64_t batch = 0;
   int32_t n_elems = 0, n_steps = 0;
   int32_t n_observers = 0;  // steps with LYNX_STEP_FLAG_OBSERVE (kept current by lynx_lattice_set_flags)
+  bool has_cavity = false;  // any cavity element: its whole-batch predicates are evaluated on the device
   int64_t pool_count = 0;
   std::vector<lynx_elem> h_elems;
   std::vector<lynx_step> h_steps;
@@ -229,6 +232,7 @@ int lynx_ctx_destroy(lynx_ctx* ctx) {
   if (ctx->scratch_partials) (void)hipFree(ctx->scratch_partials);
   if (ctx->scratch_level) (void)hipFree(ctx->scratch_level);
   if (ctx->scratch_obs) (void)hipFree(ctx->scratch_obs);
+  if (ctx->scratch_erun) (void)hipFree(ctx->scratch_erun);
   if (ctx->scratch_products) (void)hipFree(ctx->scratch_products);
   if (ctx->scratch_coefs) (void)hipFree(ctx->scratch_coefs);
   for (int i = 0; i < 3; ++i) {
@@ -433,6 +437,7 @@ int lynx_lattice_create(lynx_ctx* ctx, int dtype, int64_t batch, int32_t n_elems
   lat->pool_count = pool_count;
   lat->h_elems.assign(elems, elems + n_elems);
   lat->h_steps.assign(steps, steps + n_steps);
+  for (int32_t e = 0; e < n_elems; ++e) lat->has_cavity |= elems[e].kind == LYNX_KIND_CAVITY;
   const size_t es = dtype_size(dtype);
   int rc;
   if ((rc = count_observers(ctx, lat))) {
@@ -538,6 +543,19 @@ static void build_shape(lynx_ctx* ctx, const lynx_lattice* lat, int* threads, in
   *chunk = build_chunk(lat->n_elems, limit);
 }
 
+// Whole-batch cavity predicates for this call's energies, on `stream`, in front of whatever builds maps
+// there (no-op for lattices without cavities).
+template <typename T>
+static int launch_cavity_flags(lynx_ctx* ctx, lynx_lattice* lat, hipStream_t stream, const void* d_energy_in) {
+  if (!lat->has_cavity || lat->n_steps == 0) return LYNX_OK;
+  int rc;
+  if ((rc = ensure_scratch(ctx, &ctx->scratch_erun, &ctx->scratch_erun_bytes, (size_t)lat->batch * sizeof(T)))) return rc;
+  hipLaunchKernelGGL(k_cavity_flags<T>, dim3(1), dim3(1024), 0, stream, dev_view(lat), lat->d_elems, lat->d_steps,
+                     (const T*)d_energy_in, (T*)ctx->scratch_erun);
+  HIP_TRY(ctx, hipGetLastError());
+  return LYNX_OK;
+}
+
 // Plan of the lanes = samples build for this lattice: pieces of <= L elements inside each step, then
 // levels of pair products until every step is one slot.
 static int plan_lanes_build(lynx_ctx* ctx, lynx_lattice* lat, int L) {
@@ -622,6 +640,10 @@ static int launch_build_lanes(lynx_ctx* ctx, lynx_lattice* lat, hipStream_t stre
 template <typename T>
 static int launch_build(lynx_ctx* ctx, lynx_lattice* lat, hipStream_t stream, const void* d_energy_in,
                         void* d_steps_out, void* d_energy_out, int merge_pairs = 0) {
+  {
+    const int rc = launch_cavity_flags<T>(ctx, lat, stream, d_energy_in);
+    if (rc) return rc;
+  }
   // large batches: lanes = samples (an order of magnitude fewer wave-instructions); small ones: one
   // workgroup per sample, whose tree is shallower than a chain of launches
   if (lat->n_steps > 0 && lat->batch >= env_int("LYNX_LANES_BUILD_MIN_BATCH", 256))
@@ -844,6 +866,7 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
     }
     d_steps = ctx->scratch_steps[slot];
   }
+  if (fused && lat && (rc = launch_cavity_flags<T>(ctx, lat, ctx->stream, d_energy_in))) return rc;
   if ((int64_t)B * p.a.chunks > 0x7fffffffLL) return fail(ctx, LYNX_ERR_INVALID, "grid too large");
   double* d_partials = nullptr;
   if (moments) {
@@ -1063,6 +1086,7 @@ static int launch_track_moments(lynx_ctx* ctx, lynx_lattice* lat, const void* d_
                      ((size_t)lat->n_steps * LYNX_STEP_STRIDE + lat->n_steps + 1 + 8 + 49 + 49 + 16) * sizeof(T);
   int rc = allow_lds(ctx, k_track_moments<T>, lds);
   if (rc) return rc;
+  if ((rc = launch_cavity_flags<T>(ctx, lat, ctx->stream, d_energy_in))) return rc;
   const unsigned threads = lat->batch <= 4096 ? 256u : 64u;
   hipLaunchKernelGGL(k_track_moments<T>, dim3((unsigned)lat->batch), dim3(threads), lds, ctx->stream, dev_view(lat),
                      (const T*)d_energy_in, (const T*)d_mu_in, (const T*)d_cov_in, (T*)d_mu_out, (T*)d_cov_out,

@@ -48,6 +48,10 @@ namespace lynx {
 // 49 map entries + 8 cavity coefficients, padded to 64
 #define LYNX_STEP_STRIDE 64
 #define LYNX_COEF_OFFSET 49
+// slot 62: the step's flags as they stood when THIS table was built (a small integer stored as T).  The
+// cavity bits are whole-batch predicates of the beam energy, re-evaluated on the device before every
+// build; the streaming kernel of call n reads them here and never sees call n+1's.
+#define LYNX_FLAGS_OFFSET 62
 // last step, slot 63: the beam energy behind the last step (published by the streaming kernel)
 #define LYNX_ENERGY_OFFSET 63
 // cavity coefficient slots (lynx/accelerator/cavity.py:141-226)

@@ -226,10 +226,15 @@ class PackedLattice:
         return True
 
     # whole-batch predicates -----------------------------------------------------------------
-    def evaluate_flags(self, energy_host):
+    def evaluate_flags(self, energy_host=None):
         """
-        Element flags, cavity step flags and the reference's assertions, from the host view
-        of the beam energy.  Returns (elem_flags, step_flags).
+        Element and step flags the host decides: the parameter-only predicates of magnets (tilt,
+        misalignment, thick dipole: `_static_flags`), `LYNX_STEP_FLAG_RAW` and the observer steps.  The
+        cavity predicates depend on the beam energy on its way through the lattice and are evaluated on
+        the device before every build (`k_cavity_flags`), so the energy never has to come back to the
+        host for them.  What stays here of cavity.py:260 (`assert Ei > 0`) is the check of the INCOMING
+        energy, when the host already holds it; a cavity that decelerates the beam through zero is not
+        caught.  Returns (elem_flags, step_flags).
         """
         leaves = self.program.leaves
         if self._static is None:  # element versions are part of the cache key: these cannot change
@@ -237,35 +242,9 @@ class PackedLattice:
             self._has_cavity = any(el._kind == _ffi.KIND_CAVITY for el in leaves)
         base = _ffi.STEP_FLAG_RAW if self.program.raw else 0
         observed = {s for s, _ in self.program.observers}
-        plain = [base | (_ffi.STEP_FLAG_OBSERVE if s in observed else 0) for s in range(self.S)]
-        if not self._has_cavity:
-            return self._static, plain
-        elem_flags = list(self._static)
-        step_flags = list(plain)
-        energy = np.broadcast_to(np.asarray(energy_host, dtype=self.dtype), self.batch_shape)
-        for s, (kind, first, last) in enumerate(self.program.steps):
-            for e in range(first, last):
-                el = leaves[e]
-                if el._kind != _ffi.KIND_CAVITY:
-                    continue
-                # cavity.py:260 (also reached for switched-off cavities inside a run)
-                assert np.all(energy > 0), "Initial energy must be larger than 0"
-                voltage = np.asarray(el.voltage, dtype=self.dtype)
-                with np.errstate(all="ignore"):
-                    d_energy = voltage * np.cos(np.deg2rad(np.asarray(el.phase, dtype=self.dtype)))
-                    f = 0
-                    if np.any((voltage != 0) & (energy != 0)):  # cavity.py:290
-                        f |= _ffi.FLAG_CAV_BETA
-                    if kind == _ffi.STEP_CAVITY:
-                        if np.any(energy + d_energy > 0):  # cavity.py:128
-                            f |= _ffi.FLAG_CAV_GAIN
-                        if np.any(d_energy > 0):  # cavity.py:164
-                            f |= _ffi.FLAG_CAV_T5XX
-                        step_flags[s] = f
-                        if f & _ffi.FLAG_CAV_GAIN:
-                            energy = np.broadcast_to(energy + d_energy, self.batch_shape)
-                elem_flags[e] |= f
-        return elem_flags, step_flags
+        if self._has_cavity and energy_host is not None:
+            assert np.all(np.asarray(energy_host) > 0), "Initial energy must be larger than 0"
+        return self._static, [base | (_ffi.STEP_FLAG_OBSERVE if s in observed else 0) for s in range(self.S)]
 
     # device side ----------------------------------------------------------------------------
     def upload(self, rt, elem_flags, step_flags):
@@ -362,7 +341,7 @@ def run_program_particles(cache, program: Program, beam, moments: bool | None = 
     rt = get_runtime()
     dtype = beam.dtype
     batch_shape = beam.batch_shape
-    lat = _ready(cache, program, batch_shape, dtype, beam._energy.host())
+    lat = _ready(cache, program, batch_shape, dtype, beam._energy._host)  # no read-back: None if it lives in HBM only
     p_in = beam._particles.device(rt)  # (N, 7)-like storage when the beam is shared by the batch
     p_out = rt.empty((*batch_shape, beam.num_particles, 7), dtype)
     e_in = beam._energy.broadcast_device(rt, batch_shape)
@@ -394,7 +373,7 @@ def run_program_parameters(cache, program: Program, beam):
     rt = get_runtime()
     dtype = beam.dtype
     batch_shape = beam.batch_shape
-    lat = _ready(cache, program, batch_shape, dtype, beam._energy.host())
+    lat = _ready(cache, program, batch_shape, dtype, beam._energy._host)
     mu_in = beam._mu_d.device(rt)
     cov_in = beam._cov_d.device(rt)
     mu_out = rt.empty(mu_in.shape, dtype)

@@ -181,7 +181,7 @@ class TrackVJP:
                 rec[:, _tri(i, i)] = G[:, i, i]
                 for j in range(i + 1, 6):
                     rec[:, _tri(i, j)] = G[:, i, j] + G[:, j, i]
-        lat = engine._ready(self.cache, program, batch_shape, dtype, beam._energy.host())
+        lat = engine._ready(self.cache, program, batch_shape, dtype, beam._energy._host)
         E = lat.E
         g_rec = rt.to_device(rec)
         g_par = rt.empty((B, max(E, 1), 8), dtype)
@@ -247,7 +247,7 @@ class MomentsVJP:
             cov_bar = np.asarray(cov_bar, dtype=np.float64)
             k = cov_bar.shape[-1]
             cb[:, :k, :k] += cov_bar.reshape(B, k, k)
-        lat = engine._ready(self.cache, program, batch_shape, dtype, beam._energy.host())
+        lat = engine._ready(self.cache, program, batch_shape, dtype, beam._energy._host)
         g_par = rt.empty((B, max(lat.E, 1), 8), dtype)
         g_en = rt.empty((B,), dtype)
         g_mu = rt.empty((*batch_shape, 7), dtype)

@@ -840,6 +840,52 @@ def test_more_active_bpms_than_one_program_reads(lx):
         assert np.isclose(getattr(seg, f"m{k}").reading[0, 0], x, rtol=5e-3, atol=2e-7), (k, getattr(seg, f"m{k}").reading, x)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_cavity_predicates_are_evaluated_on_the_device(lx, dtype):
+    """
+    cavity.py:128,164,290 -- `if any(...)` over the whole batch, with the energy each cavity sees being the
+    result of the cavities before it.  `k_cavity_flags` leaves the bits in slot 62 of every step-table row;
+    checked against the oracle's bookkeeping for: an accelerating pair, a decelerating cavity (no T5XX), a
+    mixed batch where only one sample has voltage, and a switched-off cavity inside a run (BETA bit only,
+    no step).  Then the energy leaves one program in HBM and enters the next without a read-back.
+    """
+    from lynx_amd import _ffi, engine
+    from lynx_amd.device import get_runtime
+
+    B = 3
+    f = lambda v: np.full(B, v, dtype=dtype)  # noqa: E731
+    cases = [
+        (dict(voltage=f(1e7), phase=f(10.0)), _ffi.FLAG_CAV_BETA | _ffi.FLAG_CAV_GAIN | _ffi.FLAG_CAV_T5XX),
+        (dict(voltage=f(1e7), phase=f(180.0)), _ffi.FLAG_CAV_BETA | _ffi.FLAG_CAV_GAIN),
+        (dict(voltage=np.array([0.0, 1e7, 0.0], dtype=dtype), phase=f(10.0)), _ffi.FLAG_CAV_BETA | _ffi.FLAG_CAV_GAIN | _ffi.FLAG_CAV_T5XX),
+        (dict(voltage=f(-2e8), phase=f(0.0)), _ffi.FLAG_CAV_BETA),  # E + dE < 0 on every sample: no gain step at all
+    ]
+    rt = get_runtime()
+    for kw, want in cases:
+        cav = lx.Cavity(f(1.0), frequency=f(1.3e9), dtype=dtype, **kw)
+        seg = lx.Segment([lx.Drift(f(0.5), dtype=dtype), cav, lx.Drift(f(0.5), dtype=dtype)])
+        program = engine.plan(seg, seg.elements, False)[0]
+        lat = engine._ready(seg.__dict__.setdefault("_lattice_cache", engine.LatticeCache()), program, (B,), dtype, None)
+        e_in = rt.to_device(f(1e8))
+        steps = rt.empty((B, len(program.steps), _ffi.STEP_STRIDE), dtype)
+        rt.check(rt.lib.lynx_build_compose(rt.ctx, lat.handle, engine._ptr(e_in), engine._ptr(steps), None))
+        table = steps.numpy()
+        assert np.all(table[:, 1, 62] == want), (kw, table[:, :, 62])
+        assert np.all(table[:, 0, 62] == 0) and np.all(table[:, 2, 62] == 0)
+    # chained programs: the first one's outgoing energy stays in HBM, the second evaluates its predicates from it
+    seg = lx.Segment([lx.Cavity(f(1.0), voltage=f(1e7), phase=f(0.0), frequency=f(1.3e9), dtype=dtype), lx.Drift(f(0.3), dtype=dtype)])
+    P = o.gaussian_particles((B,), 2000, seed=1, dtype=dtype, sigma=[1e-4, 1e-5, 1e-4, 1e-5, 1e-4, 1e-3])
+    first = seg.track(lx.ParticleBeam(P, f(6e6), dtype=dtype))
+    assert first._energy._host is None  # lives in HBM
+    second = seg.track(first)
+    assert first._energy._host is None  # and tracking it did not read it back
+    assert np.allclose(second.energy, 6e6 + 2e7, rtol=1e-6)
+    ref1 = o.segment_track([o.Cavity(f(1.0), voltage=f(1e7), phase=f(0.0), frequency=f(1.3e9)), o.Drift(f(0.3))],
+                           o.particle_beam(P, f(6e6), dtype), dtype)
+    ref2 = o.segment_track([o.Cavity(f(1.0), voltage=f(1e7), phase=f(0.0), frequency=f(1.3e9)), o.Drift(f(0.3))], ref1, dtype)
+    _assert_moments(second, ref2, dtype)
+
+
 def test_error_conventions(lx):
     f = lambda v: np.array([v], dtype=np.float32)  # noqa: E731
     with pytest.raises(TypeError):

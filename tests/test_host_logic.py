@@ -117,15 +117,13 @@ def test_packed_lattice_layout_and_flags():
     assert np.allclose(row1, [0.2, 2.0, 0.1, 0.0, 0.0])  # sample 1 of the quadrupole: L, k1, tilt, mx, my
     ef, sf = lat.evaluate_flags(f(1e8))
     assert ef[0] == _ffi.FLAG_TILT and ef[3] == _ffi.FLAG_THICK
-    gain_t5 = _ffi.FLAG_CAV_BETA | _ffi.FLAG_CAV_GAIN | _ffi.FLAG_CAV_T5XX
-    assert ef[4] == gain_t5 and sf == [0, gain_t5]
-    # decelerating cavity on every sample: dE < 0 -> no T5XX; still E + dE > 0 -> GAIN
-    cav.phase = f(180.0)
+    # cavity bits are whole-batch predicates of the beam ENERGY: evaluated on the device before every build
+    # (k_cavity_flags; GPU test test_cavity_predicates_are_evaluated_on_the_device), never on the host
+    assert ef[4] == 0 and sf == [0, 0]
     lat2 = engine.PackedLattice(engine.partition([cav])[0], (B,), np.float32)
-    _, sf2 = lat2.evaluate_flags(f(1e8))
-    assert sf2 == [_ffi.FLAG_CAV_BETA | _ffi.FLAG_CAV_GAIN]
     with pytest.raises(AssertionError, match="Initial energy must be larger than 0"):  # cavity.py:260
         lat2.evaluate_flags(f(0.0))
+    assert lat2.evaluate_flags(None) == ([0], [0])  # energy in HBM only: no read-back for the sake of a check
 
 
 def test_shape_mismatch_is_an_assertion_error():
