@@ -45,6 +45,14 @@ __device__ __forceinline__ bool steps_pair_up(const lynx_step& run, const lynx_s
   return run.kind == LYNX_STEP_RUN && cav.kind == LYNX_STEP_CAVITY && !(run.flags & LYNX_STEP_FLAG_OBSERVE);
 }
 
+// what a builder parks in slot LYNX_FLAGS_OFFSET of step s
+__device__ __forceinline__ int step_descriptor(const LatticeDev& lat, int s, int merge_pairs) {
+  const lynx_step st = lat.steps[s];
+  int d = (st.flags & 0xffff) | (st.kind << LYNX_DESC_KIND_SHIFT);
+  if (merge_pairs && s + 1 < lat.n_steps && steps_pair_up(st, lat.steps[s + 1])) d |= LYNX_DESC_PAIR;
+  return d;
+}
+
 constexpr int kBuildChunk = 64;   // elements built in parallel per compose round (k_build may use up to 128)
 constexpr int kTrackThreads = 256;
 constexpr int kPartialStride = 36;
@@ -516,7 +524,7 @@ __global__ __launch_bounds__(64) void k_emit_steps(LatticeDev lat, const int32_t
 #pragma unroll
     for (int q = 0; q < 8; ++q) row[LYNX_COEF_OFFSET + q] = cs[q * Bp];
   }
-  row[LYNX_FLAGS_OFFSET] = (T)st.flags;
+  row[LYNX_FLAGS_OFFSET] = (T)step_descriptor(lat, s, merge_pairs);
   if (s == S - 1) {
     const T e_out = energy_before_step<T>(lat, b, energy_in[b], S);
     row[LYNX_ENERGY_OFFSET] = e_out;
@@ -764,7 +772,7 @@ __global__ __launch_bounds__(1024) void k_build(LatticeDev lat, const T* __restr
     }
   }
   for (int s = threadIdx.x; s < lat.n_steps; s += blockDim.x)
-    s_steps[s * LYNX_STEP_STRIDE + LYNX_FLAGS_OFFSET] = (T)lat.steps[s].flags;
+    s_steps[s * LYNX_STEP_STRIDE + LYNX_FLAGS_OFFSET] = (T)step_descriptor(lat, s, merge_pairs);
   if (lat.n_steps > 0 && threadIdx.x == 0)
     s_steps[(lat.n_steps - 1) * LYNX_STEP_STRIDE + LYNX_ENERGY_OFFSET] = s_energy[lat.n_steps];
   __syncthreads();
@@ -1125,8 +1133,10 @@ __device__ __forceinline__ void apply_program_lane(const LatticeDev& lat, int S,
     // to the cavity's slot, which holds T_cav . T_run
     bool merged = false;
     lynx_f32x2 s_entry[kPairs ? UNROLL / 2 : 1], d_entry[kPairs ? UNROLL / 2 : 1];
-    lynx_step st = lat.steps[sidx];
-    if (s_obs && (st.flags & LYNX_STEP_FLAG_OBSERVE) && st.kind == LYNX_STEP_RUN) {  // uniform
+    // kind, flags and pairing of the step: one wave-uniform scalar from the table this kernel was given
+    const T* table = SCALAR_TABLE ? g_steps : s_steps;
+    int desc = (int)uniform_value(table[sidx * LYNX_STEP_STRIDE + LYNX_FLAGS_OFFSET]);
+    if (s_obs && (desc & LYNX_STEP_FLAG_OBSERVE)) {  // uniform
       // an active BPM: x and y of the particles that enter it, added up per lane in float64 (LDS cells of
       // this lane only: no barrier); bpm.py:48-54 reads mu_x, mu_y of the incoming beam
 #pragma unroll
@@ -1147,7 +1157,7 @@ __device__ __forceinline__ void apply_program_lane(const LatticeDev& lat, int S,
       ++n_obs;
     }
     if constexpr (kPairs && SCALAR_TABLE) {
-      if (merged_pairs && sidx + 1 < S && steps_pair_up(st, lat.steps[sidx + 1])) {  // uniform
+      if (desc & LYNX_DESC_PAIR) {  // uniform: this run is applied together with the cavity behind it
         const float* tab = reinterpret_cast<const float*>(g_steps) + sidx * LYNX_STEP_STRIDE;
         float pre[14];
 #pragma unroll
@@ -1156,10 +1166,11 @@ __device__ __forceinline__ void apply_program_lane(const LatticeDev& lat, int S,
         for (int h = 0; h < UNROLL / 2; ++h) merged_pair_entry(pre, zp[h], s_entry[h], d_entry[h]);
         merged = true;
         ++sidx;
-        st = lat.steps[sidx];
+        desc = (int)uniform_value(table[sidx * LYNX_STEP_STRIDE + LYNX_FLAGS_OFFSET]);
         LYNX_FORGET();
       }
     }
+    const int skind = (desc >> LYNX_DESC_KIND_SHIFT) & 3, sflags = desc & 0xffff;
     if constexpr (kMapInRegs) {
       T m[57];  // T = float here
       if (SCALAR_TABLE) {
@@ -1171,22 +1182,18 @@ __device__ __forceinline__ void apply_program_lane(const LatticeDev& lat, int S,
 #pragma unroll
         for (int q = 0; q < 57; ++q) m[q] = uniform_value(tab[q]);
       }
-      // the cavity bits as they stood when this table was built (LYNX_FLAGS_OFFSET), not the lattice's
-      // current ones: the next call's k_cavity_flags may already be rewriting those
-      const int sflags = (int)uniform_value((SCALAR_TABLE ? g_steps : s_steps)[sidx * LYNX_STEP_STRIDE + LYNX_FLAGS_OFFSET]);
       if constexpr (kPairs) {
 #pragma unroll
         for (int h = 0; h < UNROLL / 2; ++h)
-          apply_step_pair(m, st.kind, sflags, zp[h], merged, s_entry[h], d_entry[h]);
+          apply_step_pair(m, skind, sflags, zp[h], merged, s_entry[h], d_entry[h]);
       } else {
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) apply_step<T>(m, st.kind, sflags, z[u]);
+        for (int u = 0; u < UNROLL; ++u) apply_step<T>(m, skind, sflags, z[u]);
       }
     } else {
       const T* tab = s_steps + sidx * LYNX_STEP_STRIDE;
-      const int sflags = (int)tab[LYNX_FLAGS_OFFSET];
 #pragma unroll
-      for (int u = 0; u < UNROLL; ++u) apply_step<T>(tab, st.kind, sflags, z[u]);
+      for (int u = 0; u < UNROLL; ++u) apply_step<T>(tab, skind, sflags, z[u]);
     }
   }
   if constexpr (kPairs) {
@@ -1263,7 +1270,7 @@ __global__ __launch_bounds__(kTrackThreads, (XPOSE ? 3 : 1)) void k_track_direct
 
   if (FUSED) {
     build_compose_sample<T>(lat, b, energy_in[b], s_steps, s_energy, s_scratch, a.build_chunk);
-    for (int s = tid; s < S; s += kTrackThreads) s_steps[s * LYNX_STEP_STRIDE + LYNX_FLAGS_OFFSET] = (T)lat.steps[s].flags;
+    for (int s = tid; s < S; s += kTrackThreads) s_steps[s * LYNX_STEP_STRIDE + LYNX_FLAGS_OFFSET] = (T)step_descriptor(lat, s, 0);
     __syncthreads();
     if (energy_out && chunk == 0 && tid == 0) energy_out[b] = s_energy[S];
   } else if (S > 0) {

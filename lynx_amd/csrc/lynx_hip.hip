@@ -715,7 +715,8 @@ static TrackPlan plan_track(lynx_ctx* ctx, const lynx_lattice* lat, int64_t B, i
   const int64_t ntiles = (N + tile - 1) / tile;
   // A workgroup pays a fixed cost (table load, 29-value cross-lane reduction, partial
   // record), so it gets at least `min_tpw` tiles -- unless that would leave CUs idle.
-  int64_t min_tpw = env_int("LYNX_MIN_TILES_PER_WG", sizeof(T) == 4 ? 3 : 4);
+  // (multi-step programs also fetch S step records per iteration: longer-lived workgroups, C5: -2.5 %)
+  int64_t min_tpw = env_int("LYNX_MIN_TILES_PER_WG", S > 1 ? 8 : (sizeof(T) == 4 ? 3 : 4));
   while (min_tpw > 1 && B * ((ntiles + min_tpw - 1) / min_tpw) < 4 * cus) --min_tpw;
   int64_t chunks = std::max<int64_t>(1, std::min<int64_t>((ntiles + min_tpw - 1) / min_tpw, (target + B - 1) / B));
   int64_t tpw = (ntiles + chunks - 1) / chunks;

@@ -52,6 +52,12 @@ namespace lynx {
 // cavity bits are whole-batch predicates of the beam energy, re-evaluated on the device before every
 // build; the streaming kernel of call n reads them here and never sees call n+1's.
 #define LYNX_FLAGS_OFFSET 62
+// ... together with the step's kind and whether it is applied merged with the cavity behind it, so that
+// the streaming kernel's step loop needs nothing but wave-uniform scalar loads from its table (reading
+// `lat.steps[s]` there cost a vector load + readfirstlane per step: the pointer sits in a by-value struct
+// and cannot be declared __restrict__)
+#define LYNX_DESC_KIND_SHIFT 16
+#define LYNX_DESC_PAIR (1 << 20)
 // last step, slot 63: the beam energy behind the last step (published by the streaming kernel)
 #define LYNX_ENERGY_OFFSET 63
 // cavity coefficient slots (lynx/accelerator/cavity.py:141-226)

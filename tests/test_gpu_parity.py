@@ -869,9 +869,9 @@ def test_cavity_predicates_are_evaluated_on_the_device(lx, dtype):
         e_in = rt.to_device(f(1e8))
         steps = rt.empty((B, len(program.steps), _ffi.STEP_STRIDE), dtype)
         rt.check(rt.lib.lynx_build_compose(rt.ctx, lat.handle, engine._ptr(e_in), engine._ptr(steps), None))
-        table = steps.numpy()
-        assert np.all(table[:, 1, 62] == want), (kw, table[:, :, 62])
-        assert np.all(table[:, 0, 62] == 0) and np.all(table[:, 2, 62] == 0)
+        desc = steps.numpy()[:, :, 62].astype(np.int64)  # flags | kind << 16 (| pair bit)
+        assert np.all(desc[:, 1] & 0xFFFF == want) and np.all(desc[:, 1] >> 16 == _ffi.STEP_CAVITY), (kw, desc)
+        assert np.all(desc[:, 0] == 0) and np.all(desc[:, 2] == 0)
     # chained programs: the first one's outgoing energy stays in HBM, the second evaluates its predicates from it
     seg = lx.Segment([lx.Cavity(f(1.0), voltage=f(1e7), phase=f(0.0), frequency=f(1.3e9), dtype=dtype), lx.Drift(f(0.3), dtype=dtype)])
     P = o.gaussian_particles((B,), 2000, seed=1, dtype=dtype, sigma=[1e-4, 1e-5, 1e-4, 1e-5, 1e-4, 1e-3])
