@@ -100,6 +100,19 @@ template <typename T> __device__ __forceinline__ T sum_over_wave(T v) {
   return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
 }
 
+// kind and flags of step s from the table's descriptor slot (a wave-uniform scalar load; `lat.steps[s]`
+// would be a vector load + readfirstlane per step, see LYNX_FLAGS_OFFSET)
+template <typename T>
+__device__ __forceinline__ lynx_step table_step(const T* g_steps, int s) {
+  const int desc = (int)uniform_value(g_steps[s * LYNX_STEP_STRIDE + LYNX_FLAGS_OFFSET]);
+  lynx_step st;
+  st.kind = (desc >> LYNX_DESC_KIND_SHIFT) & 3;
+  st.flags = desc & 0xffff;
+  st.first = 0;
+  st.last = 0;
+  return st;
+}
+
 template <typename T>
 __device__ __forceinline__ void load_step_map(const T* g_steps, int s, T (&m)[57]) {
 #pragma unroll
@@ -197,7 +210,7 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
 
     // forward sweep, parking the state that enters every K-th step
     for (int s = 0; s < S; ++s) {
-      const lynx_step st = lat.steps[s];
+      const lynx_step st = table_step<T>(g_steps, s);
       T m[57];
       load_step_map<T>(g_steps, s, m);
       if (s % K == 0) {
@@ -245,7 +258,7 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
 #pragma unroll
         for (int c = 0; c < 7; ++c) zz[j][c] = zz[j - 1][c];
         if (sp + 1 < S) {
-          const lynx_step st = lat.steps[sp];
+          const lynx_step st = table_step<T>(g_steps, sp);
           T m[57];
           load_step_map<T>(g_steps, sp, m);
           zapply(m, st.kind, st.flags, zz[j]);
@@ -255,7 +268,7 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
       for (int j = K - 1; j >= 0; --j) {
         const int s = grp * K + j;
         if (s >= S) continue;  // uniform
-        const lynx_step st = lat.steps[s];
+        const lynx_step st = table_step<T>(g_steps, s);
         T m[57];
         load_step_map<T>(g_steps, s, m);
         Z zin[7];
