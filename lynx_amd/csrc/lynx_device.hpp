@@ -18,6 +18,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "lynx_maps.hpp"
 
 namespace lynx {
@@ -242,12 +244,24 @@ __device__ void build_compose_sample(const LatticeDev& lat, int64_t b, T energy_
 // ---------------------------------------------------------------------------------------
 constexpr int kCavMask = LYNX_FLAG_CAV_BETA | LYNX_FLAG_CAV_GAIN | LYNX_FLAG_CAV_T5XX;
 
+constexpr int kFlagsPerThread = 8;  // samples whose energy a thread of k_cavity_flags keeps in registers
+
 template <typename T>
 __global__ __launch_bounds__(1024) void k_cavity_flags(LatticeDev lat, lynx_elem* elems, lynx_step* steps,
                                                        const T* __restrict__ energy_in, T* __restrict__ e_run) {
   const T* pool = static_cast<const T*>(lat.pool);
   const int64_t B = lat.batch;
-  for (int64_t b = threadIdx.x; b < B; b += blockDim.x) e_run[b] = energy_in[b];
+  // every sample's energy on its way through the cavities: in registers for batches of up to 8192, in
+  // `e_run` beyond (hundreds of thousands of ParameterBeam settings)
+  const bool in_regs = B <= (int64_t)kFlagsPerThread * 1024;
+  T e_reg[kFlagsPerThread];
+#pragma unroll
+  for (int q = 0; q < kFlagsPerThread; ++q) {
+    const int64_t b = threadIdx.x + (int64_t)q * 1024;
+    e_reg[q] = b < B ? energy_in[b] : T(1);
+  }
+  if (!in_regs)
+    for (int64_t b = threadIdx.x; b < B; b += blockDim.x) e_run[b] = energy_in[b];
   __syncthreads();
   for (int s = 0; s < lat.n_steps; ++s) {
     const lynx_step st = steps[s];
@@ -256,15 +270,26 @@ __global__ __launch_bounds__(1024) void k_cavity_flags(LatticeDev lat, lynx_elem
       if (el.kind != LYNX_KIND_CAVITY) continue;  // uniform
       const bool is_step = st.kind == LYNX_STEP_CAVITY;
       int mine = 0;
-      for (int64_t b = threadIdx.x; b < B; b += blockDim.x) {
+      T de_reg[kFlagsPerThread];
+      auto look = [&](T energy, int64_t b) -> T {
         const T* p = pool + el.param_offset + b * (int64_t)el.batch_stride;
-        const T energy = e_run[b], voltage = p[1];
+        const T voltage = p[1];
         const T d_energy = voltage * t_cos(p[2] * T(LYNX_PI / 180.0));
         if (voltage != T(0) && energy != T(0)) mine |= LYNX_FLAG_CAV_BETA;
         if (is_step) {
           if (energy + d_energy > T(0)) mine |= LYNX_FLAG_CAV_GAIN;
           if (d_energy > T(0)) mine |= LYNX_FLAG_CAV_T5XX;
         }
+        return d_energy;
+      };
+      if (in_regs) {
+#pragma unroll
+        for (int q = 0; q < kFlagsPerThread; ++q) {
+          const int64_t b = threadIdx.x + (int64_t)q * 1024;
+          de_reg[q] = b < B ? look(e_reg[q], b) : T(0);
+        }
+      } else {
+        for (int64_t b = threadIdx.x; b < B; b += blockDim.x) (void)look(e_run[b], b);
       }
       int f = 0;
       if (__syncthreads_or(mine & LYNX_FLAG_CAV_BETA)) f |= LYNX_FLAG_CAV_BETA;
@@ -275,9 +300,14 @@ __global__ __launch_bounds__(1024) void k_cavity_flags(LatticeDev lat, lynx_elem
         if (is_step) steps[s].flags = (st.flags & ~kCavMask) | f;
       }
       if (is_step && (f & LYNX_FLAG_CAV_GAIN)) {  // cavity.py:130: the whole batch moves on with E + dE
-        for (int64_t b = threadIdx.x; b < B; b += blockDim.x) {
-          const T* p = pool + el.param_offset + b * (int64_t)el.batch_stride;
-          e_run[b] = e_run[b] + p[1] * t_cos(p[2] * T(LYNX_PI / 180.0));
+        if (in_regs) {
+#pragma unroll
+          for (int q = 0; q < kFlagsPerThread; ++q) e_reg[q] = e_reg[q] + de_reg[q];
+        } else {
+          for (int64_t b = threadIdx.x; b < B; b += blockDim.x) {
+            const T* p = pool + el.param_offset + b * (int64_t)el.batch_stride;
+            e_run[b] = e_run[b] + p[1] * t_cos(p[2] * T(LYNX_PI / 180.0));
+          }
         }
       }
       __syncthreads();
@@ -1587,11 +1617,10 @@ __global__ __launch_bounds__(64) void k_reduce_observers(const double* __restric
 // parallelises over elements.  The moment propagation itself uses 49 lanes.
 // ---------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void k_track_moments(LatticeDev lat, const T* __restrict__ energy_in,
-                                                       const T* mu_in, const T* cov_in, T* mu_out,
-                                                       T* cov_out, T* __restrict__ energy_out) {
+__global__ __launch_bounds__(1024) void k_track_moments(LatticeDev lat, const T* __restrict__ energy_in,
+                                                        const T* mu_in, const T* cov_in, T* mu_out,
+                                                        T* cov_out, T* __restrict__ energy_out, int chunk) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int chunk = build_chunk(lat.n_elems);
   T* s_steps = reinterpret_cast<T*>(smem_raw + build_scratch_bytes(chunk, sizeof(T)));
   T* s_energy = s_steps + (size_t)lat.n_steps * LYNX_STEP_STRIDE;
   T* s_mu = s_energy + lat.n_steps + 1;  // 8
@@ -1658,6 +1687,116 @@ __global__ __launch_bounds__(256) void k_track_moments(LatticeDev lat, const T* 
   if (lane < 7) mu_out[b * 7 + lane] = s_mu[lane];
   if (lane < 49) cov_out[b * 49 + lane] = s_cov[lane];
   if (energy_out && lane == 0) energy_out[b] = s_energy[lat.n_steps];
+}
+
+// ---------------------------------------------------------------------------------------
+// k_apply_moments_lanes: ParameterBeam path for LARGE batches (hundreds of thousands of settings in one
+// call, tests/test_vectorized.py:298-321), lanes = samples: the step table comes from the lanes build,
+// a wave stages the 64 table rows of a step in LDS with coalesced loads, every lane takes its own row
+// and propagates ITS sample's moments in registers -- mu' = T mu, cov' = T cov T^T as X = cov T^T (row by
+// row in place) and cov' = T X (column by column in place), then the cavity branch (cavity.py:134-140,
+// 202-218).  Same operations in the same order per sample as k_track_moments, which keeps one
+// workgroup per sample and spends most of its lanes waiting (3 x 100 000 settings of the ARES lattice:
+// 1.56 ms there).
+// ---------------------------------------------------------------------------------------
+template <typename T> constexpr size_t apply_moments_lds() { return 64 * 68 * sizeof(T); }
+
+template <typename T>
+__global__ __launch_bounds__(64) void k_apply_moments_lanes(LatticeDev lat, const T* __restrict__ steps,
+                                                            const T* __restrict__ mu_in, const T* __restrict__ cov_in,
+                                                            T* __restrict__ mu_out, T* __restrict__ cov_out,
+                                                            T* __restrict__ energy_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  using V = typename VecOf<T, true>::type;
+  constexpr int W = VecOf<T, true>::width, kVecPerRow = LYNX_STEP_STRIDE / W;
+  T* rows = reinterpret_cast<T*>(smem_raw);
+  const int lane = threadIdx.x, S = lat.n_steps;
+  const int64_t b0 = (int64_t)blockIdx.x * 64, B = lat.batch;
+  const bool live = b0 + lane < B;
+  const int64_t b = live ? b0 + lane : B - 1;
+  T mu[7], C[49];
+#pragma unroll
+  for (int q = 0; q < 7; ++q) mu[q] = mu_in[b * 7 + q];
+#pragma unroll
+  for (int q = 0; q < 49; ++q) C[q] = cov_in[b * 49 + q];
+  for (int s = 0; s < S; ++s) {
+    wave_fence();
+    // the wave's 64 rows of step s: [sample][64] scalars, 16-byte pieces, consecutive lanes -> consecutive pieces
+#pragma unroll 4
+    for (int v = lane; v < 64 * kVecPerRow; v += 64) {
+      const int r = v / kVecPerRow, piece = v - r * kVecPerRow;
+      const int64_t br = (b0 + r < B) ? b0 + r : B - 1;
+      const V x = *reinterpret_cast<const V*>(steps + (br * S + s) * LYNX_STEP_STRIDE + piece * W);
+      *reinterpret_cast<V*>(rows + r * 68 + piece * W) = x;
+    }
+    wave_fence();
+    const T* M = rows + lane * 68;
+    const int desc = (int)M[LYNX_FLAGS_OFFSET];
+    const bool kick = ((desc >> LYNX_DESC_KIND_SHIFT) & 3) == LYNX_STEP_CAVITY && (desc & LYNX_FLAG_CAV_GAIN);
+    const T s_in = mu[4], d_in = mu[5], c44 = C[4 * 7 + 4], c45 = C[4 * 7 + 5], c55 = C[5 * 7 + 5];
+    // mu' = T mu
+    {
+      T out[7];
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        T acc = M[i * 7] * mu[0];
+#pragma unroll
+        for (int k = 1; k < 7; ++k) acc = t_fma(M[i * 7 + k], mu[k], acc);
+        out[i] = acc;
+      }
+#pragma unroll
+      for (int i = 0; i < 7; ++i) mu[i] = out[i];
+    }
+    // X = cov . T^T, row i of X from row i of cov
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      T out[7];
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        T acc = C[i * 7] * M[j * 7];
+#pragma unroll
+        for (int k = 1; k < 7; ++k) acc = t_fma(C[i * 7 + k], M[j * 7 + k], acc);
+        out[j] = acc;
+      }
+#pragma unroll
+      for (int j = 0; j < 7; ++j) C[i * 7 + j] = out[j];
+    }
+    // cov' = T . X, column j of cov' from column j of X
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      T out[7];
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        T acc = M[i * 7] * C[j];
+#pragma unroll
+        for (int k = 1; k < 7; ++k) acc = t_fma(M[i * 7 + k], C[k * 7 + j], acc);
+        out[i] = acc;
+      }
+#pragma unroll
+      for (int i = 0; i < 7; ++i) C[i * 7 + j] = out[i];
+    }
+    if (kick) {
+      T coef[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) coef[q] = M[LYNX_COEF_OFFSET + q];
+      T s_o = mu[4], d_o;
+      device_cavity_kick<T>(coef, s_in, d_in, s_o, d_o);  // cavity.py:134-140, 202-206
+      mu[4] = s_o;
+      mu[5] = d_o;
+      C[5 * 7 + 5] = c55;  // cavity.py:140
+      const T v = coef[LYNX_C_T566] * (c55 * c55) + coef[LYNX_C_T556] * c45 * c55 + coef[LYNX_C_T555] * (c44 * c44);  // cavity.py:207-218
+      C[4 * 7 + 4] = v;
+      C[4 * 7 + 5] = v;
+      C[5 * 7 + 4] = v;
+    }
+    if (s == S - 1 && energy_out && live) energy_out[b] = M[LYNX_ENERGY_OFFSET];
+  }
+  if (live) {
+#pragma unroll
+    for (int q = 0; q < 7; ++q) mu_out[b * 7 + q] = mu[q];
+#pragma unroll
+    for (int q = 0; q < 49; ++q) cov_out[b * 49 + q] = C[q];
+  }
 }
 
 // ---------------------------------------------------------------------------------------

@@ -60,8 +60,8 @@ struct lynx_ctx {
   size_t scratch_products_bytes = 0;
   void* scratch_coefs = nullptr;     // ... and cavity coefficients [S][8][Bp]
   size_t scratch_coefs_bytes = 0;
-  void* scratch_steps[3] = {nullptr, nullptr, nullptr};  // two alternating step tables + the reverse pass's own
-  size_t scratch_steps_bytes[3] = {0, 0, 0};
+  void* scratch_steps[4] = {nullptr, nullptr, nullptr, nullptr};  // two alternating step tables, the reverse pass's own, the ParameterBeam lanes path's
+  size_t scratch_steps_bytes[4] = {0, 0, 0, 0};
   void* scratch_grad[3] = {nullptr, nullptr, nullptr};  // backward: partials, T_bar, build scratch
   size_t scratch_grad_bytes[3] = {0, 0, 0};
   ncclComm_t comm = nullptr;
@@ -235,10 +235,10 @@ int lynx_ctx_destroy(lynx_ctx* ctx) {
   if (ctx->scratch_erun) (void)hipFree(ctx->scratch_erun);
   if (ctx->scratch_products) (void)hipFree(ctx->scratch_products);
   if (ctx->scratch_coefs) (void)hipFree(ctx->scratch_coefs);
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < 4; ++i)
     if (ctx->scratch_steps[i]) (void)hipFree(ctx->scratch_steps[i]);
+  for (int i = 0; i < 3; ++i)
     if (ctx->scratch_grad[i]) (void)hipFree(ctx->scratch_grad[i]);
-  }
   for (int i = 0; i < 2; ++i) {
     (void)hipEventDestroy(ctx->ev_built[i]);
     (void)hipEventDestroy(ctx->ev_streamed_own[i]);
@@ -1083,15 +1083,33 @@ int lynx_moments(lynx_ctx* ctx, int dtype, int64_t batch, int64_t n_particles, c
 template <typename T>
 static int launch_track_moments(lynx_ctx* ctx, lynx_lattice* lat, const void* d_energy_in, const void* d_mu_in,
                                 const void* d_cov_in, void* d_mu_out, void* d_cov_out, void* d_energy_out) {
-  const size_t lds = build_scratch_bytes(build_chunk(lat->n_elems), sizeof(T)) +
+  int rc;
+  if constexpr (sizeof(T) == 4)  // (float64: 98 VGPRs of covariance per lane -- the compiler spills; workgroup form below)
+  if (lat->n_steps > 0 && lat->batch >= env_int("LYNX_LANES_BUILD_MIN_BATCH", 256)) {
+    // large batches: lanes = samples all the way (step table from the lanes build, then one lane per sample)
+    const size_t need = (size_t)lat->batch * lat->n_steps * LYNX_STEP_STRIDE * sizeof(T);
+    if ((rc = ensure_scratch(ctx, &ctx->scratch_steps[3], &ctx->scratch_steps_bytes[3], need))) return rc;
+    if ((rc = launch_build<T>(ctx, lat, ctx->stream, d_energy_in, ctx->scratch_steps[3], nullptr, 0))) return rc;
+    hipLaunchKernelGGL(k_apply_moments_lanes<T>, dim3((unsigned)((lat->batch + 63) / 64)), dim3(64), apply_moments_lds<T>(),
+                       ctx->stream, dev_view(lat), (const T*)ctx->scratch_steps[3], (const T*)d_mu_in, (const T*)d_cov_in,
+                       (T*)d_mu_out, (T*)d_cov_out, (T*)d_energy_out);
+    HIP_TRY(ctx, hipGetLastError());
+    return LYNX_OK;
+  }
+  // one workgroup per sample: one wave for big batches, four for medium ones, sixteen (and chunks of up to
+  // 128 elements) when the batch leaves most of the GPU idle and the depth of the tree is what the call waits for
+  const int64_t cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+  const bool wide = lat->batch * 2 <= cus;
+  const unsigned threads = wide ? 1024u : (lat->batch <= 4096 ? 256u : 64u);
+  const int chunk = build_chunk(lat->n_elems, wide ? 128 : 64);
+  const size_t lds = build_scratch_bytes(chunk, sizeof(T)) +
                      ((size_t)lat->n_steps * LYNX_STEP_STRIDE + lat->n_steps + 1 + 8 + 49 + 49 + 16) * sizeof(T);
-  int rc = allow_lds(ctx, k_track_moments<T>, lds);
+  rc = allow_lds(ctx, k_track_moments<T>, lds);
   if (rc) return rc;
   if ((rc = launch_cavity_flags<T>(ctx, lat, ctx->stream, d_energy_in))) return rc;
-  const unsigned threads = lat->batch <= 4096 ? 256u : 64u;
   hipLaunchKernelGGL(k_track_moments<T>, dim3((unsigned)lat->batch), dim3(threads), lds, ctx->stream, dev_view(lat),
                      (const T*)d_energy_in, (const T*)d_mu_in, (const T*)d_cov_in, (T*)d_mu_out, (T*)d_cov_out,
-                     (T*)d_energy_out);
+                     (T*)d_energy_out, chunk);
   HIP_TRY(ctx, hipGetLastError());
   return LYNX_OK;
 }

@@ -543,6 +543,46 @@ def test_parameter_beam_through_mixed_lattice(lx, dtype):
     assert rel_err(out.energy, ref["energy"]) < 1e-6
 
 
+def test_parameter_beam_lanes_path_agrees_with_the_workgroup_path(lx, monkeypatch):
+    """
+    float32 ParameterBeam batches of >= 256 samples go lanes = samples (lanes build + k_apply_moments_lanes),
+    smaller ones one workgroup per sample (k_track_moments): the same lattice with cavities through both, and
+    against the oracle (element.py:71-82, cavity.py:134-140, 202-218).
+    """
+    B = 300
+    rng = np.random.default_rng(12)
+    f = lambda v: np.full(B, v)  # noqa: E731
+    desc = [("drift", dict(length=f(0.6))), ("quadrupole", dict(length=f(0.2), k1=rng.uniform(-5, 5, B), tilt=rng.uniform(-1, 1, B))),
+            ("cavity", dict(length=f(1.0377), voltage=rng.uniform(5e6, 2e7, B), phase=rng.uniform(-10, 10, B), frequency=f(1.3e9))),
+            ("drift", dict(length=f(0.4))), ("hcor", dict(length=f(0.1), angle=f(1e-4))),
+            ("cavity", dict(length=f(1.0377), voltage=rng.uniform(5e6, 2e7, B), phase=f(0.0), frequency=f(1.3e9))),
+            ("dipole", dict(length=f(0.5), angle=f(0.1)))]
+    for _ in range(3):
+        desc += [("quadrupole", dict(length=f(0.2), k1=rng.uniform(-5, 5, B))), ("drift", dict(length=f(0.5))), ("vcor", dict(length=f(0.1), angle=f(1e-4)))]
+    dtype = np.float32
+    kw = dict(sigma_x=f(1e-4), sigma_xp=f(1e-5), sigma_y=f(1e-4), sigma_yp=f(1e-5), sigma_s=f(1e-5), sigma_p=f(1e-3),
+              mu_x=rng.normal(0, 1e-4, B), energy=f(6e6))
+    kw = {k: np.asarray(v, dtype=dtype) for k, v in kw.items()}
+    outs = {}
+    for name, min_batch in (("workgroup", "1000000"), ("lanes", "1")):
+        monkeypatch.setenv("LYNX_LANES_BUILD_MIN_BATCH", min_batch)
+        elements, specs = make_lattice(desc, dtype, lx)
+        out = lx.Segment(elements).track(lx.ParameterBeam.from_parameters(**kw, dtype=dtype))
+        outs[name] = (np.array(out._mu), np.array(out._cov), np.array(out.energy))
+    ref = o.segment_track(specs, o.parameter_beam_from_parameters(dtype=dtype, **kw), dtype)
+    for name, (mu, cov, energy) in outs.items():
+        assert rel_err(mu, ref["mu"]) < 2e-3, name
+        assert rel_err(energy, ref["energy"]) < 1e-6, name
+        for i in range(6):
+            for j in range(6):
+                sc = np.sqrt(np.abs(ref["cov"][..., i, i] * ref["cov"][..., j, j])) + 1e-300
+                assert np.max(np.abs(cov[..., i, j] - ref["cov"][..., i, j]) / sc) < 2e-2, (name, i, j)
+    a, b = outs["workgroup"], outs["lanes"]
+    assert rel_err(b[0], a[0]) < 1e-5 and np.array_equal(a[2], b[2])
+    sc = np.sqrt(np.abs(np.einsum("bii,bjj->bij", a[1][..., :6, :6], a[1][..., :6, :6]))) + 1e-300
+    assert np.max(np.abs(b[1][..., :6, :6] - a[1][..., :6, :6]) / sc) < 1e-4
+
+
 def test_parameter_beam_huge_batch(lx):
     """reference tests/test_vectorized.py:298-321 in spirit: (3, 100000) settings at once."""
     shape = (3, 20_000)
