@@ -749,15 +749,6 @@ __device__ __forceinline__ void merged_pair_entry(const float* pre /*14*/, const
   }
 }
 
-// Whole program on one particle, step data read from LDS.
-template <typename T>
-__device__ __forceinline__ void apply_program(const LatticeDev& lat, const T* s_steps, T (&z)[7]) {
-  for (int s = 0; s < lat.n_steps; ++s) {
-    lynx_step st = lat.steps[s];
-    apply_step<T>(s_steps + s * LYNX_STEP_STRIDE, st.kind, st.flags, z);
-  }
-}
-
 // ---------------------------------------------------------------------------------------
 // k_build: standalone build+compose, one workgroup per sample: 256 threads and chunks of up to
 // 64 elements when the batch fills the GPU, 1024 threads and chunks of up to 128 when it does not
@@ -822,7 +813,7 @@ struct TrackArgs {
   int32_t build_chunk;   // fused prologue: elements per compose round
   int32_t interleave;    // 1 = a workgroup takes every `chunks`-th tile
   int64_t in_stride;     // scalars between the samples of p_in: N*7, or 0 for one shared incoming beam
-  int32_t merged_pairs;  // the step table holds [run, cavity] pairs in merged form (see k_build)
+  int32_t merged_pairs;  // the step table holds [run, cavity] pairs in merged form (the builder marks them: LYNX_DESC_PAIR)
   int32_t n_observers;   // LYNX_STEP_FLAG_OBSERVE steps of the program (their sums live behind the step table in LDS)
 };
 
@@ -1140,7 +1131,7 @@ struct LaneSums {
 // all of them; fp32 with an even UNROLL runs the particles as packed pairs
 template <typename T, int UNROLL, bool SCALAR_TABLE>
 __device__ __forceinline__ void apply_program_lane(const LatticeDev& lat, int S, const T* g_steps, const T* s_steps,
-                                                   int merged_pairs, T (&z)[UNROLL][7],
+                                                   T (&z)[UNROLL][7],
                                                    double* s_obs = nullptr /* this lane's [observer][x, y] sums, pitch 256 */,
                                                    const bool (*live)[UNROLL] = nullptr) {
   constexpr bool kMapInRegs = sizeof(T) == 4;
@@ -1365,7 +1356,7 @@ __global__ __launch_bounds__(kTrackThreads, (XPOSE ? 3 : 1)) void k_track_direct
           apply_step<T>(s_steps, LYNX_STEP_RUN, 0, z[0]);
         } else {
           const bool alive[1] = {i < end};
-          apply_program_lane<T, 1, false>(lat, S, g_steps, s_steps, 0, z, a.n_observers ? s_obs : nullptr, &alive);
+          apply_program_lane<T, 1, false>(lat, S, g_steps, s_steps, z, a.n_observers ? s_obs : nullptr, &alive);
         }
         if (MOM && it == 0 && u == 0) {
 #pragma unroll
@@ -1422,7 +1413,7 @@ __global__ __launch_bounds__(kTrackThreads, (XPOSE ? 3 : 1)) void k_track_direct
         bool alive[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) alive[u] = i0 + (int64_t)u * kLaneStep < end;
-        apply_program_lane<T, UNROLL, kScalarTable>(lat, S, g_steps, s_steps, a.merged_pairs, z,
+        apply_program_lane<T, UNROLL, kScalarTable>(lat, S, g_steps, s_steps, z,
                                                     a.n_observers ? s_obs : nullptr, &alive);
       }
 #pragma unroll

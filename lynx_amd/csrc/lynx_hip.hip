@@ -715,8 +715,11 @@ static TrackPlan plan_track(lynx_ctx* ctx, const lynx_lattice* lat, int64_t B, i
   const int64_t ntiles = (N + tile - 1) / tile;
   // A workgroup pays a fixed cost (table load, 29-value cross-lane reduction, partial
   // record), so it gets at least `min_tpw` tiles -- unless that would leave CUs idle.
-  // (multi-step programs also fetch S step records per iteration: longer-lived workgroups, C5: -2.5 %)
-  int64_t min_tpw = env_int("LYNX_MIN_TILES_PER_WG", S > 1 ? 8 : (sizeof(T) == 4 ? 3 : 4));
+  // Measured with the round-2 kernels (property-set moments, scripts/gpu/r2_c4sweep.sh, same box): single-map
+  // programs like many short-lived workgroups -- 2 tiles each: C4 5.26 -> 5.49 TB/s, c3big 4.83 -> 5.09 --
+  // while multi-step programs also fetch S step records per iteration and want long-lived ones (C5 with
+  // 2 / 4 / 8 / 16 tiles: 1.25 / 1.14 / 1.10 / 1.09 ms).
+  int64_t min_tpw = env_int("LYNX_MIN_TILES_PER_WG", S > 1 ? 16 : 2);
   while (min_tpw > 1 && B * ((ntiles + min_tpw - 1) / min_tpw) < 4 * cus) --min_tpw;
   int64_t chunks = std::max<int64_t>(1, std::min<int64_t>((ntiles + min_tpw - 1) / min_tpw, (target + B - 1) / B));
   int64_t tpw = (ntiles + chunks - 1) / chunks;
