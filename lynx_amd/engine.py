@@ -81,6 +81,10 @@ def partition(elements, fuse_observers: bool = False) -> list:
             state["new_run"] = True
         return out[-1]
 
+    def room_for_observer() -> bool:
+        """The program being filled reads fewer than MAX_OBSERVERS active BPMs so far (a new one reads none)."""
+        return not (out and isinstance(out[-1], Program)) or len(out[-1].observers) < _ffi.MAX_OBSERVERS
+
     def walk(items):
         for el in items:
             if isinstance(el, Segment):
@@ -96,8 +100,7 @@ def partition(elements, fuse_observers: bool = False) -> list:
             elif el._kind == _ffi.KIND_CAVITY:
                 current().add_cavity(el)
                 state["new_run"] = True
-            elif (fuse_observers and getattr(el, "_fusable_observer", False)
-                  and sum(1 for item in out[-1:] if isinstance(item, Program) for _ in item.observers) < _ffi.MAX_OBSERVERS):
+            elif fuse_observers and getattr(el, "_fusable_observer", False) and room_for_observer():
                 current().add_observer(el)
                 state["new_run"] = True
             elif getattr(el, "_host_barrier", False):
