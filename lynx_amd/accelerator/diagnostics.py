@@ -15,7 +15,6 @@ from typing import Optional
 
 import numpy as np
 
-from .. import _ffi
 from ..device import Dual, dtype_code, get_runtime
 from .element import Element
 

@@ -18,7 +18,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 from . import _ffi, config
-from .device import DeviceArray, Dual, dtype_code, get_runtime
+from .device import Dual, dtype_code, get_runtime
 
 ELECTRON_MASS_EV = 510998.95069  # cavity.py:20
 
