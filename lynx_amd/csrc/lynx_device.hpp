@@ -817,18 +817,6 @@ struct TrackArgs {
   int32_t n_observers;   // LYNX_STEP_FLAG_OBSERVE steps of the program (their sums live behind the step table in LDS)
 };
 
-// Moment reduction folded into the streaming kernel: the workgroup that arrives LAST at a group of partial
-// records (an atomic ticket per group) adds the group up, the one that arrives last at the sample's groups
-// writes the sample's record.  Who adds is decided by arrival; WHAT is added and in which order is not
-// (rows in row order from the stored records), so results stay bit-reproducible.
-struct FoldArgs {
-  double* records;        // [B][LYNX_MOMENT_STRIDE]; null: the partial records are left to k_reduce_moments
-  double* level;          // [B][groups][36] group records (groups > 1)
-  unsigned int* tickets;  // [B][groups + 1], all zero between launches (the last arrival resets what it took)
-  int32_t rows_per_group;
-  int32_t groups;
-};
-
 __device__ __forceinline__ float uniform_value(float v) {
   return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
 }
@@ -915,111 +903,6 @@ template <typename T, bool FULL> struct MomentAcc {
     products<0>(e);
   }
 };
-
-// ---------------------------------------------------------------------------------------
-// Adding up partial records in a fixed order -- no float atomics.
-//   reduce_rows (256 threads): stages up to 70 of the `n_rows` records at `src` at a time in LDS with
-//   coalesced loads; thread (q, j) (7 sets of 36 threads) moves value j of staged rows q, q + 7, ... to the
-//   reference point of the first row (moment_slot_moved) and adds them in row order, the 7 set sums are
-//   then added in set order.  Returns the sum record (in LDS, valid for all threads).
-//   Callers: the last-arriving workgroups of k_track_direct (FoldArgs), and
-//   k_reduce_moments, grid = B x groups: workgroup (b, g) owns the rows [g * rows_per_group, ...) of sample
-//   b's `rows` input records;
-//   FINAL = false: writes one record per group (same layout) -- the level of a reduction tree when a
-//                  sample has more rows than one workgroup should walk (a B = 1 beam of 8 M particles
-//                  has ~4000 of them);
-//   FINAL = true : writes the moment record of the sample (include/lynx_hip.h); groups must be 1.
-// ---------------------------------------------------------------------------------------
-constexpr int kReduceSets = 7;
-constexpr int kReduceStage = 70;  // rows staged per pass: 10 per set
-constexpr int kReduceLdsDoubles = (kReduceStage + kReduceSets + 1) * kPartialStride;
-
-__device__ __forceinline__ void write_moment_record(const double* s, double* dst, int tid) {
-  const double n = s[35];
-  if (tid < 6) {
-    dst[tid] = s[28 + tid] + s[tid] / n;
-  } else if (tid == 6) {
-    dst[6] = s[6] / n;
-  } else if (tid < 28) {
-    int k = tid - 7, i = 0, row = 6;  // upper-triangle index -> (i, j)
-    while (k >= row) { k -= row; --row; ++i; }
-    const int j = i + k;
-    // a property-set record (s[34] == 0) carries the variances, cov(x, x') and cov(y, y') only
-    const bool have = s[34] != 0.0 || i == j || (i == 0 && j == 1) || (i == 2 && j == 3);
-    dst[tid] = have ? (s[tid] - s[i] * s[j] / n) / n : __longlong_as_double(0x7ff8000000000000ll);
-  } else if (tid < 34) {
-    dst[tid] = 0.0;
-  } else if (tid == 34) {
-    dst[34] = s[34];
-  } else if (tid == 35) {
-    dst[35] = n;
-  }
-}
-
-// Device-coherent accesses for records that travel between workgroups INSIDE a launch (FoldArgs): relaxed
-// agent-scope atomics, i.e. global_store / global_load with sc1 -- written through to, and read from, the
-// level all eight L2s agree on.  What the folded reduction deliberately does NOT use is an agent-scope
-// release fence per workgroup: on gfx950 that is a write-back of the XCD's whole L2 (buffer_wbl2 sc1) and
-// made the C4 streaming kernel 13x slower (scripts/gpu/r2_gap.sh).
-__device__ __forceinline__ void store_coherent(double* p, double v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double load_coherent(const double* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// this wave's outstanding vector-memory operations (loads and stores share vmcnt on gfx9) have completed
-__device__ __forceinline__ void wait_vector_memory() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-template <bool COHERENT>
-__device__ __forceinline__ const double* reduce_rows(const double* src, int n_rows, double* lds, int tid) {
-  double* s_rows = lds;                                       // [kReduceStage][36]
-  double* s_set = lds + kReduceStage * kPartialStride;        // [kReduceSets][36]
-  double* s = s_set + kReduceSets * kPartialStride;           // [36]
-  const int q = tid / kPartialStride, j = tid - q * kPartialStride;
-  double v = 0.0;
-  for (int base = 0; base < n_rows; base += kReduceStage) {
-    const int n_stage = (n_rows - base) < kReduceStage ? (n_rows - base) : kReduceStage;
-    __syncthreads();  // the previous pass (or the caller) is done with the staging area
-    for (int i = tid; i < n_stage * kPartialStride; i += 256) {
-      const double* at = src + (int64_t)base * kPartialStride + i;
-      s_rows[i] = COHERENT ? load_coherent(at) : *at;
-    }
-    __syncthreads();
-    if (base == 0 && tid < 8) s[28 + tid] = tid < 7 ? s_rows[28 + tid] : 0.0;  // the reference point of the sum (s[35] set below)
-    __syncthreads();
-    if (q < kReduceSets && (j < 28 || j == 35)) {
-#pragma unroll 2
-      for (int r = q; r < n_stage; r += kReduceSets) v += moment_slot_moved(s_rows + r * kPartialStride, s + 28, j);
-    }
-  }
-  if (q < kReduceSets) s_set[q * kPartialStride + j] = v;
-  __syncthreads();
-  if (tid < kPartialStride && (tid < 28 || tid == 35)) {
-    double t = 0.0;
-#pragma unroll
-    for (int k = 0; k < kReduceSets; ++k) t += s_set[k * kPartialStride + tid];
-    s[tid] = t;
-  }
-  __syncthreads();
-  return s;
-}
-
-template <bool FINAL>
-__global__ __launch_bounds__(256) void k_reduce_moments(const double* __restrict__ in, int rows, int rows_per_group,
-                                                         int groups, double* __restrict__ out) {
-  __shared__ double lds[kReduceLdsDoubles];
-  const int64_t b = blockIdx.x / groups;
-  const int g = blockIdx.x % groups;
-  const int tid = threadIdx.x;
-  const int lo = g * rows_per_group;
-  const int hi = (lo + rows_per_group) < rows ? (lo + rows_per_group) : rows;
-  const double* s = reduce_rows<false>(in + (b * (int64_t)rows + lo) * kPartialStride, hi - lo, lds, tid);
-  if (FINAL) {
-    write_moment_record(s, out + b * LYNX_MOMENT_STRIDE, tid);
-  } else if (tid < kPartialStride) {
-    out[(b * (int64_t)groups + g) * kPartialStride + tid] = s[tid];
-  }
-}
 
 // ---------------------------------------------------------------------------------------
 // k_track_direct: the streaming kernel.  grid.x = B * chunks; each 256-thread workgroup owns
@@ -1348,8 +1231,8 @@ __device__ __forceinline__ void apply_program_lane(const LatticeDev& lat, int S,
 template <typename T, int MOM, bool FULL, int UNROLL, bool FUSED, bool XPOSE>
 __global__ __launch_bounds__(kTrackThreads, (XPOSE ? 3 : 1)) void k_track_direct(
     LatticeDev lat, TrackArgs a, const T* __restrict__ energy_in, const T* p_in, T* p_out,
-    T* __restrict__ energy_out, const T* __restrict__ steps_in, double* partials,
-    double* __restrict__ obs_partials, FoldArgs fold) {
+    T* __restrict__ energy_out, const T* __restrict__ steps_in, double* __restrict__ partials,
+    double* __restrict__ obs_partials) {
   static_assert(!XPOSE || (UNROLL * 7 * sizeof(T) == 112 && !FUSED), "XPOSE: a lane owns 112 bytes");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned char* s_scratch = smem_raw;                                 // build scratch / wave tiles / reduction
@@ -1619,43 +1502,89 @@ __global__ __launch_bounds__(kTrackThreads, (XPOSE ? 3 : 1)) void k_track_direct
 #pragma unroll
         for (int w = 0; w < kTrackThreads / 64; ++w) v += moment_slot_moved(s_red + w * kPartialStride, s_red + 28, tid);
       }
-      if (fold.records) store_coherent(out + tid, v);
-      else out[tid] = v;
+      out[tid] = v;
     }
-    if (fold.records) {
-      // Publication protocol (hardware level, gfx950): the record goes out with device-coherent stores;
-      // once they have completed (s_waitcnt vmcnt(0) of the storing wave, then the workgroup barrier)
-      // thread 0 takes the group's ticket with a device-scope atomic.  Whoever draws the last ticket
-      // therefore finds every record of the group complete and reads them with device-coherent loads.
-      __shared__ int s_last;
-      const int g = chunk / fold.rows_per_group;
-      const int rows_left = a.chunks - g * fold.rows_per_group;
-      const int rows_here = rows_left < fold.rows_per_group ? rows_left : fold.rows_per_group;
-      unsigned int* tickets = fold.tickets + b * (fold.groups + 1);
-      if (tid < kPartialStride) wait_vector_memory();
-      __syncthreads();
-      if (tid == 0) s_last = atomicAdd(tickets + g, 1u) == (unsigned)(rows_here - 1);
-      __syncthreads();
-      if (!s_last) return;
-      double* lds = reinterpret_cast<double*>(s_scratch);
-      const double* s = reduce_rows<true>(partials + ((int64_t)b * a.chunks + (int64_t)g * fold.rows_per_group) * kPartialStride,
-                                          rows_here, lds, tid);
-      if (tid == 0) tickets[g] = 0u;
-      if (fold.groups > 1) {
-        double* row = fold.level + ((int64_t)b * fold.groups + g) * kPartialStride;
-        if (tid < kPartialStride) {
-          store_coherent(row + tid, s[tid]);
-          wait_vector_memory();
-        }
-        __syncthreads();
-        if (tid == 0) s_last = atomicAdd(tickets + fold.groups, 1u) == (unsigned)(fold.groups - 1);
-        __syncthreads();
-        if (!s_last) return;
-        s = reduce_rows<true>(fold.level + (int64_t)b * fold.groups * kPartialStride, fold.groups, lds, tid);
-        if (tid == 0) tickets[fold.groups] = 0u;
-      }
-      write_moment_record(s, fold.records + b * LYNX_MOMENT_STRIDE, tid);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_reduce_moments: adds up partial records in a fixed order -- no float atomics.
+//   grid = B x groups, 256 threads.  Workgroup (b, g) owns the rows [g * rows_per_group, ...) of
+//   sample b's `rows` input records; it stages up to 70 rows at a time in LDS with coalesced loads,
+//   thread (q, j) (7 sets of 36 threads) moves value j of staged rows q, q + 7, ... to the reference
+//   point of the group's first row (moment_slot_moved) and adds them in row order, the 7 set sums are
+//   then added in set order.
+//   FINAL = false: writes one partial record per group (same layout) -- the level of a reduction tree
+//                  when a sample has more rows than one workgroup should walk (a B = 1 beam of 8 M
+//                  particles has ~8000 of them);
+//   FINAL = true : writes the moment record of the sample (include/lynx_hip.h); groups must be 1.
+// ---------------------------------------------------------------------------------------
+constexpr int kReduceSets = 7;
+constexpr int kReduceStage = 70;  // rows staged per pass: 10 per set
+
+__device__ __forceinline__ void write_moment_record(const double* s, double* dst, int tid) {
+  const double n = s[35];
+  if (tid < 6) {
+    dst[tid] = s[28 + tid] + s[tid] / n;
+  } else if (tid == 6) {
+    dst[6] = s[6] / n;
+  } else if (tid < 28) {
+    int k = tid - 7, i = 0, row = 6;  // upper-triangle index -> (i, j)
+    while (k >= row) { k -= row; --row; ++i; }
+    const int j = i + k;
+    // a property-set record (s[34] == 0) carries the variances, cov(x, x') and cov(y, y') only
+    const bool have = s[34] != 0.0 || i == j || (i == 0 && j == 1) || (i == 2 && j == 3);
+    dst[tid] = have ? (s[tid] - s[i] * s[j] / n) / n : __longlong_as_double(0x7ff8000000000000ll);
+  } else if (tid < 34) {
+    dst[tid] = 0.0;
+  } else if (tid == 34) {
+    dst[34] = s[34];
+  } else if (tid == 35) {
+    dst[35] = n;
+  }
+}
+
+template <bool FINAL>
+__global__ __launch_bounds__(256) void k_reduce_moments(const double* __restrict__ in, int rows, int rows_per_group,
+                                                         int groups, double* __restrict__ out) {
+  __shared__ double s_rows[kReduceStage * kPartialStride];
+  __shared__ double s_set[kReduceSets][kPartialStride];
+  __shared__ double s[kPartialStride];
+  const int64_t b = blockIdx.x / groups;
+  const int g = blockIdx.x % groups;
+  const int tid = threadIdx.x;
+  const int q = tid / kPartialStride, j = tid - q * kPartialStride;
+  const int lo = g * rows_per_group;
+  const int hi = (lo + rows_per_group) < rows ? (lo + rows_per_group) : rows;
+  const double* src = in + (b * (int64_t)rows + lo) * kPartialStride;
+  double v = 0.0;
+  double c0 = 0.0;  // thread j < 6 keeps component j of the reference point in a register too
+  for (int base = 0; base < hi - lo; base += kReduceStage) {
+    const int n_stage = (hi - lo - base) < kReduceStage ? (hi - lo - base) : kReduceStage;
+    __syncthreads();  // the previous pass is done with the staging area
+    for (int i = tid; i < n_stage * kPartialStride; i += 256) s_rows[i] = src[(int64_t)base * kPartialStride + i];
+    __syncthreads();
+    if (base == 0 && tid < 8) s[28 + tid] = tid < 7 ? s_rows[28 + tid] : 0.0;  // the group's reference point (s[35] set below)
+    __syncthreads();
+    if (q < kReduceSets && (j < 28 || j == 35)) {
+#pragma unroll 2
+      for (int r = q; r < n_stage; r += kReduceSets) v += moment_slot_moved(s_rows + r * kPartialStride, s + 28, j);
     }
+    (void)c0;
+  }
+  if (q < kReduceSets) s_set[q][j] = v;
+  __syncthreads();
+  if (tid < kPartialStride && (tid < 28 || tid == 35)) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < kReduceSets; ++k) t += s_set[k][tid];
+    s[tid] = t;
+  }
+  __syncthreads();
+  if (FINAL) {
+    write_moment_record(s, out + b * LYNX_MOMENT_STRIDE, tid);
+  } else if (tid < kPartialStride) {
+    out[(b * (int64_t)groups + g) * kPartialStride + tid] = s[tid];
   }
 }
 

@@ -52,8 +52,6 @@ struct lynx_ctx {
   size_t scratch_partials_bytes = 0;
   void* scratch_level = nullptr;  // second level of the moment reduction (long beams)
   size_t scratch_level_bytes = 0;
-  void* scratch_tickets = nullptr;  // arrival counters of the folded moment reduction (FoldArgs), zero at rest
-  size_t scratch_tickets_bytes = 0;
   void* scratch_obs = nullptr;  // per-workgroup sums of x, y at the observers [B][chunks][2 * LYNX_MAX_OBSERVERS]
   size_t scratch_obs_bytes = 0;
   void* scratch_erun = nullptr;      // k_cavity_flags: every sample's energy on its way through the cavities
@@ -233,7 +231,6 @@ int lynx_ctx_destroy(lynx_ctx* ctx) {
   for (auto& kv : ctx->live) (void)hipFree(kv.first);
   if (ctx->scratch_partials) (void)hipFree(ctx->scratch_partials);
   if (ctx->scratch_level) (void)hipFree(ctx->scratch_level);
-  if (ctx->scratch_tickets) (void)hipFree(ctx->scratch_tickets);
   if (ctx->scratch_obs) (void)hipFree(ctx->scratch_obs);
   if (ctx->scratch_erun) (void)hipFree(ctx->scratch_erun);
   if (ctx->scratch_products) (void)hipFree(ctx->scratch_products);
@@ -682,7 +679,6 @@ struct TrackPlan {
   int mom_mode;  // 1 = float64 per particle, 2 = float32 partial sums per iteration, 3 = float32 lane sums
   bool xpose;    // wave tiles through LDS (full-width accesses) instead of per-particle accesses
   TrackArgs a;
-  FoldArgs fold;  // records == nullptr: the reduction runs as launches of its own
   size_t lds;
   unsigned grid;
 };
@@ -736,7 +732,6 @@ static TrackPlan plan_track(lynx_ctx* ctx, const lynx_lattice* lat, int64_t B, i
   size_t scratch = 4 * kPartialStride * sizeof(double);
   if (moments)
     scratch = std::max<size_t>(scratch, (size_t)(full_cov ? kMomSlabScalars : kMomSlabScalarsCompact) * (p.mom_mode >= 2 ? 4 : 8));
-  if (moments) scratch = std::max<size_t>(scratch, (size_t)kReduceLdsDoubles * sizeof(double));  // a last arrival adds records up
   if (p.xpose) scratch = std::max<size_t>(scratch, (size_t)(kTrackThreads / 64) * kWaveTileBytes);
   if (p.a.fused_build) {
     p.a.build_chunk = build_chunk(lat->n_elems, sizeof(T) == 4 ? 32 : 64);
@@ -747,7 +742,6 @@ static TrackPlan plan_track(lynx_ctx* ctx, const lynx_lattice* lat, int64_t B, i
   p.a.n_observers = lat ? lat->n_observers : 0;
   p.lds = (scratch + ((size_t)S * LYNX_STEP_STRIDE + S + 1) * sizeof(T) + 7) / 8 * 8 + (size_t)2 * p.a.n_observers * 256 * sizeof(double);
   p.grid = (unsigned)(B * chunks);
-  p.fold = FoldArgs{nullptr, nullptr, nullptr, 1, 1};
   return p;
 }
 
@@ -768,7 +762,7 @@ static int launch_direct_inst(lynx_ctx* ctx, const TrackPlan& p, const LatticeDe
   }
   hipExtLaunchKernelGGL((k_track_direct<T, MOM, FULL, UNROLL, FUSED, XPOSE>), dim3(p.grid), dim3(kTrackThreads),
                         (std::uint32_t)p.lds, ctx->stream, e0, e1, 0u, lv, p.a, (const T*)d_energy_in, (const T*)d_p_in,
-                        (T*)d_p_out, (T*)d_energy_out, (const T*)d_steps, d_partials, d_obs, p.fold);
+                        (T*)d_p_out, (T*)d_energy_out, (const T*)d_steps, d_partials, d_obs);
   HIP_TRY(ctx, hipGetLastError());
   if (ctx->profiling) ctx->prof_events.emplace_back(e0, e1);
   ctx->last_stream_stop = e1;  // what "this streaming kernel has finished" is, for the build stream
@@ -891,25 +885,6 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
     if ((rc = ensure_scratch(ctx, &ctx->scratch_obs, &ctx->scratch_obs_bytes, need))) return rc;
     d_obs = (double*)ctx->scratch_obs;
   }
-  // The moment reduction: folded into the streaming kernel (its last-arriving workgroups add the partial
-  // records up: no launch of its own between two streaming kernels), or LYNX_FOLD_REDUCE=0: one or two
-  // launches of k_reduce_moments.  Up to 70 rows in one go, otherwise a level of <= 64 groups in between
-  // (rows_per_group grows with the beam, the walk stays short).
-  const int rows = p.a.chunks;
-  const int rpg = rows > kReduceStage ? (rows + 63) / 64 : rows;
-  const int groups = (rows + rpg - 1) / rpg;
-  const bool fold = moments && env_int("LYNX_FOLD_REDUCE", 1) != 0;
-  if (moments && groups > 1) {
-    const size_t need = (size_t)B * groups * kPartialStride * sizeof(double);
-    if ((rc = ensure_scratch(ctx, &ctx->scratch_level, &ctx->scratch_level_bytes, need))) return rc;
-  }
-  if (fold) {
-    const void* before = ctx->scratch_tickets;
-    if ((rc = ensure_scratch(ctx, &ctx->scratch_tickets, &ctx->scratch_tickets_bytes, (size_t)B * (groups + 1) * sizeof(unsigned int)))) return rc;
-    if (ctx->scratch_tickets != before)
-      HIP_TRY(ctx, hipMemsetAsync(ctx->scratch_tickets, 0, ctx->scratch_tickets_bytes, ctx->stream));
-    p.fold = FoldArgs{d_moments_out, (double*)ctx->scratch_level, (unsigned int*)ctx->scratch_tickets, rpg, groups};
-  }
   p.done = (slot >= 0) ? ctx->ev_streamed_own[slot] : nullptr;
   rc = launch_direct<T>(ctx, p, lv, d_energy_in, d_p_in, d_p_out, d_energy_out, d_steps, d_partials, d_obs, moments);
   if (rc) return rc;
@@ -923,16 +898,24 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
     ctx->streamed_valid[slot] = true;
   }
   if (d_energy_out) ctx->main_wrote = d_energy_out;  // a later build that reads it must wait for this kernel
-  if (moments && !fold) {
+  if (moments) {
+    // records of the workgroups -> record of the sample: one pass for up to 70 rows, otherwise a level of
+    // <= 64 groups in between (rows_per_group grows with the beam, the walk stays short)
+    int rows = p.a.chunks;
     const double* level_in = d_partials;
-    if (groups > 1) {
+    if (rows > kReduceStage) {
+      const int rpg = (rows + 63) / 64;
+      const int groups = (rows + rpg - 1) / rpg;
+      const size_t need = (size_t)B * groups * kPartialStride * sizeof(double);
+      if ((rc = ensure_scratch(ctx, &ctx->scratch_level, &ctx->scratch_level_bytes, need))) return rc;
       hipLaunchKernelGGL(k_reduce_moments<false>, dim3((unsigned)(B * groups)), dim3(256), 0, ctx->stream, level_in, rows,
                          rpg, groups, (double*)ctx->scratch_level);
       HIP_TRY(ctx, hipGetLastError());
       level_in = (const double*)ctx->scratch_level;
+      rows = groups;
     }
-    hipLaunchKernelGGL(k_reduce_moments<true>, dim3((unsigned)B), dim3(256), 0, ctx->stream, level_in, groups > 1 ? groups : rows,
-                       groups > 1 ? groups : rows, 1, d_moments_out);
+    hipLaunchKernelGGL(k_reduce_moments<true>, dim3((unsigned)B), dim3(256), 0, ctx->stream, level_in, rows, rows, 1,
+                       d_moments_out);
     HIP_TRY(ctx, hipGetLastError());
   }
   return LYNX_OK;

@@ -3,9 +3,8 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/r2gap; rm -rf $OUT; mkdir -p $OUT
 timeout -k 10 600 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; echo "pytest rc $?"; tail -2 $OUT/pytest.log
-# LYNX_FOLD_REDUCE=0: the moment reduction as launches of its own (the form before it was folded into the streaming kernel)
-for i in 1 2 3; do for f in 1 0; do LYNX_FOLD_REDUCE=$f timeout -k 10 180 python bench.py --workload c4 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/c4_fold${f}_$i.json 2> $OUT/c4_fold${f}_$i.err; done; done
-for w in c3 c2 c3big c5; do for f in 1 0; do LYNX_FOLD_REDUCE=$f timeout -k 10 180 python bench.py --workload $w --steps 100 --warmup 5 --no-cpu-baseline > $OUT/${w}_fold$f.json 2> $OUT/${w}_fold$f.err; done; done
+for i in 1 2 3; do timeout -k 10 180 python bench.py --workload c4 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/c4_$i.json 2> $OUT/c4_$i.err; done
+for w in c3 c2 c3big c5; do timeout -k 10 180 python bench.py --workload $w --steps 100 --warmup 5 --no-cpu-baseline > $OUT/$w.json 2> $OUT/$w.err; done
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 bench.py --workload c4 --steps 6 --warmup 2 --no-cpu-baseline > $OUT/trace.json 2> $OUT/trace.err
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace3 -- python3 bench.py --workload c3 --steps 6 --warmup 2 --no-cpu-baseline > $OUT/trace3.json 2> $OUT/trace3.err
 python3 - <<'PY'
