@@ -30,10 +30,20 @@ namespace lynx {
 constexpr int kGradStride = 64;   // per (sample, step): 49 T_bar + 8 coef_bar + padding
 constexpr int kGradParams = 8;    // gradient slots per element (kinds with <= 8 parameters)
 
+constexpr int kBwdGroup = 4;
+constexpr int kBwdMaxGroups = 16;  // => at most 64 units
+
+// The sweeps of k_track_bwd walk UNITS: a step of the program, or (float32 packed pairs) a [run, cavity]
+// pair in the merged form the forward kernel uses (one 7x7 application instead of two, see k_build).
 struct BwdArgs {
   int64_t n_particles;
   int32_t chunks;
   int32_t tiles_per_wg;  // tiles of 256 particles
+  int32_t n_units;
+  // table slot of each unit's map; a merged pair: the cavity's slot (T_cav . T_run + coefficients), the
+  // run's slot in front of it holds the two rows that give the s and delta entering the cavity and
+  // carries LYNX_DESC_PAIR in its descriptor
+  unsigned char unit_slot[kBwdGroup * kBwdMaxGroups];
 };
 
 // ---------------------------------------------------------------------------------------
@@ -52,12 +62,11 @@ struct BwdArgs {
 //
 // LDS: exchange [4][21][ExGeom::kPitch] T | accumulators [4][S][64] T
 // ---------------------------------------------------------------------------------------
-constexpr int kBwdGroup = 4;
-constexpr int kBwdMaxGroups = 16;  // => at most 64 steps
-// Rows of the exchange buffer: 14 (o_lin, z_in), or 21 when the first 7 cavity-coefficient
-// cotangents also travel through it (summed by the otherwise idle lanes 56..63).  Packed pairs
-// double the row length; with 21 rows only two workgroups fit a CU, with 14 three.
-template <int W> struct ExRows { static constexpr int value = W == 1 ? 21 : 14; };
+// Rows of the exchange buffer: 14 (o_lin, z_in) + 1 (packed pairs: the cotangent of the s that enters a
+// merged pair's cavity), or 21 when the first 7 cavity-coefficient cotangents also travel through it
+// (summed by the otherwise idle lanes 56..63).  Packed pairs double the row length; with 21 rows only
+// two workgroups fit a CU, with 15 three.
+template <int W> struct ExRows { static constexpr int value = W == 1 ? 21 : 15; };
 
 // LDS hand-over inside one wave: make this wave's LDS writes visible to its own later reads
 // (and keep the compiler from moving accesses across); no workgroup barrier is involved.
@@ -119,6 +128,12 @@ __device__ __forceinline__ void load_step_map(const T* g_steps, int s, T (&m)[57
   for (int q = 0; q < 57; ++q) m[q] = g_steps[s * LYNX_STEP_STRIDE + q];  // wave-uniform: scalar loads
 }
 
+// does the unit whose map sits in `slot` apply a [run, cavity] pair in merged form?  (wave-uniform)
+template <typename T>
+__device__ __forceinline__ bool unit_is_pair(const T* g_steps, int slot) {
+  return slot > 0 && (((int)uniform_value(g_steps[(slot - 1) * LYNX_STEP_STRIDE + LYNX_FLAGS_OFFSET])) & LYNX_DESC_PAIR) != 0;
+}
+
 // ---- lane values: one particle per lane (float64) or two as a packed pair (float32) -----
 // The reverse sweep is VALU-bound; with two float32 particles per lane every multiply-add of
 // the step applications, of T^T z_bar and of the exchange products is one v_pk_fma_f32 for
@@ -150,6 +165,29 @@ __device__ __forceinline__ void zapply(const float* m, int kind, int flags, floa
 __device__ __forceinline__ void zapply(const double* m, int kind, int flags, double (&z)[7]) { apply_step<double>(m, kind, flags, z); }
 __device__ __forceinline__ void zapply(const float* m, int kind, int flags, lynx_f32x2 (&z)[7]) { apply_step_pair(m, kind, flags, z); }
 
+// one unit of the forward / recompute sweeps
+template <typename T, typename Z>
+__device__ __forceinline__ void apply_unit(const T* g_steps, int slot, Z (&z)[7]) {
+  const lynx_step st = table_step<T>(g_steps, slot);
+  if constexpr (LaneOf<Z>::W == 2) {
+    if (unit_is_pair<T>(g_steps, slot)) {  // uniform
+      float pre[14];
+#pragma unroll
+      for (int q = 0; q < 14; ++q) pre[q] = g_steps[(slot - 1) * LYNX_STEP_STRIDE + q];
+      lynx_f32x2 s_entry, d_entry;
+      merged_pair_entry(pre, z, s_entry, d_entry);
+      LYNX_FORGET();  // the 14 scalars are dead before the 57 of the pair's map arrive
+      T m[57];
+      load_step_map<T>(g_steps, slot, m);
+      apply_step_pair(m, st.kind, st.flags, z, true, s_entry, d_entry);
+      return;
+    }
+  }
+  T m[57];
+  load_step_map<T>(g_steps, slot, m);
+  zapply(m, st.kind, st.flags, z);
+}
+
 // Exchange-buffer geometry: a row holds the 64 W values of one quantity; lane (i, kb) works on
 // the 16-byte pieces l * 32 + kb * 4 (in scalars of 4 bytes; 8-byte scalars: l * 16 + kb * 2)
 // of its rows, so that the 8 lanes of one row group read 128 consecutive bytes per access.
@@ -172,7 +210,8 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
   using V = typename VecOf<T, true>::type;  // 16-byte LDS accesses
   constexpr int VW = Geo::kVW, P = Geo::kPitch;
   const int S = lat.n_steps;
-  const int G = (S + K - 1) / K;
+  const int U = a.n_units;
+  const int G = (U + K - 1) / K;
   constexpr int kExRows = ExRows<W>::value;
   constexpr bool kCoefRows = kExRows == 21;
   T* s_ex = reinterpret_cast<T*>(smem_raw);                  // [4][kExRows][P]
@@ -208,16 +247,13 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
       for (int c = 0; c < 7; ++c) zset(z[c], w, zw[c]);
     }
 
-    // forward sweep, parking the state that enters every K-th step
-    for (int s = 0; s < S; ++s) {
-      const lynx_step st = table_step<T>(g_steps, s);
-      T m[57];
-      load_step_map<T>(g_steps, s, m);
-      if (s % K == 0) {
+    // forward sweep, parking the state that enters every K-th unit
+    for (int u = 0; u < U; ++u) {
+      if (u % K == 0) {
 #pragma unroll
-        for (int c = 0; c < 7; ++c) stack[(s / K) * 7 + c] = z[c];
+        for (int c = 0; c < 7; ++c) stack[(u / K) * 7 + c] = z[c];
       }
-      zapply(m, st.kind, st.flags, z);
+      apply_unit<T, Z>(g_steps, a.unit_slot[u], z);
     }
 
     // cotangent of the outgoing particle: (1/N) (mu_bar + G_hat (z - mean)), G_hat built from
@@ -248,29 +284,23 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
     }
 
     for (int grp = G - 1; grp >= 0; --grp) {
-      // states entering steps grp*K .. grp*K + K-1
+      // states entering units grp*K .. grp*K + K-1
       Z zz[K][7];
 #pragma unroll
       for (int c = 0; c < 7; ++c) zz[0][c] = stack[grp * 7 + c];
 #pragma unroll
       for (int j = 1; j < K; ++j) {
-        const int sp = grp * K + j - 1;  // step that produces zz[j]
+        const int up = grp * K + j - 1;  // unit that produces zz[j]
 #pragma unroll
         for (int c = 0; c < 7; ++c) zz[j][c] = zz[j - 1][c];
-        if (sp + 1 < S) {
-          const lynx_step st = table_step<T>(g_steps, sp);
-          T m[57];
-          load_step_map<T>(g_steps, sp, m);
-          zapply(m, st.kind, st.flags, zz[j]);
-        }
+        if (up + 1 < U) apply_unit<T, Z>(g_steps, a.unit_slot[up], zz[j]);
       }
 
       for (int j = K - 1; j >= 0; --j) {
-        const int s = grp * K + j;
-        if (s >= S) continue;  // uniform
+        const int u = grp * K + j;
+        if (u >= U) continue;  // uniform
+        const int s = a.unit_slot[u];
         const lynx_step st = table_step<T>(g_steps, s);
-        T m[57];
-        load_step_map<T>(g_steps, s, m);
         Z zin[7];
 #pragma unroll
         for (int c = 0; c < 7; ++c) {
@@ -279,15 +309,32 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
           for (int q = 1; q < K; ++q) v = (j == q) ? zz[q][c] : v;
           zin[c] = v;
         }
+        // what drives the cavity's kick: s and delta of the unit's incoming state, or -- merged pair --
+        // of the state behind the pair's run: the two entry rows (run's slot) applied to z_in
+        bool paired = false;
+        Z s_in = zin[4], d_in = zin[5];
+        if constexpr (W == 2) {
+          if (unit_is_pair<T>(g_steps, s)) {  // uniform
+            paired = true;
+            float pre[14];
+#pragma unroll
+            for (int q = 0; q < 14; ++q) pre[q] = g_steps[(s - 1) * LYNX_STEP_STRIDE + q];
+            merged_pair_entry(pre, zin, s_in, d_in);
+            LYNX_FORGET();
+          }
+        }
+        T m[57];
+        load_step_map<T>(g_steps, s, m);
 
         const bool kick = st.kind == LYNX_STEP_CAVITY && (st.flags & LYNX_FLAG_CAV_GAIN);
+        const bool entry_rows = paired && kick;  // cotangents of the two entry rows are due
         Z olin[7], cc[8], dir4 = Z(T(0)), dir5 = Z(T(0));
 #pragma unroll
         for (int c = 0; c < 7; ++c) olin[c] = zb[c];
         if (kick) {
           // o5' = z5 c0 + c1 (cos(a) - c4), a = -z4 c2 + c3 ; o4' = o4 + c5 z5^2 + c6 z4 z5 + c7 z4^2
           const T* cf = m + LYNX_COEF_OFFSET;
-          const Z z4 = zin[4], z5 = zin[5], o4b = zb[4], o5b = zb[5];
+          const Z z4 = s_in, z5 = d_in, o4b = zb[4], o5b = zb[5];
           const Z arg = T(-1) * z4 * cf[LYNX_C_BK] + cf[LYNX_C_PHI];
           Z ca, sa;
           zsincos(arg, sa, ca);
@@ -314,11 +361,16 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
         // lane-per-output mapping.  The 8 lanes with i = 7 run the same instructions on ones
         // against rows 14..20, which sums 7 of the 8 coefficient cotangents for free; the 8th
         // takes one DPP wave sum.
+        //
+        // Merged pair with a kick: o_lin[5] is zero (the linear delta was overwritten), so row 5 carries the
+        // cotangent of the delta that ENTERS the cavity instead and the idle lanes 56..63 take the one of
+        // s from row 14: their sums against z_in are the cotangents of the run slot's two entry rows.
         Z* exz = reinterpret_cast<Z*>(ex);
 #pragma unroll
-        for (int c = 0; c < 7; ++c) exz[(c * P) / W + lane] = olin[c];
+        for (int c = 0; c < 7; ++c) exz[(c * P) / W + lane] = (c == 5 && entry_rows) ? dir5 : olin[c];
 #pragma unroll
         for (int c = 0; c < 7; ++c) exz[((7 + c) * P) / W + lane] = zin[c];
+        if (W == 2 && entry_rows) exz[(14 * P) / W + lane] = dir4;
         if (kCoefRows && kick) {
 #pragma unroll
           for (int c = 0; c < 7; ++c) exz[((14 + c) * P) / W + lane] = cc[c];
@@ -328,7 +380,8 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
           constexpr int NP = Geo::kPieces;
           const int oi = lane >> 3, kb = lane & 7;
           const bool coef_lane = kCoefRows && oi == 7;
-          const T* arow = ex + (coef_lane ? 0 : oi) * P + kb * VW;
+          const bool entry_lane = W == 2 && entry_rows && oi == 7;
+          const T* arow = ex + (coef_lane ? 0 : (entry_lane ? 14 : oi)) * P + kb * VW;
           const T* rows = ex + (coef_lane ? 14 : 7) * P + kb * VW;
           V av[NP];
 #pragma unroll
@@ -354,8 +407,16 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
             const T total = sum_over_8_lanes(folded);
             mine = (kb == j) ? total : mine;
           }
-          if (kb < 7 && oi < (kCoefRows ? 8 : 7) && (!coef_lane || kick))
-            acc[s * 64 + (coef_lane ? 49 : oi * 7) + kb] += mine;
+          if (kb < 7) {
+            if (coef_lane) {
+              if (kick) acc[s * 64 + 49 + kb] += mine;
+            } else if (entry_lane) {
+              acc[(s - 1) * 64 + kb] += mine;      // run slot, row of s
+            } else if (oi < 7) {
+              if (entry_rows && oi == 5) acc[(s - 1) * 64 + 7 + kb] += mine;  // run slot, row of delta
+              else acc[s * 64 + oi * 7 + kb] += mine;
+            }
+          }
           if (kick) {
             // coefficient cotangents that did not travel through the buffer: DPP wave sums
             T rest = T(0);
@@ -377,8 +438,19 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
           for (int r = 1; r < 7; ++r) v = zfma(olin[r], m[r * 7 + jj], v);
           zb[jj] = v;
         }
-        zb[4] += dir4;
-        zb[5] += dir5;
+        if (!paired) {
+          zb[4] += dir4;
+          zb[5] += dir5;
+        } else if (kick) {
+          if constexpr (W == 2) {  // through the two entry rows back to the unit's incoming state
+            LYNX_FORGET();
+            float pre[14];
+#pragma unroll
+            for (int q = 0; q < 14; ++q) pre[q] = g_steps[(s - 1) * LYNX_STEP_STRIDE + q];
+#pragma unroll
+            for (int jj = 0; jj < 7; ++jj) zb[jj] = zfma(dir5, pre[7 + jj], zfma(dir4, pre[jj], zb[jj]));
+          }
+        }
       }
     }
     // what is left after the last (= first) step is dL/d(incoming particle)
@@ -575,9 +647,9 @@ __global__ __launch_bounds__(64) void k_reduce_tbar(const T* __restrict__ partia
 // ---------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_build_bwd(LatticeDev lat, const T* __restrict__ energy_in,
-                                                    const T* __restrict__ tbar, T* __restrict__ scratch,
+                                                    T* tbar, T* __restrict__ scratch,
                                                     T* __restrict__ grad_params /* [B][E][8] */,
-                                                    T* __restrict__ grad_energy /* [B] */) {
+                                                    T* __restrict__ grad_energy /* [B] */, int merged_pairs) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int E = lat.n_elems, S = lat.n_steps;
   T* s_energy = reinterpret_cast<T*>(smem_raw);  // [S+1]
@@ -641,7 +713,35 @@ __global__ __launch_bounds__(256) void k_build_bwd(LatticeDev lat, const T* __re
       __threadfence_block();
       __syncthreads();
     }
-    if (tid < 49) s_a[tid] = tb[tid];
+    if (merged_pairs && s + 1 < S && steps_pair_up(st, lat.steps[s + 1])) {  // uniform
+      // k_track_bwd walked this run and the cavity behind it as ONE unit, M = T_cav . T_run, with the kick
+      // driven by rows 4 and 5 of T_run: slot s + 1 holds M_bar, this slot the cotangents of those two rows.
+      //   T_run_bar = T_cav^T M_bar (+ the two rows),   T_cav_bar = M_bar T_run^T  (parked for the next round)
+      T* mbar = tbar + (b * S + s + 1) * (int64_t)kGradStride;
+      const T* Tc = g_maps + (int64_t)lat.steps[s + 1].first * 49;
+      const T* Tr = g_pref + (int64_t)(st.last + s) * 49;
+      T run_bar = T(0), cav_bar = T(0);
+      if (tid < 49) {
+        const int i = tid / 7, j = tid - i * 7;
+        run_bar = Tc[i] * mbar[j];
+        cav_bar = mbar[i * 7] * Tr[j * 7];
+#pragma unroll
+        for (int k = 1; k < 7; ++k) {
+          run_bar = t_fma(Tc[k * 7 + i], mbar[k * 7 + j], run_bar);
+          cav_bar = t_fma(mbar[i * 7 + k], Tr[j * 7 + k], cav_bar);
+        }
+        if (i == 4) run_bar += tb[j];
+        if (i == 5) run_bar += tb[7 + j];
+      }
+      __syncthreads();  // every entry of M_bar has been read
+      if (tid < 49) {
+        s_a[tid] = run_bar;
+        mbar[tid] = cav_bar;
+      }
+      __threadfence_block();
+    } else if (tid < 49) {
+      s_a[tid] = tb[tid];
+    }
     __syncthreads();
     for (int e = st.last - 1; e >= st.first; --e) {
       // M_bar_e = A . P_{e-1}^T ;  A <- M_e^T . A

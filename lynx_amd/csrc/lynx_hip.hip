@@ -949,28 +949,42 @@ static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const v
   const int64_t B = lat->batch;
   const int32_t S = lat->n_steps, E = lat->n_elems;
   int rc;
-  // forward step tables
+  // forward step tables; packed float32 pairs walk [run, cavity] pairs in the merged form of the forward
+  // kernel (LYNX_BWD_MERGE=0: every step on its own), k_build_bwd takes the cotangents apart again
+  constexpr int W = LaneOf<Z>::W;
+  BwdArgs a;
+  int merged = 0;
+  if (W == 2 && env_int("LYNX_BWD_MERGE", 1))
+    for (int32_t s = 1; s < S; ++s)
+      merged |= lat->h_steps[s].kind == LYNX_STEP_CAVITY && lat->h_steps[s - 1].kind == LYNX_STEP_RUN &&
+                !(lat->h_steps[s - 1].flags & LYNX_STEP_FLAG_OBSERVE);
+  a.n_units = 0;
+  for (int32_t s = 0; s < S; ++s) {
+    const bool pair = merged && s + 1 < S && lat->h_steps[s].kind == LYNX_STEP_RUN &&
+                      lat->h_steps[s + 1].kind == LYNX_STEP_CAVITY && !(lat->h_steps[s].flags & LYNX_STEP_FLAG_OBSERVE);
+    if (pair) ++s;
+    if (a.n_units >= kBwdGroup * kBwdMaxGroups || s > 255)
+      return fail(ctx, LYNX_ERR_INVALID,
+                  "lynx_track_particles_backward: " + std::to_string(S) + " steps; this version parks at most " +
+                      std::to_string(kBwdGroup * kBwdMaxGroups) + " (merge skippable elements or split the lattice)");
+    a.unit_slot[a.n_units++] = (unsigned char)s;
+  }
+  for (int u = a.n_units; u < kBwdGroup * kBwdMaxGroups; ++u) a.unit_slot[u] = 0;
   const size_t steps_bytes = (size_t)B * S * LYNX_STEP_STRIDE * sizeof(T);
   if ((rc = ensure_scratch(ctx, &ctx->scratch_steps[2], &ctx->scratch_steps_bytes[2], steps_bytes))) return rc;
-  if ((rc = launch_build<T>(ctx, lat, ctx->stream, d_energy_in, ctx->scratch_steps[2], nullptr))) return rc;
+  if ((rc = launch_build<T>(ctx, lat, ctx->stream, d_energy_in, ctx->scratch_steps[2], nullptr, merged))) return rc;
   ctx->main_dirty = true;
 
   // Z: what a lane carries -- one particle, or (float32) two as a packed pair
-  constexpr int W = LaneOf<Z>::W;
   using Geo = ExGeom<T, W>;
   const int64_t cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
   const int64_t ntiles = (N + kTrackThreads * W - 1) / (kTrackThreads * W);
   int64_t chunks = std::max<int64_t>(1, std::min<int64_t>(ntiles, ((int64_t)env_int("LYNX_BWD_WGS_PER_CU", 24) * cus + B - 1) / B));
   const int64_t tpw = (ntiles + chunks - 1) / chunks;
   chunks = (ntiles + tpw - 1) / tpw;
-  BwdArgs a;
   a.n_particles = N;
   a.chunks = (int32_t)chunks;
   a.tiles_per_wg = (int32_t)tpw;
-  if (S > kBwdGroup * kBwdMaxGroups)
-    return fail(ctx, LYNX_ERR_INVALID,
-                "lynx_track_particles_backward: " + std::to_string(S) + " steps; this version parks at most " +
-                    std::to_string(kBwdGroup * kBwdMaxGroups) + " (merge skippable elements or split the lattice)");
   const size_t lds = ((size_t)4 * ExRows<W>::value * Geo::kPitch + (size_t)4 * S * 64) * sizeof(T);
   if (lds > 160 * 1024) return fail(ctx, LYNX_ERR_INVALID, "lynx_track_particles_backward: LDS budget exceeded");
   if ((rc = allow_lds(ctx, k_track_bwd<T, Z>, lds))) return rc;
@@ -995,7 +1009,7 @@ static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const v
   if ((rc = allow_lds(ctx, k_build_bwd<T>, lds2))) return rc;
   HIP_TRY(ctx, hipMemsetAsync(d_grad_params, 0, (size_t)B * E * kGradParams * sizeof(T), ctx->stream));
   hipLaunchKernelGGL(k_build_bwd<T>, dim3((unsigned)B), dim3(256), lds2, ctx->stream, lv, (const T*)d_energy_in,
-                     (const T*)ctx->scratch_grad[1], (T*)ctx->scratch_grad[2], (T*)d_grad_params, (T*)d_grad_energy_in);
+                     (T*)ctx->scratch_grad[1], (T*)ctx->scratch_grad[2], (T*)d_grad_params, (T*)d_grad_energy_in, merged);
   HIP_TRY(ctx, hipGetLastError());
   return LYNX_OK;
 }
@@ -1044,7 +1058,7 @@ static int moments_backward_t(lynx_ctx* ctx, lynx_lattice* lat, const void* d_en
   if ((rc = allow_lds(ctx, k_build_bwd<T>, lds2))) return rc;
   HIP_TRY(ctx, hipMemsetAsync(d_grad_params, 0, (size_t)B * E * kGradParams * sizeof(T), ctx->stream));
   hipLaunchKernelGGL(k_build_bwd<T>, dim3((unsigned)B), dim3(256), lds2, ctx->stream, lv, (const T*)d_energy_in,
-                     (const T*)ctx->scratch_grad[1], (T*)ctx->scratch_grad[2], (T*)d_grad_params, (T*)d_grad_energy_in);
+                     (T*)ctx->scratch_grad[1], (T*)ctx->scratch_grad[2], (T*)d_grad_params, (T*)d_grad_energy_in, 0);
   HIP_TRY(ctx, hipGetLastError());
   return LYNX_OK;
 }

@@ -102,6 +102,48 @@ def test_gradients_match_finite_differences_fp64(lx):
     assert checked > 50
 
 
+@pytest.mark.parametrize("B,N", [(2, 3000), (300, 256)], ids=["workgroup-build", "lanes-build"])
+def test_merged_pairs_reverse_pass_fp32(lx, monkeypatch, B, N):
+    """
+    float32 reverse pass over [run, cavity] pairs in the merged form of the forward kernel (one 7x7 application
+    per pair, kick driven by two entry rows; k_build_bwd takes M_bar apart into T_run_bar and T_cav_bar):
+    every parameter gradient against (a) the step-by-step float32 reverse pass (LYNX_BWD_MERGE=0) and (b) the
+    float64 reverse pass, which the test above pins to finite differences of the oracle.
+    """
+    rng = np.random.default_rng(42)
+    desc = _desc(B, rng)
+    P = o.gaussian_particles((B,), N, seed=9, dtype=np.float64, sigma=[1e-3, 1e-4, 1e-3, 1e-4, 1e-3, 1e-3],
+                             mu=[1e-3, -1e-4, 5e-4, 2e-4, 1e-4, 1e-3])
+    energy = rng.uniform(6e6, 8e6, B)
+    w_mu = rng.normal(size=(B, 6))
+    w_cov = rng.normal(size=(B, 6, 6)) * 1e3
+
+    def gradients(dtype):
+        elements, _ = make_lattice(desc, dtype, lx)
+        g = lx.grad.track_vjp(lx.Segment(elements), lx.ParticleBeam(P.astype(dtype), energy.astype(dtype), dtype=dtype))(
+            mu_bar=w_mu, cov_bar=w_cov)
+        out = {(e, name): np.asarray(g[elements[e]][name], dtype=np.float64)
+               for e, (kind, _) in enumerate(desc) for name in PARAMS_TO_CHECK.get(kind, [])
+               if getattr(elements[e], name, None) is not None}
+        out["energy"] = np.asarray(g.energy, dtype=np.float64)
+        return out
+
+    g64 = gradients(np.float64)
+    merged = gradients(np.float32)
+    monkeypatch.setenv("LYNX_BWD_MERGE", "0")
+    stepwise = gradients(np.float32)
+    monkeypatch.delenv("LYNX_BWD_MERGE")
+    assert sum(v.size for v in g64.values()) > 50
+    for key, ref in g64.items():
+        floor = 1e-4 * max(np.max(np.abs(ref)), 1e-9 * np.max(np.abs(w_cov)))
+        for name, got in (("merged", merged[key]), ("stepwise", stepwise[key])):
+            assert got.shape == ref.shape
+            assert np.all(np.abs(got - ref) <= 3e-3 * np.abs(ref) + floor), (name, key, got, ref)
+        assert np.all(np.abs(merged[key] - stepwise[key]) <= 1e-3 * np.abs(ref) + floor), (key, merged[key], stepwise[key])
+    # the two float32 passes are different computations (they round differently): the switch did switch
+    assert any(np.any(merged[key] != stepwise[key]) for key in g64)
+
+
 def test_gradient_of_linear_lattice_and_broadcast_parameters(lx):
     """All-skippable lattice (one composed map), fp32; a parameter shared by the whole batch
     receives the sum of the per-sample gradients."""
