@@ -654,10 +654,45 @@ __device__ __forceinline__ void phase_sincos(lynx_f32x2 x, lynx_f32x2& s, lynx_f
   s = lynx_f32x2{s0, s1};
   c = lynx_f32x2{c0, c1};
 }
-template <typename V> __device__ __forceinline__ V phase_cos(V x) {
-  V s, c;
-  phase_sincos(x, s, c);
-  return c;
+// The forward kernels need the cosine alone: one polynomial on [-pi/2, pi/2] (cos r = 1 - z/2 + z^2 q(z),
+// z = r^2; |error| <= 7.5e-8, i.e. what rounding the result to float costs anyway) and the sign of the
+// half-period, instead of both quadrant polynomials and a select -- 23 instead of 40 instructions per pair
+// of particles in the cavity step.
+template <typename V>
+__device__ __forceinline__ V cos_half_period(V x, V& n) {
+  n = vrint(x * 0.31830987334251404f);
+  V r = vfma(n, V(-3.1415927410125732f), x);
+  r = vfma(n, V(8.742277657347586e-08f), r);
+  r = vfma(n, V(3.4302490200117637e-15f), r);
+  const V z = r * r;
+  V q = vfma(z, V(-2.654408035596134e-07f), V(2.478602073097136e-05f));
+  q = vfma(q, z, V(-0.0013888812391087413f));
+  q = vfma(q, z, V(0.0416666679084301f));
+  return vfma(q * z, z, vfma(z, V(-0.5f), V(1.0f)));
+}
+__device__ __forceinline__ float negate_if_odd(float c, float n) {
+  return __int_as_float(__float_as_int(c) ^ ((int)n << 31));
+}
+__device__ __forceinline__ float phase_cos(float x) {
+  if (__builtin_expect(!(__builtin_fabsf(x) <= kFastTrigLimit), 0)) return t_cos(x);
+  float n;
+  const float c = cos_half_period<float>(x, n);
+  return negate_if_odd(c, n);
+}
+__device__ __forceinline__ double phase_cos(double x) { return t_cos(x); }
+__device__ __forceinline__ lynx_f32x2 phase_cos(lynx_f32x2 x) {
+  const float big = __builtin_fmaxf(__builtin_fabsf(x.x), __builtin_fabsf(x.y));
+  lynx_f32x2 out;
+  if (__builtin_expect(!(big <= kFastTrigLimit), 0)) {
+    out.x = phase_cos(x.x);
+    out.y = phase_cos(x.y);
+  } else {
+    lynx_f32x2 n;
+    const lynx_f32x2 c = cos_half_period<lynx_f32x2>(x, n);
+    out.x = negate_if_odd(c.x, n.x);
+    out.y = negate_if_odd(c.y, n.y);
+  }
+  return out;
 }
 
 // Non-linear cavity step on the device: the expression of cavity_kick<T> (lynx_maps.hpp, the
@@ -665,7 +700,7 @@ template <typename V> __device__ __forceinline__ V phase_cos(V x) {
 template <typename T>
 __device__ __forceinline__ void device_cavity_kick(const T* coef, T s_in, T d_in, T& s_out, T& d_out) {
   d_out = d_in * coef[LYNX_C_DSCALE] +
-          coef[LYNX_C_DKICK] * (phase_cos<T>(T(-1) * s_in * coef[LYNX_C_BK] + coef[LYNX_C_PHI]) - coef[LYNX_C_COSPHI]);
+          coef[LYNX_C_DKICK] * (phase_cos(T(-1) * s_in * coef[LYNX_C_BK] + coef[LYNX_C_PHI]) - coef[LYNX_C_COSPHI]);
   s_out = s_out + (coef[LYNX_C_T566] * (d_in * d_in) + coef[LYNX_C_T556] * s_in * d_in +
                    coef[LYNX_C_T555] * (s_in * s_in));
 }
@@ -724,7 +759,7 @@ __device__ __forceinline__ void apply_step_pair(const float* M /*49 + coef*/, in
   if (step_kind == LYNX_STEP_CAVITY && (step_flags & LYNX_FLAG_CAV_GAIN)) {
     const float* coef = M + LYNX_COEF_OFFSET;
     const lynx_f32x2 arg = -1.0f * s_in * coef[LYNX_C_BK] + coef[LYNX_C_PHI];
-    const lynx_f32x2 ca = phase_cos<lynx_f32x2>(arg);
+    const lynx_f32x2 ca = phase_cos(arg);
     o[5] = d_in * coef[LYNX_C_DSCALE] + coef[LYNX_C_DKICK] * (ca - coef[LYNX_C_COSPHI]);
     o[4] = o[4] + (coef[LYNX_C_T566] * (d_in * d_in) + coef[LYNX_C_T556] * s_in * d_in +
                    coef[LYNX_C_T555] * (s_in * s_in));
