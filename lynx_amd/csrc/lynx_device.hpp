@@ -55,6 +55,16 @@ __device__ __forceinline__ int step_descriptor(const LatticeDev& lat, int s, int
   return d;
 }
 
+// LYNX_ENTRY_OFFSET: inverse of the (s, delta) block of a cavity's rounded map, formed in float64
+template <typename T>
+__device__ __forceinline__ void cavity_entry_inverse(T c44, T c45, T c54, T c55, T (&ci)[4]) {
+  const double det = (double)c44 * (double)c55 - (double)c45 * (double)c54;
+  ci[0] = (T)((double)c55 / det);
+  ci[1] = (T)(-(double)c45 / det);
+  ci[2] = (T)(-(double)c54 / det);
+  ci[3] = (T)((double)c44 / det);
+}
+
 constexpr int kBuildChunk = 64;   // elements built in parallel per compose round (k_build may use up to 128)
 constexpr int kTrackThreads = 256;
 constexpr int kPartialStride = 36;
@@ -520,10 +530,19 @@ __global__ __launch_bounds__(64) void k_emit_steps(LatticeDev lat, const int32_t
     LYNX_FORGET();
 #pragma unroll
     for (int q = 0; q < 49; ++q) R[q] = row[q];
+    T c4[2] = {T(0), T(0)}, c5[2] = {T(0), T(0)};  // the cavity's (s, delta) block
 #pragma unroll 1
     for (int i = 0; i < 7; ++i) {
       double x[7];
       emit_row(src, Bp, i, true, x);
+      if (i == 4) {
+        c4[0] = (T)x[4];
+        c4[1] = (T)x[5];
+      }
+      if (i == 5) {
+        c5[0] = (T)x[4];
+        c5[1] = (T)x[5];
+      }
 #pragma unroll
       for (int j = 0; j < 7; ++j) {
         double acc = (double)(T)x[0] * (double)R[j];
@@ -532,6 +551,10 @@ __global__ __launch_bounds__(64) void k_emit_steps(LatticeDev lat, const int32_t
         row[i * 7 + j] = (T)acc;
       }
     }
+    T ci[4];
+    cavity_entry_inverse<T>(c4[0], c4[1], c5[0], c5[1], ci);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) row[LYNX_ENTRY_OFFSET + q] = ci[q];
   } else {
 #pragma unroll 1
     for (int i = 0; i < 7; ++i) {
@@ -741,13 +764,17 @@ __device__ __forceinline__ lynx_f32x2 pk_fma(lynx_f32x2 a, float b, lynx_f32x2 c
   return __builtin_elementwise_fma(a, (lynx_f32x2)(b), c);
 }
 
-__device__ __forceinline__ void apply_step_pair(const float* M /*49 + coef*/, int step_kind, int step_flags,
-                                                lynx_f32x2 (&z)[7], bool merged = false,
+// `entry`: where the s and delta that drive a cavity's kick come from --
+//   kEntryOwn     the pair's own components 4, 5 (a cavity step on its own),
+//   kEntryGiven   s_entry, d_entry (merged [run, cavity] pair, reverse pass: rows 4, 5 of T_run applied to z),
+//   kEntryInverse merged pair, forward pass: the inverse of T_cav's (s, delta) block (LYNX_ENTRY_OFFSET) applied
+//                 to components 4, 5 of M z, M = T_cav . T_run
+enum { kEntryOwn = 0, kEntryGiven = 1, kEntryInverse = 2 };
+
+__device__ __forceinline__ void apply_step_pair(const float* M /*49 + coef (+ 4)*/, int step_kind, int step_flags,
+                                                lynx_f32x2 (&z)[7], int entry = kEntryOwn,
                                                 lynx_f32x2 s_entry = lynx_f32x2{0.f, 0.f},
                                                 lynx_f32x2 d_entry = lynx_f32x2{0.f, 0.f}) {
-  // merged [run, cavity] pair: M = T_cav . T_run and the kick is driven by the s and delta that
-  // enter the cavity (s_entry, d_entry = rows 4 and 5 of T_run applied to z), see k_build
-  const lynx_f32x2 s_in = merged ? s_entry : z[4], d_in = merged ? d_entry : z[5];
   lynx_f32x2 o[7];
 #pragma unroll
   for (int i = 0; i < 7; ++i) {
@@ -758,6 +785,15 @@ __device__ __forceinline__ void apply_step_pair(const float* M /*49 + coef*/, in
   }
   if (step_kind == LYNX_STEP_CAVITY && (step_flags & LYNX_FLAG_CAV_GAIN)) {
     const float* coef = M + LYNX_COEF_OFFSET;
+    lynx_f32x2 s_in = z[4], d_in = z[5];
+    if (entry == kEntryGiven) {
+      s_in = s_entry;
+      d_in = d_entry;
+    } else if (entry == kEntryInverse) {
+      const float* ci = M + LYNX_ENTRY_OFFSET;
+      s_in = pk_fma(o[5], ci[1], o[4] * ci[0]);
+      d_in = pk_fma(o[5], ci[3], o[4] * ci[2]);
+    }
     const lynx_f32x2 arg = -1.0f * s_in * coef[LYNX_C_BK] + coef[LYNX_C_PHI];
     const lynx_f32x2 ca = phase_cos(arg);
     o[5] = d_in * coef[LYNX_C_DSCALE] + coef[LYNX_C_DKICK] * (ca - coef[LYNX_C_COSPHI]);
@@ -768,11 +804,12 @@ __device__ __forceinline__ void apply_step_pair(const float* M /*49 + coef*/, in
   for (int i = 0; i < 7; ++i) z[i] = o[i];
 }
 
-// [run, cavity] pair in merged form: `pre` = rows 4 and 5 of the run's map, `M` = T_cav . T_run
-// with the cavity's coefficients.  One 7x7 application + two rows instead of two applications:
+// [run, cavity] pair in merged form, as the REVERSE pass walks it: `pre` = rows 4 and 5 of the run's map
+// (the run's slot), `M` = T_cav . T_run with the cavity's coefficients.  One 7x7 application + two rows
+// instead of two applications:
 //   z_cav_in[4], z_cav_in[5] = pre . z (merged_pair_entry);  o = M z;  kick from those two.
 // Same algebra as the two steps one after the other; the product is rounded once more in
-// k_build and once less per particle.
+// k_build and once less per particle.  (The forward kernel gets the two from M z itself: kEntryInverse.)
 __device__ __forceinline__ void merged_pair_entry(const float* pre /*14*/, const lynx_f32x2 (&z)[7],
                                                   lynx_f32x2& s_in, lynx_f32x2& d_in) {
   s_in = z[0] * pre[0];
@@ -821,8 +858,14 @@ __global__ __launch_bounds__(1024) void k_build(LatticeDev lat, const T* __restr
         for (int k = 1; k < 7; ++k) acc = fma((double)cav[i * 7 + k], (double)run[k * 7 + j], acc);
         v = (T)acc;
       }
+      T ci[4] = {T(0), T(0), T(0), T(0)};
+      if (threadIdx.x == 49) cavity_entry_inverse<T>(cav[4 * 7 + 4], cav[4 * 7 + 5], cav[5 * 7 + 4], cav[5 * 7 + 5], ci);
       __syncthreads();
       if (threadIdx.x < 49) cav[threadIdx.x] = v;
+      if (threadIdx.x == 49) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cav[LYNX_ENTRY_OFFSET + q] = ci[q];
+      }
       if (threadIdx.x >= 64 && threadIdx.x < 78) run[threadIdx.x - 64] = run[28 + (threadIdx.x - 64)];
       __syncthreads();
     }
@@ -1183,12 +1226,10 @@ __device__ __forceinline__ void apply_program_lane(const LatticeDev& lat, int S,
   }
   int n_obs = 0;
   for (int sidx = 0; sidx < S; ++sidx) {
-    // merged [run, cavity] pair (see k_build): the run's slot holds the two rows that give the
-    // s and delta entering the cavity; they are formed first (their 14 scalars are dead before
-    // the 57 of the pair's map arrive: SGPRs are the scarce resource), then the loop moves on
-    // to the cavity's slot, which holds T_cav . T_run
+    // merged [run, cavity] pair (see k_build): the loop moves straight on to the cavity's slot, which holds
+    // T_cav . T_run, the cavity's coefficients and the 2x2 that recovers the s and delta entering the cavity
+    // from the product's own components (kEntryInverse) -- one scalar fetch and one 7x7 application per pair
     bool merged = false;
-    lynx_f32x2 s_entry[kPairs ? UNROLL / 2 : 1], d_entry[kPairs ? UNROLL / 2 : 1];
     // kind, flags and pairing of the step: one wave-uniform scalar from the table this kernel was given
     const T* table = SCALAR_TABLE ? g_steps : s_steps;
     int desc = (int)uniform_value(table[sidx * LYNX_STEP_STRIDE + LYNX_FLAGS_OFFSET]);
@@ -1214,34 +1255,27 @@ __device__ __forceinline__ void apply_program_lane(const LatticeDev& lat, int S,
     }
     if constexpr (kPairs && SCALAR_TABLE) {
       if (desc & LYNX_DESC_PAIR) {  // uniform: this run is applied together with the cavity behind it
-        const float* tab = reinterpret_cast<const float*>(g_steps) + sidx * LYNX_STEP_STRIDE;
-        float pre[14];
-#pragma unroll
-        for (int q = 0; q < 14; ++q) pre[q] = uniform_value(tab[q]);
-#pragma unroll
-        for (int h = 0; h < UNROLL / 2; ++h) merged_pair_entry(pre, zp[h], s_entry[h], d_entry[h]);
         merged = true;
         ++sidx;
         desc = (int)uniform_value(table[sidx * LYNX_STEP_STRIDE + LYNX_FLAGS_OFFSET]);
-        LYNX_FORGET();
       }
     }
     const int skind = (desc >> LYNX_DESC_KIND_SHIFT) & 3, sflags = desc & 0xffff;
     if constexpr (kMapInRegs) {
-      T m[57];  // T = float here
+      T m[61];  // T = float here: map, coefficients, entry inverse
       if (SCALAR_TABLE) {
         const T* tab = g_steps + sidx * LYNX_STEP_STRIDE;  // global: s_load
 #pragma unroll
-        for (int q = 0; q < 57; ++q) m[q] = uniform_value(tab[q]);
+        for (int q = 0; q < 61; ++q) m[q] = uniform_value(tab[q]);
       } else {
         const T* tab = s_steps + sidx * LYNX_STEP_STRIDE;  // LDS
 #pragma unroll
-        for (int q = 0; q < 57; ++q) m[q] = uniform_value(tab[q]);
+        for (int q = 0; q < 61; ++q) m[q] = uniform_value(tab[q]);
       }
       if constexpr (kPairs) {
 #pragma unroll
         for (int h = 0; h < UNROLL / 2; ++h)
-          apply_step_pair(m, skind, sflags, zp[h], merged, s_entry[h], d_entry[h]);
+          apply_step_pair(m, skind, sflags, zp[h], merged ? kEntryInverse : kEntryOwn);
       } else {
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) apply_step<T>(m, skind, sflags, z[u]);

@@ -179,7 +179,7 @@ __device__ __forceinline__ void apply_unit(const T* g_steps, int slot, Z (&z)[7]
       LYNX_FORGET();  // the 14 scalars are dead before the 57 of the pair's map arrive
       T m[57];
       load_step_map<T>(g_steps, slot, m);
-      apply_step_pair(m, st.kind, st.flags, z, true, s_entry, d_entry);
+      apply_step_pair(m, st.kind, st.flags, z, kEntryGiven, s_entry, d_entry);
       return;
     }
   }

@@ -48,6 +48,11 @@ namespace lynx {
 // 49 map entries + 8 cavity coefficients, padded to 64
 #define LYNX_STEP_STRIDE 64
 #define LYNX_COEF_OFFSET 49
+// slots 57..60 of a cavity that is applied merged with the run in front of it (M = T_cav . T_run): the inverse
+// of T_cav's (s, delta) block.  The cavity's map couples s and delta only with each other (cavity.py:311-323),
+// so this 2x2 applied to components 4, 5 of M z returns the s and delta that ENTER the cavity and drive its
+// kick -- 4 multiply-adds on scalars that arrive with the map, instead of two 7-term rows from a second slot
+#define LYNX_ENTRY_OFFSET 57
 // slot 62: the step's flags as they stood when THIS table was built (a small integer stored as T).  The
 // cavity bits are whole-batch predicates of the beam energy, re-evaluated on the device before every
 // build; the streaming kernel of call n reads them here and never sees call n+1's.

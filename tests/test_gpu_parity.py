@@ -731,7 +731,10 @@ def test_two_kernel_path_is_bit_identical_to_fused(lx):
     assert not np.array_equal(got, seq)
     for k in range(6):
         scale = np.max(np.abs(ref["particles"][..., k]))
-        assert np.max(np.abs(got[..., k] - seq[..., k])) < 5e-6 * scale, k
+        # delta: the merged form recovers the s that enters the cavity from the product's own components (a few
+        # float32 roundings away from the step-by-step value), which can move the float32 cosine of the kick
+        # by one ulp (6e-8 at cos ~ 1), times the kick's amplitude V beta0 / (E_out beta1) < 1
+        assert np.max(np.abs(got[..., k] - seq[..., k])) < 5e-6 * scale + (1.2e-7 if k == 5 else 0.0), k
         assert np.max(np.abs(got[..., k] - ref["particles"][..., k])) < 1e-4 * scale, k  # the oracle's cos is NumPy's
 
 
