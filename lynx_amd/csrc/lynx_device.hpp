@@ -678,9 +678,10 @@ __device__ __forceinline__ void phase_sincos(lynx_f32x2 x, lynx_f32x2& s, lynx_f
   c = lynx_f32x2{c0, c1};
 }
 // The forward kernels need the cosine alone: one polynomial on [-pi/2, pi/2] (cos r = 1 - z/2 + z^2 q(z),
-// z = r^2; |error| <= 7.5e-8, i.e. what rounding the result to float costs anyway) and the sign of the
-// half-period, instead of both quadrant polynomials and a select -- 23 instead of 40 instructions per pair
-// of particles in the cavity step.
+// z = r^2) and the sign of the half-period, instead of both quadrant polynomials and a select -- 23 instead
+// of 40 instructions per pair of particles in the cavity step.  Absolute error <= 7.5e-8 for |x| <= pi/2
+// (no reduction; what rounding the result to float costs anyway), <= 1.3e-7 beyond (the reduced argument is
+// itself rounded to float); the kick is DKICK (cos a - cos phi), so the absolute error is the one that counts.
 template <typename V>
 __device__ __forceinline__ V cos_half_period(V x, V& n) {
   n = vrint(x * 0.31830987334251404f);
@@ -2009,23 +2010,25 @@ __global__ __launch_bounds__(256) void k_aperture_compact(const T* __restrict__ 
 }
 
 // k_diag_phase_trig: phase_sincos on an array, scalar and packed-pair code paths (test hook for
-// the accuracy statement above).
+// the accuracy statement above); bit 1 of `packed`: the cosine from phase_cos, the forward kernels' own.
 __global__ __launch_bounds__(256) void k_diag_phase_trig(const float* __restrict__ x, int64_t n, int packed,
                                                           float* __restrict__ s_out, float* __restrict__ c_out) {
   const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
   if (i >= n) return;
   const int64_t j = i + 1 < n ? i + 1 : i;
-  if (packed) {
+  const bool cos_alone = (packed & 2) != 0;
+  if (packed & 1) {
     lynx_f32x2 s, c;
     phase_sincos(lynx_f32x2{x[i], x[j]}, s, c);
+    if (cos_alone) c = phase_cos(lynx_f32x2{x[i], x[j]});
     s_out[i] = s.x; c_out[i] = c.x;
     s_out[j] = s.y; c_out[j] = c.y;
   } else {
     float s, c;
     phase_sincos(x[i], s, c);
-    s_out[i] = s; c_out[i] = c;
+    s_out[i] = s; c_out[i] = cos_alone ? phase_cos(x[i]) : c;
     phase_sincos(x[j], s, c);
-    s_out[j] = s; c_out[j] = c;
+    s_out[j] = s; c_out[j] = cos_alone ? phase_cos(x[j]) : c;
   }
 }
 

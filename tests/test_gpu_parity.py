@@ -1155,6 +1155,16 @@ def test_device_phase_trig_accuracy(lx, packed):
         assert err.max() < 1.2e-7, err.max()
         ulp = np.spacing(np.maximum(np.abs(ref), 1e-3).astype(np.float32)).astype(np.float64)  # relative, away from zeros
         assert (err / ulp).max() < 2.0, (err / ulp).max()
+    # the forward kernels' cosine (one half-period polynomial): the kick is DKICK (cos(a) - cos(phi)), a difference
+    # of numbers of order one, so what counts is the ABSOLUTE error: one float32 ulp of 1
+    rt.check(rt.lib.lynx_diag_phase_trig(rt.ctx, xs.size, C.c_void_p(d_x.ptr), packed | 2, C.c_void_p(d_s.ptr), C.c_void_p(d_c.ptr)))
+    c = d_c.numpy()
+    assert np.all(np.isnan(c[x.size:]))
+    err = np.abs(c[: x.size].astype(np.float64) - np.cos(x64))
+    # up to pi/2 (no reduction: where cavity phases live) the polynomial's own 7.5e-8; beyond, the reduced argument
+    # -- up to pi/2 in size -- is itself rounded to float32, which adds up to 6e-8 sin(r)
+    assert err[np.abs(x64) <= np.pi / 2].max() < 8e-8, err[np.abs(x64) <= np.pi / 2].max()
+    assert err.max() < 1.35e-7, err.max()
 
 
 def test_attribute_writes_between_tracks_take_effect(lx):
