@@ -170,16 +170,11 @@ template <typename T, typename Z>
 __device__ __forceinline__ void apply_unit(const T* g_steps, int slot, Z (&z)[7]) {
   const lynx_step st = table_step<T>(g_steps, slot);
   if constexpr (LaneOf<Z>::W == 2) {
-    if (unit_is_pair<T>(g_steps, slot)) {  // uniform
-      float pre[14];
+    if (unit_is_pair<T>(g_steps, slot)) {  // uniform: as the forward kernel applies it (kEntryInverse)
+      T m[61];
 #pragma unroll
-      for (int q = 0; q < 14; ++q) pre[q] = g_steps[(slot - 1) * LYNX_STEP_STRIDE + q];
-      lynx_f32x2 s_entry, d_entry;
-      merged_pair_entry(pre, z, s_entry, d_entry);
-      LYNX_FORGET();  // the 14 scalars are dead before the 57 of the pair's map arrive
-      T m[57];
-      load_step_map<T>(g_steps, slot, m);
-      apply_step_pair(m, st.kind, st.flags, z, kEntryGiven, s_entry, d_entry);
+      for (int q = 0; q < 61; ++q) m[q] = g_steps[slot * LYNX_STEP_STRIDE + q];
+      apply_step_pair(m, st.kind, st.flags, z, kEntryInverse);
       return;
     }
   }
