@@ -1628,19 +1628,57 @@ __global__ __launch_bounds__(256) void k_reduce_moments(const double* __restrict
   const int hi = (lo + rows_per_group) < rows ? (lo + rows_per_group) : rows;
   const double* src = in + (b * (int64_t)rows + lo) * kPartialStride;
   double v = 0.0;
-  double c0 = 0.0;  // thread j < 6 keeps component j of the reference point in a register too
+  int mi = 0, mj = 0;  // j in [7, 28): the pair (mi <= mj) of components of second moment j (row-major upper triangle)
+  if (j >= 7 && j < 28) {
+    int k = j - 7, len = 6;
+    while (k >= len) { k -= len; --len; ++mi; }
+    mj = mi + k;
+  }
   for (int base = 0; base < hi - lo; base += kReduceStage) {
     const int n_stage = (hi - lo - base) < kReduceStage ? (hi - lo - base) : kReduceStage;
     __syncthreads();  // the previous pass is done with the staging area
-    for (int i = tid; i < n_stage * kPartialStride; i += 256) s_rows[i] = src[(int64_t)base * kPartialStride + i];
+    {
+      // all of a thread's loads are issued before the first one is waited for
+      constexpr int kPerThread = (kReduceStage * kPartialStride + 255) / 256;
+      double staged[kPerThread];
+#pragma unroll
+      for (int k = 0; k < kPerThread; ++k) {
+        const int i = tid + k * 256;
+        staged[k] = i < n_stage * kPartialStride ? src[(int64_t)base * kPartialStride + i] : 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < kPerThread; ++k) {
+        const int i = tid + k * 256;
+        if (i < n_stage * kPartialStride) s_rows[i] = staged[k];
+      }
+    }
     __syncthreads();
     if (base == 0 && tid < 8) s[28 + tid] = tid < 7 ? s_rows[28 + tid] : 0.0;  // the group's reference point (s[35] set below)
     __syncthreads();
     if (q < kReduceSets && (j < 28 || j == 35)) {
-#pragma unroll 2
-      for (int r = q; r < n_stage; r += kReduceSets) v += moment_slot_moved(s_rows + r * kPartialStride, s + 28, j);
+      // moment_slot_moved with everything that depends on j alone taken out of the row loop (which pair of
+      // components a second moment belongs to, the reference point's two components): what is left per row
+      // is six LDS reads and five multiply-adds, rows independent of each other
+      if (j == 6 || j == 35) {
+#pragma unroll 5
+        for (int r = q; r < n_stage; r += kReduceSets) v += s_rows[r * kPartialStride + j];
+      } else if (j < 6) {
+        const double c0j = s[28 + j];
+#pragma unroll 5
+        for (int r = q; r < n_stage; r += kReduceSets) {
+          const double* row = s_rows + r * kPartialStride;
+          v += row[j] + row[35] * (row[28 + j] - c0j);
+        }
+      } else {
+        const double c0i = s[28 + mi], c0j = s[28 + mj];
+#pragma unroll 5
+        for (int r = q; r < n_stage; r += kReduceSets) {
+          const double* row = s_rows + r * kPartialStride;
+          const double ei = row[28 + mi] - c0i, ej = row[28 + mj] - c0j;
+          v += row[j] + ei * row[mj] + row[mi] * ej + row[35] * ei * ej;
+        }
+      }
     }
-    (void)c0;
   }
   if (q < kReduceSets) s_set[q][j] = v;
   __syncthreads();
