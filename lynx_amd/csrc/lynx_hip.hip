@@ -701,9 +701,13 @@ static TrackPlan plan_track(lynx_ctx* ctx, const lynx_lattice* lat, int64_t B, i
   p.a.store = 0;
   p.a.interleave = env_int("LYNX_INTERLEAVE", 0);
   p.a.build_chunk = 1;
-  // wave tiles: measured +10 % on float64 (BASELINE config 3 at 8 M particles), -3..8 % on float32, and
-  // slower on multi-step float32 programs, which want two particles per lane, not four
-  p.xpose = !p.a.fused_build && env_int("LYNX_XPOSE", sizeof(T) == 8 ? 1 : 0) != 0;
+  // wave tiles: with non-temporal full-width stores +7 % on single-map float32 programs (BASELINE config 4:
+  // 5.4 -> 5.8 TB/s) and +10 % (+7 % of that from the stores) on float64 (config 3 at 8 M particles); slower on
+  // multi-step float32 programs, which want two particles per lane, not four
+  // (a read-only pass -- lynx_moments, S = 0 -- has no stores to gain from and stays with per-particle loads)
+  const bool single_map = S == 1 && lat && lat->h_steps[0].kind == LYNX_STEP_RUN &&
+                          !(lat->h_steps[0].flags & LYNX_STEP_FLAG_OBSERVE);
+  p.xpose = !p.a.fused_build && env_int("LYNX_XPOSE", (sizeof(T) == 8 || single_map) ? 1 : 0) != 0;
   int u = env_int("LYNX_UNROLL", p.xpose ? P : (sizeof(T) == 4 ? (S > 1 ? 2 : 4) : 1));
   if (u != 1 && u != 2 && u != 4) u = 2;
   if (sizeof(T) == 8 && u > 2) u = 2;
