@@ -1592,8 +1592,11 @@ __global__ __launch_bounds__(kTrackThreads, (XPOSE ? 3 : 1)) void k_track_direct
 //                  particles has ~8000 of them);
 //   FINAL = true : writes the moment record of the sample (include/lynx_hip.h); groups must be 1.
 // ---------------------------------------------------------------------------------------
-constexpr int kReduceSets = 7;
-constexpr int kReduceStage = 70;  // rows staged per pass: 10 per set
+constexpr int kReduceStage = 70;        // rows staged per pass by the 256-thread shape: 10 per set
+constexpr int kReduceStageWide = 448;   // ... by the 1024-thread shape: 16 per set
+template <int THREADS, int STAGE> constexpr size_t reduce_lds_bytes() {
+  return (size_t)(STAGE + THREADS / kPartialStride + 1) * kPartialStride * sizeof(double);
+}
 
 __device__ __forceinline__ void write_moment_record(const double* s, double* dst, int tid) {
   const double n = s[35];
@@ -1617,12 +1620,20 @@ __device__ __forceinline__ void write_moment_record(const double* s, double* dst
   }
 }
 
-template <bool FINAL>
-__global__ __launch_bounds__(256) void k_reduce_moments(const double* __restrict__ in, int rows, int rows_per_group,
-                                                         int groups, double* __restrict__ out) {
-  __shared__ double s_rows[kReduceStage * kPartialStride];
-  __shared__ double s_set[kReduceSets][kPartialStride];
-  __shared__ double s[kPartialStride];
+// THREADS / 36 sets of 36 threads; STAGE rows staged per pass (STAGE / sets per set).  Two shapes are used:
+//   <FINAL, 256, 70>    7 sets, 22 KB of LDS: many samples, or the groups of a level;
+//   <true, 1024, 448>   28 sets, 137 KB: ONE workgroup per sample walks a few hundred rows in one pass -- beams of
+//                       few samples (BASELINE configs 2 and 3: 391 and 977 rows), where a level in between costs a
+//                       launch and a kernel boundary (~10 us) and there are no other samples to fill the CUs with.
+template <bool FINAL, int THREADS, int STAGE>
+__global__ __launch_bounds__(THREADS) void k_reduce_moments(const double* __restrict__ in, int rows, int rows_per_group,
+                                                             int groups, double* __restrict__ out) {
+  constexpr int kSets = THREADS / kPartialStride;
+  static_assert(STAGE % kSets == 0, "every set takes the same number of staged rows");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* s_rows = reinterpret_cast<double*>(smem_raw);        // [STAGE][36]
+  double* s_set = s_rows + STAGE * kPartialStride;              // [kSets][36]
+  double* s = s_set + kSets * kPartialStride;                   // [36]
   const int64_t b = blockIdx.x / groups;
   const int g = blockIdx.x % groups;
   const int tid = threadIdx.x;
@@ -1637,45 +1648,45 @@ __global__ __launch_bounds__(256) void k_reduce_moments(const double* __restrict
     while (k >= len) { k -= len; --len; ++mi; }
     mj = mi + k;
   }
-  for (int base = 0; base < hi - lo; base += kReduceStage) {
-    const int n_stage = (hi - lo - base) < kReduceStage ? (hi - lo - base) : kReduceStage;
+  for (int base = 0; base < hi - lo; base += STAGE) {
+    const int n_stage = (hi - lo - base) < STAGE ? (hi - lo - base) : STAGE;
     __syncthreads();  // the previous pass is done with the staging area
     {
       // all of a thread's loads are issued before the first one is waited for
-      constexpr int kPerThread = (kReduceStage * kPartialStride + 255) / 256;
+      constexpr int kPerThread = (STAGE * kPartialStride + THREADS - 1) / THREADS;
       double staged[kPerThread];
 #pragma unroll
       for (int k = 0; k < kPerThread; ++k) {
-        const int i = tid + k * 256;
+        const int i = tid + k * THREADS;
         staged[k] = i < n_stage * kPartialStride ? src[(int64_t)base * kPartialStride + i] : 0.0;
       }
 #pragma unroll
       for (int k = 0; k < kPerThread; ++k) {
-        const int i = tid + k * 256;
+        const int i = tid + k * THREADS;
         if (i < n_stage * kPartialStride) s_rows[i] = staged[k];
       }
     }
     __syncthreads();
     if (base == 0 && tid < 8) s[28 + tid] = tid < 7 ? s_rows[28 + tid] : 0.0;  // the group's reference point (s[35] set below)
     __syncthreads();
-    if (q < kReduceSets && (j < 28 || j == 35)) {
+    if (q < kSets && (j < 28 || j == 35)) {
       // moment_slot_moved with everything that depends on j alone taken out of the row loop (which pair of
       // components a second moment belongs to, the reference point's two components): what is left per row
       // is six LDS reads and five multiply-adds, rows independent of each other
       if (j == 6 || j == 35) {
-#pragma unroll 5
-        for (int r = q; r < n_stage; r += kReduceSets) v += s_rows[r * kPartialStride + j];
+#pragma unroll 4
+        for (int r = q; r < n_stage; r += kSets) v += s_rows[r * kPartialStride + j];
       } else if (j < 6) {
         const double c0j = s[28 + j];
-#pragma unroll 5
-        for (int r = q; r < n_stage; r += kReduceSets) {
+#pragma unroll 4
+        for (int r = q; r < n_stage; r += kSets) {
           const double* row = s_rows + r * kPartialStride;
           v += row[j] + row[35] * (row[28 + j] - c0j);
         }
       } else {
         const double c0i = s[28 + mi], c0j = s[28 + mj];
-#pragma unroll 5
-        for (int r = q; r < n_stage; r += kReduceSets) {
+#pragma unroll 4
+        for (int r = q; r < n_stage; r += kSets) {
           const double* row = s_rows + r * kPartialStride;
           const double ei = row[28 + mi] - c0i, ej = row[28 + mj] - c0j;
           v += row[j] + ei * row[mj] + row[mi] * ej + row[35] * ei * ej;
@@ -1683,12 +1694,12 @@ __global__ __launch_bounds__(256) void k_reduce_moments(const double* __restrict
       }
     }
   }
-  if (q < kReduceSets) s_set[q][j] = v;
+  if (q < kSets) s_set[q * kPartialStride + j] = v;
   __syncthreads();
   if (tid < kPartialStride && (tid < 28 || tid == 35)) {
     double t = 0.0;
 #pragma unroll
-    for (int k = 0; k < kReduceSets; ++k) t += s_set[k][tid];
+    for (int k = 0; k < kSets; ++k) t += s_set[k * kPartialStride + tid];
     s[tid] = t;
   }
   __syncthreads();

@@ -839,6 +839,7 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
   const void* d_steps = nullptr;
   int rc;
   int slot = -1;
+  bool async_build = false;
   if (S > 0 && !fused) {
     slot = (int)(ctx->seq++ & 1u);
     const size_t need = (size_t)B * S * LYNX_STEP_STRIDE * sizeof(T);
@@ -855,6 +856,7 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
     // million particles per call the extra event traffic costs more host time than the overlap returns
     // (BASELINE config 2: 31 -> 46 us per call with it).
     const bool async = env_int("LYNX_ASYNC_BUILD", B * N >= (int64_t)512 << 10 ? 1 : 0) != 0;
+    async_build = async;
     hipStream_t bs = async ? ctx->s_build : ctx->stream;
     if (async) {
       // the table slot was last read by the streaming kernel two calls ago
@@ -889,7 +891,11 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
     if ((rc = ensure_scratch(ctx, &ctx->scratch_obs, &ctx->scratch_obs_bytes, need))) return rc;
     d_obs = (double*)ctx->scratch_obs;
   }
-  p.done = (slot >= 0) ? ctx->ev_streamed_own[slot] : nullptr;
+  // the time stamp on the dispatch is what a later build on the second stream waits for before it reuses the
+  // table slot; a call whose build ran on the main stream leaves it out (it costs host time: BASELINE config 2 is
+  // bound by the host's enqueue rate) and marks the main stream dirty instead, which makes the next asynchronous
+  // build wait for everything enqueued here
+  p.done = (slot >= 0 && async_build) ? ctx->ev_streamed_own[slot] : nullptr;
   rc = launch_direct<T>(ctx, p, lv, d_energy_in, d_p_in, d_p_out, d_energy_out, d_steps, d_partials, d_obs, moments);
   if (rc) return rc;
   if (p.a.n_observers) {
@@ -899,27 +905,40 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
   }
   if (slot >= 0) {
     ctx->ev_streamed[slot] = ctx->last_stream_stop;
-    ctx->streamed_valid[slot] = true;
+    ctx->streamed_valid[slot] = async_build && ctx->last_stream_stop != nullptr;
+    if (!async_build) ctx->main_dirty = true;
   }
   if (d_energy_out) ctx->main_wrote = d_energy_out;  // a later build that reads it must wait for this kernel
   if (moments) {
-    // records of the workgroups -> record of the sample: one pass for up to 70 rows, otherwise a level of
-    // <= 64 groups in between (rows_per_group grows with the beam, the walk stays short)
+    // records of the workgroups -> record of the sample.  Many samples: one 256-thread workgroup per sample
+    // walks up to 70 rows, more rows go through a level of <= 64 groups first (rows_per_group grows with the
+    // beam).  Few samples with a few hundred rows each (BASELINE configs 2 and 3): one 1024-thread workgroup
+    // per sample stages 448 rows per pass -- one launch instead of two (LYNX_REDUCE_WIDE=0: the level form).
     int rows = p.a.chunks;
     const double* level_in = d_partials;
+    const bool wide = B <= 4 && rows > kReduceStage && rows <= 3 * kReduceStageWide && env_int("LYNX_REDUCE_WIDE", 1);
+    if (wide) {
+      constexpr size_t lds = reduce_lds_bytes<1024, kReduceStageWide>();
+      if ((rc = allow_lds(ctx, k_reduce_moments<true, 1024, kReduceStageWide>, lds))) return rc;
+      hipLaunchKernelGGL((k_reduce_moments<true, 1024, kReduceStageWide>), dim3((unsigned)B), dim3(1024), lds, ctx->stream,
+                         level_in, rows, rows, 1, d_moments_out);
+      HIP_TRY(ctx, hipGetLastError());
+      return LYNX_OK;
+    }
+    constexpr size_t lds = reduce_lds_bytes<256, kReduceStage>();
     if (rows > kReduceStage) {
       const int rpg = (rows + 63) / 64;
       const int groups = (rows + rpg - 1) / rpg;
       const size_t need = (size_t)B * groups * kPartialStride * sizeof(double);
       if ((rc = ensure_scratch(ctx, &ctx->scratch_level, &ctx->scratch_level_bytes, need))) return rc;
-      hipLaunchKernelGGL(k_reduce_moments<false>, dim3((unsigned)(B * groups)), dim3(256), 0, ctx->stream, level_in, rows,
-                         rpg, groups, (double*)ctx->scratch_level);
+      hipLaunchKernelGGL((k_reduce_moments<false, 256, kReduceStage>), dim3((unsigned)(B * groups)), dim3(256), lds, ctx->stream,
+                         level_in, rows, rpg, groups, (double*)ctx->scratch_level);
       HIP_TRY(ctx, hipGetLastError());
       level_in = (const double*)ctx->scratch_level;
       rows = groups;
     }
-    hipLaunchKernelGGL(k_reduce_moments<true>, dim3((unsigned)B), dim3(256), 0, ctx->stream, level_in, rows, rows, 1,
-                       d_moments_out);
+    hipLaunchKernelGGL((k_reduce_moments<true, 256, kReduceStage>), dim3((unsigned)B), dim3(256), lds, ctx->stream, level_in,
+                       rows, rows, 1, d_moments_out);
     HIP_TRY(ctx, hipGetLastError());
   }
   return LYNX_OK;

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import atexit
 import ctypes as C
+import math
 import os
 import weakref
 
@@ -143,7 +144,7 @@ class DeviceArray:
         self.rt = rt
         self.shape = shape
         self.dtype = dtype
-        self.size = int(np.prod(shape, dtype=np.int64)) if shape else 1
+        self.size = math.prod(shape)  # () -> 1; Python ints: no overflow
         self.nbytes = self.size * dtype.itemsize
         self.ptr = rt.alloc(max(self.nbytes, 1))
         self._finalizer = weakref.finalize(self, rt.free, self.ptr)
