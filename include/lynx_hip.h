@@ -148,7 +148,8 @@ int lynx_profile_end(lynx_ctx* ctx, double* total_ms, int64_t* launches);
 /* Calibration: average time of a plain 16-byte-per-lane copy of `bytes` (read + write),
  * i.e. the practical HBM ceiling of this GPU for a stream shaped like a tracking pass.
  * vec_per_thread: 16-byte vectors each thread copies (a workgroup owns one contiguous block of
- * 256 * vec_per_thread vectors); 0 = grid-stride loop.  1 is the fastest shape on MI355X.     */
+ * 256 * vec_per_thread vectors); 0 = grid-stride loop; 100 + n = n per thread with non-temporal
+ * stores.  1 is the fastest shape on MI355X (6.2 TB/s, with either kind of store).             */
 int lynx_diag_copy(lynx_ctx* ctx, void* d_dst, const void* d_src, size_t bytes, int repeats,
                    int vec_per_thread, float* avg_ms);
 

@@ -2092,6 +2092,9 @@ __global__ __launch_bounds__(256) void k_diag_copy(const lynx_f32x4* __restrict_
                                                     lynx_f32x4* __restrict__ dst, int64_t n_vec, int vec_per_thread) {
   // vec_per_thread == 0: grid-stride; > 0: each workgroup copies one contiguous block of
   // 256 * vec_per_thread vectors, workgroups in linear order
+  // vec_per_thread >= 100: the same with non-temporal stores (what the wave-tile form of k_track_direct uses)
+  const bool nt = vec_per_thread >= 100;
+  if (nt) vec_per_thread -= 100;
   if (vec_per_thread == 0) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += stride) dst[i] = src[i];
@@ -2099,7 +2102,10 @@ __global__ __launch_bounds__(256) void k_diag_copy(const lynx_f32x4* __restrict_
     const int64_t base = (int64_t)blockIdx.x * 256 * vec_per_thread + threadIdx.x;
     for (int k = 0; k < vec_per_thread; ++k) {
       const int64_t i = base + (int64_t)k * 256;
-      if (i < n_vec) dst[i] = src[i];
+      if (i < n_vec) {
+        if (nt) __builtin_nontemporal_store(src[i], dst + i);
+        else dst[i] = src[i];
+      }
     }
   }
 }

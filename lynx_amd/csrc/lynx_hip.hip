@@ -1288,12 +1288,14 @@ int lynx_fill_gaussian(lynx_ctx* ctx, int dtype, int64_t batch, int64_t n_partic
 
 int lynx_diag_copy(lynx_ctx* ctx, void* d_dst, const void* d_src, size_t bytes, int repeats, int vec_per_thread,
                    float* avg_ms) {
-  if (!ctx || !d_dst || !d_src || bytes % 16 || repeats <= 0 || vec_per_thread < 0 || vec_per_thread > 64)
+  const int per_thread = vec_per_thread >= 100 ? vec_per_thread - 100 : vec_per_thread;  // >= 100: non-temporal stores
+  if (!ctx || !d_dst || !d_src || bytes % 16 || repeats <= 0 || vec_per_thread < 0 || per_thread > 64 ||
+      (vec_per_thread >= 100 && per_thread == 0))
     return fail(ctx, LYNX_ERR_INVALID, "bad argument");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const int64_t n_vec = (int64_t)(bytes / 16);
   const int vpt = vec_per_thread;  // 0 = grid-stride
-  const unsigned grid = vpt > 0 ? (unsigned)((n_vec + 256LL * vpt - 1) / (256LL * vpt))
+  const unsigned grid = per_thread > 0 ? (unsigned)((n_vec + 256LL * per_thread - 1) / (256LL * per_thread))
                                 : (unsigned)std::min<int64_t>((n_vec + 255) / 256, 256 * 16);
   hipLaunchKernelGGL(k_diag_copy, dim3(grid), dim3(256), 0, ctx->stream, (const lynx_f32x4*)d_src,
                      (lynx_f32x4*)d_dst, n_vec, vpt);  // warm-up

@@ -86,10 +86,11 @@ class Runtime:
         self.check(self.lib.lynx_profile_end(self.ctx, C.byref(ms), C.byref(n)))
         return float(ms.value), int(n.value)
 
-    def copy_bandwidth(self, nbytes: int, repeats: int = 10, shapes=(1, 4, 0)) -> dict:
+    def copy_bandwidth(self, nbytes: int, repeats: int = 10, shapes=(1, 4, 0, 101, 104)) -> dict:
         """
         GB/s (read + write bytes) of a plain 16 B/lane device copy of `nbytes` for each launch shape in
-        `shapes` (vectors per thread; 0 = grid-stride): the practical HBM ceiling is the best of them.
+        `shapes` (vectors per thread; 0 = grid-stride; 100 + n = n per thread with non-temporal stores):
+        the practical HBM ceiling is the best of them.
         """
         nbytes = int(nbytes) // 16 * 16
         a, b = self.alloc(nbytes), self.alloc(nbytes)
@@ -99,7 +100,9 @@ class Runtime:
                 ms = C.c_float()
                 self.check(self.lib.lynx_diag_copy(self.ctx, C.c_void_p(b), C.c_void_p(a), nbytes, repeats, int(vpt),
                                                    C.byref(ms)))
-                out[f"{vpt}_vec_per_thread" if vpt else "grid_stride"] = 2 * nbytes / (ms.value * 1e-3) / 1e9
+                name = "grid_stride" if not vpt else (f"{vpt - 100}_vec_per_thread_nt_store" if vpt >= 100
+                                                      else f"{vpt}_vec_per_thread")
+                out[name] = 2 * nbytes / (ms.value * 1e-3) / 1e9
         finally:
             self.free(a)
             self.free(b)
