@@ -966,7 +966,8 @@ template <typename T, bool FULL> struct MomentAcc {
   }
   template <int K> __device__ __forceinline__ void products(const double (&e)[6]) {
     if constexpr (K < Set::N) {
-      dd[K] = fma(e[Set::row(K)], e[Set::col(K)], dd[K]);
+      constexpr int r = Set::row(K), c = Set::col(K);  // constant-evaluated here: as call operands they were not
+      dd[K] = fma(e[r], e[c], dd[K]);
       products<K + 1>(e);
     }
   }
@@ -1150,7 +1151,10 @@ struct LaneSums {
   // scratch memory
   template <int K> __device__ __forceinline__ void products(const float (&e)[6]) {
     if constexpr (K < Set::N) {
-      f_dd[K] = fmaf(e[Set::row(K)], e[Set::col(K)], f_dd[K]);
+      // constant-evaluated here; as call operands the triangle walk ran per particle (whole covariance: 400
+      // selects per iteration, the kernel at half its rate)
+      constexpr int r = Set::row(K), c = Set::col(K);
+      f_dd[K] = fmaf(e[r], e[c], f_dd[K]);
       products<K + 1>(e);
     }
   }
@@ -1197,14 +1201,18 @@ struct LaneSums {
     }
   }
   // record slot of slab row r
+  template <int K> __device__ static __forceinline__ int slot_scan(int r, int sl) {
+    if constexpr (K < Set::N) {
+      constexpr int slot = Set::slot(K);
+      return slot_scan<K + 1>(r, r == 7 + K ? slot : sl);
+    } else {
+      return sl;
+    }
+  }
   __device__ static __forceinline__ int slot_of_row(int r) {
     if (r < 7) return r;
     if (r == 7 + Set::N) return 35;
-    int sl = 0;
-#pragma unroll
-    for (int k = 0; k < Set::N; ++k)
-      if (r == 7 + k) sl = Set::slot(k);
-    return sl;
+    return slot_scan<0>(r, 0);
   }
 };
 
