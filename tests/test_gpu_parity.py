@@ -186,6 +186,24 @@ def test_c2_ares_segment_particles(lx, n):
         _assert_moments(out, ref, np.float32)
 
 
+@pytest.mark.parametrize("dtype,n", [(np.float32, 100_000), (np.float64, 300_001)])
+def test_wide_reduction_matches_the_level_form(lx, dtype, n, monkeypatch):
+    """
+    Beams of few samples: the workgroups' records are added up by ONE 1024-thread workgroup per sample (a few
+    hundred rows: BASELINE config 2's shape) instead of a level of groups and a final launch.  Both forms add the
+    same records, in a different association: the moment records agree to float64 rounding, and with the oracle.
+    """
+    out, ref = _particle_case(lx, ARES, dtype, (1,), n, seed=5, sigma=[175e-9, 2e-7, 175e-9, 2e-7, 1e-6, 1e-6])
+    wide = out.moment_record().copy()
+    _assert_moments(out, ref, dtype)
+    monkeypatch.setenv("LYNX_REDUCE_WIDE", "0")
+    level, _ = _particle_case(lx, ARES, dtype, (1,), n, seed=5, sigma=[175e-9, 2e-7, 175e-9, 2e-7, 1e-6, 1e-6])
+    rec = level.moment_record()
+    have = ~np.isnan(rec)
+    assert np.array_equal(np.isnan(wide), np.isnan(rec))
+    assert np.allclose(wide[have], rec[have], rtol=1e-11, atol=1e-300)
+
+
 @pytest.mark.parametrize("dtype,n", [(np.float32, 4096), (np.float32, 4099), (np.float64, 2048), (np.float64, 2047)])
 def test_fodo_scan_particles(lx, dtype, n):
     """BASELINE configs 3/4 in small: 128-element FODO, k1 scan over the batch; odd N takes
