@@ -66,6 +66,11 @@ struct lynx_ctx {
   size_t scratch_grad_bytes[3] = {0, 0, 0};
   ncclComm_t comm = nullptr;
   int comm_ranks = 0;
+  // the moment gather runs on a stream of its own, underneath the next streaming kernel (lynx_gather_moments)
+  hipStream_t s_comm = nullptr;
+  hipEvent_t ev_gather_in = nullptr, ev_gather_done[2] = {nullptr, nullptr};
+  unsigned gather_seq = 0;
+  bool comm_busy = false;  // s_comm may still be writing a gathered block: readers on the host wait for it
   // per-launch profiling of k_track (lynx_profile_begin / _end)
   bool profiling = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
@@ -226,7 +231,14 @@ int lynx_ctx_destroy(lynx_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->s_build);
   (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->s_comm) (void)hipStreamSynchronize(ctx->s_comm);
   if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
+  if (ctx->s_comm) {
+    (void)hipEventDestroy(ctx->ev_gather_in);
+    (void)hipEventDestroy(ctx->ev_gather_done[0]);
+    (void)hipEventDestroy(ctx->ev_gather_done[1]);
+    (void)hipStreamDestroy(ctx->s_comm);
+  }
   for (auto& kv : ctx->free_blocks) (void)hipFree(kv.second);
   for (auto& kv : ctx->live) (void)hipFree(kv.first);
   if (ctx->scratch_partials) (void)hipFree(ctx->scratch_partials);
@@ -264,10 +276,19 @@ int lynx_device_info(lynx_ctx* ctx, lynx_device_info_t* out) {
   return LYNX_OK;
 }
 
+// s_comm is the one stream whose work nothing on the main stream waits for by itself
+static int wait_for_gathers(lynx_ctx* ctx) {
+  if (ctx->comm_busy) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->s_comm));
+    ctx->comm_busy = false;
+  }
+  return LYNX_OK;
+}
+
 int lynx_sync(lynx_ctx* ctx) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  return LYNX_OK;
+  return wait_for_gathers(ctx);
 }
 
 int lynx_timer_start(lynx_ctx* ctx) {
@@ -328,6 +349,10 @@ int lynx_buf_h2d(lynx_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
 
 int lynx_buf_d2h(lynx_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
   if (bytes == 0) return LYNX_OK;
+  {
+    const int rc = wait_for_gathers(ctx);  // the block may be a gathered one
+    if (rc) return rc;
+  }
   HIP_TRY(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return LYNX_OK;
@@ -1336,6 +1361,8 @@ int lynx_comm_init(lynx_ctx* ctx, int n_ranks, int rank, const char* id) {
 
 int lynx_comm_destroy(lynx_ctx* ctx) {
   if (ctx && ctx->comm) {
+    if (ctx->s_comm) HIP_TRY(ctx, hipStreamSynchronize(ctx->s_comm));
+    ctx->comm_busy = false;
     NCCL_TRY(ctx, ncclCommDestroy(ctx->comm));
     ctx->comm = nullptr;
     ctx->comm_ranks = 0;
@@ -1363,7 +1390,32 @@ int lynx_comm_info(lynx_ctx* ctx, int32_t* rccl_version, int32_t* n_ranks, int32
 int lynx_gather_moments(lynx_ctx* ctx, const double* d_send, double* d_recv, int64_t count) {
   if (!ctx || !ctx->comm) return fail(ctx, LYNX_ERR_INVALID, "communicator not initialised");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  NCCL_TRY(ctx, ncclAllGather(d_send, d_recv, (size_t)count, ncclDouble, ctx->comm, ctx->stream));
+  if (env_int("LYNX_GATHER_OVERLAP", 0) == 0) {  // default: in line, on the main stream
+    NCCL_TRY(ctx, ncclAllGather(d_send, d_recv, (size_t)count, ncclDouble, ctx->comm, ctx->stream));
+    return LYNX_OK;
+  }
+  // LYNX_GATHER_OVERLAP=1.  The gather is latency (a few hundred KB over xGMI) and nothing on this GPU waits for
+  // its result but the host: it can run on a stream of its own, underneath the next call's streaming kernel,
+  // instead of between two of them.  Opt-in: on the one-GPU box (world size 1, scripts/gpu/r2_gather.sh) the
+  // in-line gather costs nothing measurable and the overlapped one 5-8 us of event traffic per step; whether it
+  // pays at 8 ranks can only be measured on a node this build has no access to.  Order: it starts when everything enqueued on the main stream so far has run (the records are
+  // final), and the main stream waits for the PREVIOUS gather before it goes on -- by then long finished -- so
+  // that no later kernel can be handed a block a gather still reads or writes.  The host sees the result through
+  // lynx_buf_d2h / lynx_sync, which wait for this stream.
+  if (!ctx->s_comm) {
+    int prio_low = 0, prio_high = 0;
+    HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+    HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->s_comm, hipStreamNonBlocking, prio_high));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_gather_in, hipEventDisableTiming));
+    for (int i = 0; i < 2; ++i) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_gather_done[i], hipEventDisableTiming));
+  }
+  const unsigned n = ctx->gather_seq++;
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_gather_in, ctx->stream));
+  HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_comm, ctx->ev_gather_in, 0));
+  NCCL_TRY(ctx, ncclAllGather(d_send, d_recv, (size_t)count, ncclDouble, ctx->comm, ctx->s_comm));
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_gather_done[n & 1], ctx->s_comm));
+  if (n > 0 && env_int("LYNX_GATHER_FENCE", 1)) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_gather_done[(n - 1) & 1], 0));
+  ctx->comm_busy = true;
   return LYNX_OK;
 }
 

@@ -114,15 +114,22 @@ class RcclCommunicator:
                 "rccl_rank": r.value}
 
     def all_gather(self, local: DeviceArray) -> DeviceArray:
-        """(rows, 36) float64 per rank -> (n_ranks, rows, 36) on every rank (async on the stream)."""
+        """
+        (rows, 36) float64 per rank -> (n_ranks, rows, 36) on every rank.  Asynchronous: enqueued on the main
+        stream (default) or, with `LYNX_GATHER_OVERLAP=1`, on the context's communication stream underneath
+        whatever is tracked next; reading the result (`np.asarray`, `rt.sync()`) waits for it either way.
+        """
         assert local.dtype == np.float64
         out = self.rt.empty((self.n_ranks, *local.shape), np.float64)
         self.rt.check(self.rt.lib.lynx_gather_moments(self.rt.ctx, C.c_void_p(local.ptr), C.c_void_p(out.ptr),
                                                       local.size))
+        # both blocks stay out of the allocator until the next gather has made the main stream wait for this one
+        self._in_flight = (local, out)
         return out
 
     def close(self):
         """Destroy the communicator (collective: every rank calls it).  No-op once the runtime is closed."""
         if not self.rt.closed and not getattr(self, "_closed", False):
             self._closed = True
-            self.rt.check(self.rt.lib.lynx_comm_destroy(self.rt.ctx))
+            self.rt.check(self.rt.lib.lynx_comm_destroy(self.rt.ctx))  # waits for the communication stream
+            self._in_flight = None
