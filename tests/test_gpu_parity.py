@@ -1033,11 +1033,15 @@ def test_c4_shard_linearity_fp32(lx):
     assert np.array_equal(alone[0], out[5])
 
 
-def test_rccl_communicator_single_rank(lx):
-    """The RCCL path of lynx_amd.parallel at world_size 1 (the only size a 1-GPU box allows)."""
+@pytest.mark.parametrize("overlap", ["0", "1"], ids=["main-stream", "communication-stream"])
+def test_rccl_communicator_single_rank(lx, overlap, monkeypatch):
+    """The RCCL path of lynx_amd.parallel at world_size 1 (the only size a 1-GPU box allows): the gather in line
+    on the main stream, and on the communication stream (LYNX_GATHER_OVERLAP=1) with tracking going on around it --
+    several gathers in flight, results read back afterwards."""
     from lynx_amd.device import get_runtime
     from lynx_amd.parallel import RcclCommunicator
 
+    monkeypatch.setenv("LYNX_GATHER_OVERLAP", overlap)
     rt = get_runtime()
     comm = RcclCommunicator(1, 0, lambda uid: uid, rt)
     try:
@@ -1045,6 +1049,14 @@ def test_rccl_communicator_single_rank(lx):
         out = comm.all_gather(local)
         assert out.shape == (1, 5, 36)
         assert np.array_equal(np.asarray(out)[0], np.asarray(local))
+        seg = lx.Segment([lx.Drift(np.full(4, 0.5, np.float32)), lx.Quadrupole(np.full(4, 0.2, np.float32), k1=np.full(4, 3.0, np.float32))])
+        beam = lx.ParticleBeam.synthetic((4,), 50_000, seed=3)
+        results = []
+        for _ in range(4):  # the host runs ahead: gathers queue up behind the tracking they belong to
+            beam = seg.track(beam)
+            results.append((beam, comm.all_gather(beam._moments.device(rt).reshape(4, 36))))
+        for tracked, gathered in results:
+            assert np.array_equal(np.asarray(gathered)[0], tracked.moment_record().reshape(4, 36), equal_nan=True)
     finally:
         comm.close()
 
