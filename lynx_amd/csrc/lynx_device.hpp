@@ -6,14 +6,16 @@
 //   lattice     elems[E], steps[S], elem_step[E] (int32) + parameter pool (T), see
 //               include/lynx_hip.h.
 //   step table  [B][S][64] T: per sample and step the composed 7x7 map (49), the cavity
-//               coefficients (8) and, in step 0, the moment reference point (7).  Written by
-//               k_build, read with scalar loads by the streaming kernel (in the optional
-//               fused variant it only ever lives in LDS).
-//   partials    [B][chunks][36] double: per-workgroup moment sums (deterministic
-//               two-stage reduction; no float atomics).
+//               coefficients (8), a merged pair's entry inverse (4), the step's descriptor (slot 62)
+//               and, in the last step, the outgoing energy (slot 63); lynx_maps.hpp.  Written by the
+//               builders (k_build, or k_build_pieces / k_pair_products / k_emit_steps for large
+//               batches), read with scalar loads by the streaming kernel (in the optional fused
+//               variant it only ever lives in LDS).
+//   partials    [B][chunks][36] double: per-workgroup moment records, each around a reference
+//               point of its own (deterministic reduction in k_reduce_moments; no float atomics).
 //
-// Wavefront = 64 everywhere; workgroups are 256 threads (4 waves) for the streaming and build
-// kernels, 64 or 256 threads for the per-sample moment kernels.
+// Wavefront = 64 everywhere; workgroups are 256 threads (4 waves) for the streaming kernel, 64 to
+// 1024 for the builders and the per-sample kernels.
 #pragma once
 
 #include <hip/hip_runtime.h>
