@@ -898,15 +898,7 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
     if ((rc = launch_build<T>(ctx, lat, bs, d_energy_in, ctx->scratch_steps[slot], nullptr, p.a.merged_pairs))) return rc;
     if (async) {
       HIP_TRY(ctx, hipEventRecord(ctx->ev_built[slot], bs));
-      // How the streaming kernel learns that its table is there.  A device-side wait on the event is a barrier
-      // packet in front of the kernel (~6 us on the main stream's critical path); for very large beams -- a
-      // streaming kernel of half a millisecond or more -- the HOST waits for the build instead, which was enqueued
-      // a whole call earlier and finishes ~0.2 ms into the previous call's kernel: the host then runs one call
-      // ahead of the GPU instead of many, which starves nothing, and the kernel starts without a barrier packet
-      // (BASELINE configs 4 and 5: step - kernel 29 -> 23 us; config 3, a 30-us kernel: 51 -> 69 us/step, hence
-      // the threshold; scripts/gpu/r2_hostwait.sh)
-      if (env_int("LYNX_HOST_WAIT_BUILD", B * N >= ((int64_t)32 << 20) ? 1 : 0)) HIP_TRY(ctx, hipEventSynchronize(ctx->ev_built[slot]));
-      else HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_built[slot], 0));
+      HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_built[slot], 0));
     }
     d_steps = ctx->scratch_steps[slot];
   }
