@@ -644,7 +644,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_build_bwd(LatticeDev lat, const T* __restrict__ energy_in,
                                                     T* tbar, T* __restrict__ scratch,
                                                     T* __restrict__ grad_params /* [B][E][8] */,
-                                                    T* __restrict__ grad_energy /* [B] */, int merged_pairs) {
+                                                    T* __restrict__ grad_energy /* [B] */, int merged_pairs,
+                                                    int maps_in_lds) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int E = lat.n_elems, S = lat.n_steps;
   T* s_energy = reinterpret_cast<T*>(smem_raw);  // [S+1]
@@ -656,23 +657,35 @@ __global__ __launch_bounds__(256) void k_build_bwd(LatticeDev lat, const T* __re
   const int tid = threadIdx.x;
   const int64_t b = blockIdx.x;
   const T* pool = static_cast<const T*>(lat.pool);
-  T* g_maps = scratch + b * (int64_t)(2 * E + S + 1) * 49;  // M_e
+  // The element maps and prefix products are walked in a chain of small dependent steps (49 threads, one 7-term
+  // product each, a barrier in between): kept in LDS when they fit (maps_in_lds; BASELINE config 5: 16 KB),
+  // every hop is an LDS round trip instead of one to L2 -- the kernel was latency-bound on exactly that
+  // (0.88 -> 0.3 ms).  Long lattices (a 1051-element one needs 412 KB) keep them in the HBM scratch.
+  T* g_maps = maps_in_lds ? s_t + 49 : scratch + b * (int64_t)(2 * E + S + 1) * 49;  // M_e
   // prefix products of step s live in slots [first+s .. last+s]: slot(first+s) = start
   // (identity), slot(e+s+1) = M_e ... M_first; the reverse sweep then overwrites slot(e+s+1)
   // with M_bar_e.  (The +s keeps neighbouring steps from sharing a slot.)
   T* g_pref = g_maps + (int64_t)E * 49;
 
-  // energies (same walk as the forward build)
+  // energies (same walk as the forward build).  The steps' energy gains are fetched by one thread per step --
+  // lattice tables and parameters sit behind two dependent loads from memory, which the serial walk used to pay
+  // step after step -- and the walk itself only adds them up.
+  if (tid < S) {
+    const lynx_step st = lat.steps[tid];
+    T gain = T(0);
+    if (st.kind == LYNX_STEP_CAVITY && (st.flags & LYNX_FLAG_CAV_GAIN)) {
+      const lynx_elem el = lat.elems[st.first];
+      const T* p = pool + el.param_offset + b * (int64_t)el.batch_stride;
+      gain = p[1] * t_cos(p[2] * T(LYNX_PI / 180.0));
+    }
+    s_ebar[tid] = gain;  // parked here until the walk has used it
+  }
+  __syncthreads();
   if (tid == 0) {
     T e = energy_in[b];
     for (int s = 0; s < S; ++s) {
       s_energy[s] = e;
-      lynx_step st = lat.steps[s];
-      if (st.kind == LYNX_STEP_CAVITY && (st.flags & LYNX_FLAG_CAV_GAIN)) {
-        lynx_elem el = lat.elems[st.first];
-        const T* p = pool + el.param_offset + b * (int64_t)el.batch_stride;
-        e = e + p[1] * t_cos(p[2] * T(LYNX_PI / 180.0));
-      }
+      e = e + s_ebar[s];  // same operation as `e + V cos(phi)` in the forward build; zero for every other step
     }
     s_energy[S] = e;
     for (int s = 0; s <= S; ++s) s_ebar[s] = T(0);
@@ -820,23 +833,36 @@ __global__ __launch_bounds__(256) void k_build_bwd(LatticeDev lat, const T* __re
   }
   __syncthreads();
 
-  // 4. energy cotangent: sum per step, then back through the cavities' energy gains
+  // 4. energy cotangent: sum per step (one thread per step over its elements, in element order), the carries by a
+  //    serial walk over the S sums, then back through the cavities' energy gains (one thread per step again)
+  if (tid < S) {
+    const lynx_step st = lat.steps[tid];
+    T sum = T(0);
+    for (int e = st.first; e < st.last; ++e) sum += s_econ[e];
+    s_ebar[tid] = sum;
+  }
+  __syncthreads();
   if (tid == 0) {
-    for (int e = 0; e < E; ++e) s_ebar[lat.elem_step[e]] += s_econ[e];
     T carry = T(0);  // cotangent of the energy leaving step s
     for (int s = S - 1; s >= 0; --s) {
-      const lynx_step st = lat.steps[s];
-      if (st.kind == LYNX_STEP_CAVITY && (st.flags & LYNX_FLAG_CAV_GAIN)) {
-        lynx_elem el = lat.elems[st.first];
-        const T* p = pool + el.param_offset + b * (int64_t)el.batch_stride;
-        const T phi = p[2] * T(LYNX_PI / 180.0);
-        T* gp = grad_params + (b * E + st.first) * (int64_t)kGradParams;
-        gp[1] += carry * t_cos(phi);                                   // dE_out/dV
-        gp[2] += carry * (-p[1] * t_sin(phi)) * T(LYNX_PI / 180.0);    // dE_out/dphase[deg]
-      }
-      carry += s_ebar[s];
+      const T own = s_ebar[s];
+      s_ebar[s] = carry;
+      carry += own;
     }
     grad_energy[b] = carry;
+  }
+  __syncthreads();
+  if (tid < S) {
+    const lynx_step st = lat.steps[tid];
+    if (st.kind == LYNX_STEP_CAVITY && (st.flags & LYNX_FLAG_CAV_GAIN)) {
+      const T carry = s_ebar[tid];
+      const lynx_elem el = lat.elems[st.first];
+      const T* p = pool + el.param_offset + b * (int64_t)el.batch_stride;
+      const T phi = p[2] * T(LYNX_PI / 180.0);
+      T* gp = grad_params + (b * E + st.first) * (int64_t)kGradParams;
+      gp[1] += carry * t_cos(phi);                                   // dE_out/dV
+      gp[2] += carry * (-p[1] * t_sin(phi)) * T(LYNX_PI / 180.0);    // dE_out/dphase[deg]
+    }
   }
 }
 

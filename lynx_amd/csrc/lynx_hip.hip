@@ -1054,11 +1054,15 @@ static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const v
   hipLaunchKernelGGL(k_reduce_tbar<T>, dim3((unsigned)(B * S)), dim3(64), 0, ctx->stream, (const T*)ctx->scratch_grad[0],
                      (int)chunks, (int)S, (T*)ctx->scratch_grad[1]);
   HIP_TRY(ctx, hipGetLastError());
-  const size_t lds2 = ((size_t)2 * (S + 1) + E + 49 + 49) * sizeof(T);
+  size_t lds2 = ((size_t)2 * (S + 1) + E + 49 + 49) * sizeof(T);
+  const size_t maps_bytes = (size_t)(2 * E + S + 1) * 49 * sizeof(T);
+  const int maps_in_lds = lds2 + maps_bytes <= (size_t)env_int("LYNX_BWD_MAPS_LDS_KB", 40) * 1024;
+  if (maps_in_lds) lds2 += maps_bytes;
   if ((rc = allow_lds(ctx, k_build_bwd<T>, lds2))) return rc;
   HIP_TRY(ctx, hipMemsetAsync(d_grad_params, 0, (size_t)B * E * kGradParams * sizeof(T), ctx->stream));
   hipLaunchKernelGGL(k_build_bwd<T>, dim3((unsigned)B), dim3(256), lds2, ctx->stream, lv, (const T*)d_energy_in,
-                     (T*)ctx->scratch_grad[1], (T*)ctx->scratch_grad[2], (T*)d_grad_params, (T*)d_grad_energy_in, merged);
+                     (T*)ctx->scratch_grad[1], (T*)ctx->scratch_grad[2], (T*)d_grad_params, (T*)d_grad_energy_in, merged,
+                     maps_in_lds);
   HIP_TRY(ctx, hipGetLastError());
   return LYNX_OK;
 }
@@ -1103,11 +1107,15 @@ static int moments_backward_t(lynx_ctx* ctx, lynx_lattice* lat, const void* d_en
                      (const T*)d_mu_in, (const T*)d_cov_in, (const T*)d_mu_bar, (const T*)d_cov_bar,
                      (T*)ctx->scratch_grad[0], (T*)ctx->scratch_grad[1], (T*)d_grad_mu_in, (T*)d_grad_cov_in);
   HIP_TRY(ctx, hipGetLastError());
-  const size_t lds2 = ((size_t)2 * (S + 1) + E + 49 + 49) * sizeof(T);
+  size_t lds2 = ((size_t)2 * (S + 1) + E + 49 + 49) * sizeof(T);
+  const size_t maps_bytes = (size_t)(2 * E + S + 1) * 49 * sizeof(T);
+  const int maps_in_lds = lds2 + maps_bytes <= (size_t)env_int("LYNX_BWD_MAPS_LDS_KB", 40) * 1024;
+  if (maps_in_lds) lds2 += maps_bytes;
   if ((rc = allow_lds(ctx, k_build_bwd<T>, lds2))) return rc;
   HIP_TRY(ctx, hipMemsetAsync(d_grad_params, 0, (size_t)B * E * kGradParams * sizeof(T), ctx->stream));
   hipLaunchKernelGGL(k_build_bwd<T>, dim3((unsigned)B), dim3(256), lds2, ctx->stream, lv, (const T*)d_energy_in,
-                     (T*)ctx->scratch_grad[1], (T*)ctx->scratch_grad[2], (T*)d_grad_params, (T*)d_grad_energy_in, 0);
+                     (T*)ctx->scratch_grad[1], (T*)ctx->scratch_grad[2], (T*)d_grad_params, (T*)d_grad_energy_in, 0,
+                     maps_in_lds);
   HIP_TRY(ctx, hipGetLastError());
   return LYNX_OK;
 }
