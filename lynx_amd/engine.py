@@ -22,6 +22,29 @@ from .device import Dual, dtype_code, get_runtime
 
 ELECTRON_MASS_EV = 510998.95069  # cavity.py:20
 
+_LATE = None
+
+
+def _late():
+    """
+    What the engine needs from modules that import the engine themselves, bound on first use.  (As `from ... import`
+    statements inside `track` and friends they cost seven import-system look-ups per call -- a fifth of the host
+    time of a ParameterBeam `track`, which is bound by the host's enqueue rate.)
+    """
+    global _LATE
+    if _LATE is None:
+        from types import SimpleNamespace
+
+        from .accelerator.element import EPOCH, STRUCTURE
+        from .accelerator.segment import Segment
+        from .particles.beam import Beam
+        from .particles.parameter_beam import ParameterBeam
+        from .particles.particle_beam import ParticleBeam
+
+        _LATE = SimpleNamespace(EPOCH=EPOCH, STRUCTURE=STRUCTURE, Segment=Segment, Beam=Beam,
+                                ParameterBeam=ParameterBeam, ParticleBeam=ParticleBeam)
+    return _LATE
+
 
 # -------------------------------------------------------------------------------------------
 # program = what Segment.track iterates over
@@ -29,6 +52,7 @@ ELECTRON_MASS_EV = 510998.95069  # cavity.py:20
 
 
 @dataclass
+
 class Program:
     """A maximal stretch of the lattice one kernel launch can run: runs + active cavities."""
 
@@ -70,7 +94,7 @@ def partition(elements, fuse_observers: bool = False) -> list:
     starts and ends a run; a nested skippable Segment's elements join the current run (the
     reference multiplies its pre-composed product instead: same map up to rounding).
     """
-    from .accelerator.segment import Segment  # cycle-free at call time
+    Segment = _late().Segment
 
     out: list = []
     state = {"new_run": True}
@@ -120,8 +144,8 @@ def plan(owner, elements, raw: bool, fuse_observers: bool = False) -> list:
     objects: a tracking loop then costs one C-level pass over the list instead of Python work
     per element, also when magnet strengths are rewritten between the calls.
     """
-    from .accelerator.element import STRUCTURE
-    from .accelerator.segment import Segment
+    late = _late()
+    STRUCTURE, Segment = late.STRUCTURE, late.Segment
 
     def identities(items):
         ids = tuple(map(id, items))
@@ -296,8 +320,7 @@ class LatticeCache:
         self._last = None
 
     def get(self, program: Program, batch_shape, dtype) -> PackedLattice:
-        from .accelerator.element import EPOCH
-
+        EPOCH = _late().EPOCH
         shape_key = (tuple(batch_shape), np.dtype(dtype).str, program.raw)
         last = self._last
         if last is not None and last[0] is program and last[1] == EPOCH[0] and last[2] == shape_key:
@@ -339,8 +362,7 @@ def _ptr(x):
 
 def run_program_particles(cache, program: Program, beam, moments: bool | None = None):
     """One launch of the fused kernel: ParticleBeam -> ParticleBeam."""
-    from .particles.particle_beam import ParticleBeam
-
+    ParticleBeam = _late().ParticleBeam
     rt = get_runtime()
     dtype = beam.dtype
     batch_shape = beam.batch_shape
@@ -371,8 +393,7 @@ def run_program_particles(cache, program: Program, beam, moments: bool | None = 
 
 def run_program_parameters(cache, program: Program, beam):
     """ParameterBeam -> ParameterBeam (lynx_track_moments)."""
-    from .particles.parameter_beam import ParameterBeam
-
+    ParameterBeam = _late().ParameterBeam
     rt = get_runtime()
     dtype = beam.dtype
     batch_shape = beam.batch_shape
@@ -393,10 +414,8 @@ def run_program_parameters(cache, program: Program, beam):
 
 def track(owner, elements, incoming, raw: bool = False):
     """`Segment.track` (raw=False) / `Element.track` (raw=True) for both beam types."""
-    from .particles.beam import Beam
-    from .particles.parameter_beam import ParameterBeam
-    from .particles.particle_beam import ParticleBeam
-
+    late = _late()
+    Beam, ParameterBeam, ParticleBeam = late.Beam, late.ParameterBeam, late.ParticleBeam
     if incoming is Beam.empty:
         for el in elements:
             if getattr(el, "_host_barrier", False):
