@@ -1033,6 +1033,35 @@ def test_c4_shard_linearity_fp32(lx):
     assert np.array_equal(alone[0], out[5])
 
 
+@pytest.mark.parametrize("dtype,n", [(np.float32, 300_000), (np.float32, 70_001), (np.float64, 200_003)])
+def test_tracking_in_place_through_the_c_abi(lx, dtype, n):
+    """
+    include/lynx_hip.h: `d_p_in` and `d_p_out` of lynx_track_particles may alias.  Wave tiles (every wave reads a
+    tile, prefetches the next and writes the first back) and per-particle accesses, full and cut tiles: tracking
+    a copy of the beam in place gives the bytes of the out-of-place call.
+    """
+    import ctypes as C
+
+    from lynx_amd import _ffi, engine
+    from lynx_amd.device import get_runtime
+
+    rt = get_runtime()
+    B = 3
+    f = lambda v: np.full(B, v, dtype=dtype)  # noqa: E731
+    seg = lx.Segment([lx.Drift(f(0.4), dtype=dtype), lx.Quadrupole(f(0.2), k1=np.asarray([4.0, -3.0, 0.5], dtype), dtype=dtype),
+                      lx.Drift(f(0.7), dtype=dtype)])
+    beam = lx.ParticleBeam.synthetic((B,), n, seed=4, dtype=dtype, sigma=[1e-4, 1e-5, 1e-4, 1e-5, 1e-4, 1e-3])
+    expected = np.asarray(seg.track(beam).particles)
+    program, = engine.plan(seg, seg.elements, False, fuse_observers=True)
+    lat = engine._ready(seg.__dict__["_lattice_cache"], program, (B,), np.dtype(dtype), beam._energy._host)
+    work = rt.to_device(np.asarray(beam.particles))
+    e_in = beam._energy.broadcast_device(rt, (B,))
+    mom = rt.empty((B, _ffi.MOMENT_STRIDE), np.float64)
+    rt.check(rt.lib.lynx_track_particles(rt.ctx, lat.handle, n, C.c_void_p(e_in.ptr), C.c_void_p(work.ptr),
+                                         C.c_void_p(work.ptr), None, C.c_void_p(mom.ptr), _ffi.TRACK_MOMENTS, None))
+    assert np.array_equal(np.asarray(work), expected)
+
+
 @pytest.mark.parametrize("overlap", ["0", "1"], ids=["main-stream", "communication-stream"])
 def test_rccl_communicator_single_rank(lx, overlap, monkeypatch):
     """The RCCL path of lynx_amd.parallel at world_size 1 (the only size a 1-GPU box allows): the gather in line
