@@ -1185,6 +1185,27 @@ def test_lazily_broadcast_beam_tracks_like_the_repeated_one(lx, dtype):
     assert shared.is_shared  # the copy was written to, not the original
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_lazily_broadcast_beam_through_wave_tiles(lx, dtype):
+    """The same on the streaming kernel's wave-tile form (one composed map, enough particles for whole tiles plus
+    a cut one): every sample reads the ONE stored beam (sample stride 0) and writes its own."""
+    shape = (8,)
+    single = lx.ParticleBeam.synthetic((1,), 150_001, seed=6, dtype=dtype, sigma=[1e-4, 1e-5, 1e-4, 1e-5, 1e-4, 1e-3])
+    shared = single.broadcast(shape)
+    lx.config.lazy_broadcast = False
+    try:
+        repeated = single.broadcast(shape)
+    finally:
+        lx.config.lazy_broadcast = True
+    assert shared.is_shared and not repeated.is_shared
+    f = lambda v: np.full(shape, v, dtype)  # noqa: E731
+    seg = lx.Segment([lx.Drift(f(0.3)), lx.Quadrupole(f(0.2), k1=np.linspace(-5, 5, 8).astype(dtype)), lx.Drift(f(0.4))])
+    a, b = seg.track(shared), seg.track(repeated)
+    assert not a.is_shared
+    assert np.array_equal(np.asarray(a.particles), np.asarray(b.particles))
+    assert np.array_equal(a.moment_record(), b.moment_record(), equal_nan=True)
+
+
 @pytest.mark.parametrize("packed", [0, 1])
 def test_device_phase_trig_accuracy(lx, packed):
     """
