@@ -1422,7 +1422,7 @@ int lynx_gather_moments(lynx_ctx* ctx, const double* d_send, double* d_recv, int
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_comm, ctx->ev_gather_in, 0));
   NCCL_TRY(ctx, ncclAllGather(d_send, d_recv, (size_t)count, ncclDouble, ctx->comm, ctx->s_comm));
   HIP_TRY(ctx, hipEventRecord(ctx->ev_gather_done[n & 1], ctx->s_comm));
-  if (n > 0 && env_int("LYNX_GATHER_FENCE", 1)) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_gather_done[(n - 1) & 1], 0));
+  if (n > 0) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_gather_done[(n - 1) & 1], 0));
   ctx->comm_busy = true;
   return LYNX_OK;
 }

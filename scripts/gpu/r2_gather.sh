@@ -1,14 +1,12 @@
 #!/bin/bash
-# RCCL all-gather of the moment records at world size 1 (LYNX_FORCE_COMM=1): on the communication stream underneath the next
-# streaming kernel (default) vs in line on the main stream (LYNX_GATHER_OVERLAP=0); LYNX_GATHER_FENCE=0 drops the main
-# stream's wait for the previous gather (measures what that ordering costs).
+# RCCL all-gather of the moment records at world size 1 (LYNX_FORCE_COMM=1): in line on the main stream (default) vs on the
+# communication stream underneath the next streaming kernel (LYNX_GATHER_OVERLAP=1).
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/r2gather; rm -rf $OUT; mkdir -p $OUT
 timeout -k 10 600 python -m pytest tests -m gpu -q -k "rccl or comm or gather" > $OUT/pytest.log 2>&1; echo "pytest rc $?"; tail -2 $OUT/pytest.log
 for i in 1 2; do
 timeout -k 10 200 python bench.py --no-cpu-baseline --steps 20 > $OUT/nocomm_$i.json 2> $OUT/nocomm_$i.err
-LYNX_FORCE_COMM=1 timeout -k 10 200 python bench.py --no-cpu-baseline --steps 20 > $OUT/overlap_$i.json 2> $OUT/overlap_$i.err
-LYNX_FORCE_COMM=1 LYNX_GATHER_FENCE=0 timeout -k 10 200 python bench.py --no-cpu-baseline --steps 20 > $OUT/overlap_nofence_$i.json 2> $OUT/overlap_nofence_$i.err
+LYNX_FORCE_COMM=1 LYNX_GATHER_OVERLAP=1 timeout -k 10 200 python bench.py --no-cpu-baseline --steps 20 > $OUT/overlap_$i.json 2> $OUT/overlap_$i.err
 LYNX_FORCE_COMM=1 LYNX_GATHER_OVERLAP=0 timeout -k 10 200 python bench.py --no-cpu-baseline --steps 20 > $OUT/inline_$i.json 2> $OUT/inline_$i.err
 done
 python3 - <<'PY'
