@@ -29,6 +29,8 @@ namespace lynx {
 
 constexpr int kGradStride = 64;   // per (sample, step): 49 T_bar + 8 coef_bar + padding
 constexpr int kGradParams = 8;    // gradient slots per element (kinds with <= 8 parameters)
+// k_build_bwd's kind-sorted task list: every (element, parameter or energy) pair + one wave of padding per kind
+__host__ __device__ constexpr int bwd_task_capacity(int n_elems) { return n_elems * (kGradParams + 1) + 13 * 64; }
 
 constexpr int kBwdGroup = 4;
 constexpr int kBwdMaxGroups = 16;  // => at most 64 units
@@ -784,25 +786,68 @@ __global__ __launch_bounds__(256) void k_build_bwd(LatticeDev lat, const T* __re
   }
 
   // 3. theta_bar = <M_bar, dM/dtheta> (+ <coef_bar, dcoef/dtheta>) by dual evaluation; one task
-  //    per (element, parameter), parameter index np = derivative w.r.t. the step energy
-  for (int task = tid; task < E * (kGradParams + 1); task += blockDim.x) {
-    const int e = task / (kGradParams + 1), pidx = task % (kGradParams + 1);
-    lynx_elem el = lat.elems[e];
-    int np = 0;
-    switch (el.kind) {
-      case LYNX_KIND_DRIFT: np = 1; break;
-      case LYNX_KIND_QUADRUPOLE: np = 5; break;
-      case LYNX_KIND_DIPOLE: np = 8; break;
+  //    per (element, parameter), parameter index np = derivative w.r.t. the step energy.
+  //    A task evaluates its element's builder on dual numbers: a wave whose lanes hold elements of different
+  //    kinds runs every one of those builders one after the other.  With the maps in LDS (short lattices) the
+  //    tasks are therefore listed kind by kind, each kind padded to whole waves -- a wave then runs ONE builder,
+  //    the kinds run side by side on different waves, and slots of parameters a kind does not have do not
+  //    exist (BASELINE config 5: 120 tasks of 3 kinds instead of 288 slots over mixed waves).
+  const auto kind_params = [](int kind) {
+    switch (kind) {
+      case LYNX_KIND_DRIFT: return 1;
+      case LYNX_KIND_QUADRUPOLE: return 5;
+      case LYNX_KIND_DIPOLE: return 8;
       case LYNX_KIND_HCOR:
-      case LYNX_KIND_VCOR: np = 2; break;
-      case LYNX_KIND_CAVITY: np = 4; break;
-      case LYNX_KIND_BASE_RMATRIX: np = 4; break;
-      case LYNX_KIND_ROTATION: np = 1; break;
-      case LYNX_KIND_MISALIGNMENT: np = 3; break;
-      case LYNX_KIND_SOLENOID: np = 4; break;
-      case LYNX_KIND_UNDULATOR: np = 1; break;
-      default: np = 0; break;  // identity; custom maps carry no differentiable parameters here
+      case LYNX_KIND_VCOR: return 2;
+      case LYNX_KIND_CAVITY: return 4;
+      case LYNX_KIND_BASE_RMATRIX: return 4;
+      case LYNX_KIND_ROTATION: return 1;
+      case LYNX_KIND_MISALIGNMENT: return 3;
+      case LYNX_KIND_SOLENOID: return 4;
+      case LYNX_KIND_UNDULATOR: return 1;
+      default: return 0;  // identity; custom maps carry no differentiable parameters here
     }
+  };
+  unsigned short* s_task = reinterpret_cast<unsigned short*>(g_pref + (int64_t)(E + S + 1) * 49);  // sorted list (maps_in_lds)
+  unsigned short* s_kind = s_task + bwd_task_capacity(E);                                            // [E]
+  __shared__ int s_ntasks;
+  int n_tasks = E * (kGradParams + 1);
+  if (maps_in_lds) {
+    for (int e = tid; e < E; e += blockDim.x) {
+      s_kind[e] = (unsigned short)lat.elems[e].kind;
+      s_econ[e] = T(0);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int n = 0;
+      for (int k = 1; k <= LYNX_KIND_UNDULATOR; ++k) {
+        const int np = kind_params(k);
+        if (np == 0) continue;
+        const int first = n;
+        for (int e = 0; e < E; ++e)
+          if (s_kind[e] == k)
+            for (int q = 0; q <= np; ++q) s_task[n++] = (unsigned short)(e * 16 + (q == np ? kGradParams : q));
+        if (n > first)
+          while (n & 63) s_task[n++] = 0xffffu;  // a wave never mixes kinds
+      }
+      s_ntasks = n;
+    }
+    __syncthreads();
+    n_tasks = s_ntasks;
+  }
+  for (int task = tid; task < n_tasks; task += blockDim.x) {
+    int e, pidx;
+    if (maps_in_lds) {
+      const unsigned code = s_task[task];
+      if (code == 0xffffu) continue;
+      e = (int)(code >> 4);
+      pidx = (int)(code & 15u);
+    } else {
+      e = task / (kGradParams + 1);
+      pidx = task % (kGradParams + 1);
+    }
+    lynx_elem el = lat.elems[e];
+    const int np = kind_params(el.kind);
     const bool energy_task = pidx == kGradParams;
     T g = T(0);
     if ((pidx < np || energy_task) && np > 0) {

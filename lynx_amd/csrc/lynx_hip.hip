@@ -1057,8 +1057,9 @@ static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const v
                      (int)chunks, (int)S, (T*)ctx->scratch_grad[1]);
   HIP_TRY(ctx, hipGetLastError());
   size_t lds2 = ((size_t)2 * (S + 1) + E + 49 + 49) * sizeof(T);
-  const size_t maps_bytes = (size_t)(2 * E + S + 1) * 49 * sizeof(T);
-  const int maps_in_lds = lds2 + maps_bytes <= (size_t)env_int("LYNX_BWD_MAPS_LDS_KB", 40) * 1024;
+  // maps + prefix products, then the kind-sorted task list and the elements' kinds (unsigned short each)
+  const size_t maps_bytes = (size_t)(2 * E + S + 1) * 49 * sizeof(T) + ((size_t)bwd_task_capacity(E) + E) * sizeof(unsigned short);
+  const int maps_in_lds = E < 4096 && lds2 + maps_bytes <= (size_t)env_int("LYNX_BWD_MAPS_LDS_KB", 40) * 1024;
   if (maps_in_lds) lds2 += maps_bytes;
   if ((rc = allow_lds(ctx, k_build_bwd<T>, lds2))) return rc;
   HIP_TRY(ctx, hipMemsetAsync(d_grad_params, 0, (size_t)B * E * kGradParams * sizeof(T), ctx->stream));
@@ -1110,8 +1111,9 @@ static int moments_backward_t(lynx_ctx* ctx, lynx_lattice* lat, const void* d_en
                      (T*)ctx->scratch_grad[0], (T*)ctx->scratch_grad[1], (T*)d_grad_mu_in, (T*)d_grad_cov_in);
   HIP_TRY(ctx, hipGetLastError());
   size_t lds2 = ((size_t)2 * (S + 1) + E + 49 + 49) * sizeof(T);
-  const size_t maps_bytes = (size_t)(2 * E + S + 1) * 49 * sizeof(T);
-  const int maps_in_lds = lds2 + maps_bytes <= (size_t)env_int("LYNX_BWD_MAPS_LDS_KB", 40) * 1024;
+  // maps + prefix products, then the kind-sorted task list and the elements' kinds (unsigned short each)
+  const size_t maps_bytes = (size_t)(2 * E + S + 1) * 49 * sizeof(T) + ((size_t)bwd_task_capacity(E) + E) * sizeof(unsigned short);
+  const int maps_in_lds = E < 4096 && lds2 + maps_bytes <= (size_t)env_int("LYNX_BWD_MAPS_LDS_KB", 40) * 1024;
   if (maps_in_lds) lds2 += maps_bytes;
   if ((rc = allow_lds(ctx, k_build_bwd<T>, lds2))) return rc;
   HIP_TRY(ctx, hipMemsetAsync(d_grad_params, 0, (size_t)B * E * kGradParams * sizeof(T), ctx->stream));
