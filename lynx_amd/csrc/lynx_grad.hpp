@@ -105,6 +105,43 @@ __device__ __forceinline__ double lane_value(double v, int l) {
   const int lo = __builtin_amdgcn_readlane((int)bits, l), hi = __builtin_amdgcn_readlane((int)(bits >> 32), l);
   return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
+// Wave sums of EIGHT values at once: lane c (c < 8) ends up with the sum of v[c] over the 64 lanes.  Three
+// halving steps over lane bits 0, 1, 2 -- a lane keeps the half of its values whose index bit matches its lane bit
+// and hands the other half to its partner, which keeps exactly those -- leave every lane with ONE value, the sum
+// over its aligned group of 8 lanes of v[lane & 7]; lane bits 3, 4, 5 then take one row rotation and two
+// ds_bpermute.  ~30 VALU instructions where eight separate butterflies cost ~100 (float only).
+template <int CTRL, int BANK_MASK> __device__ __forceinline__ float dpp_take_banks(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL,
+                                                                0xF, BANK_MASK, false));
+}
+__device__ __forceinline__ float sum_eight_over_wave(const float (&v)[8], int lane) {
+  const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0, b2 = (lane & 4) != 0;
+  float a[4], g[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {  // bit 0: partner lane ^ 1 (quad_perm [1,0,3,2]); keeps index 2k + b0
+    a[k] = b0 ? v[2 * k + 1] : v[2 * k];
+    g[k] = b0 ? v[2 * k] : v[2 * k + 1];
+    a[k] += dpp_take<0xB1>(g[k]);
+  }
+  float c2[2], g2[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {  // bit 1: partner lane ^ 2 (quad_perm [2,3,0,1]); index 4k + 2 b1 + b0
+    c2[k] = b1 ? a[2 * k + 1] : a[2 * k];
+    g2[k] = b1 ? a[2 * k] : a[2 * k + 1];
+    c2[k] += dpp_take<0x4E>(g2[k]);
+  }
+  // bit 2: partner lane ^ 4 = row_shl:4 for banks 0 and 2 of a row, row_shr:4 for banks 1 and 3
+  float one = b2 ? c2[1] : c2[0];
+  const float give = b2 ? c2[0] : c2[1];
+  float got = dpp_take_banks<0x104, 0x5>(0.f, give);   // row_shl:4 -> lanes with bit 2 clear read lane + 4
+  got = dpp_take_banks<0x114, 0xA>(got, give);         // row_shr:4 -> lanes with bit 2 set read lane - 4
+  one += got;
+  one += dpp_take<0x128>(one);                          // bit 3: row_ror:8 = lane ^ 8 within the row of 16
+  one += __shfl_xor(one, 16, 64);                       // bits 4, 5: the four rows
+  one += __shfl_xor(one, 32, 64);
+  return one;  // lanes with (lane & 7) == c hold the total of v[c]
+}
+
 template <typename T> __device__ __forceinline__ T sum_over_wave(T v) {
   v = sum_over_8_lanes(v);
   v += dpp_take<0x140>(v);
@@ -417,10 +454,17 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
           if (kick) {
             // coefficient cotangents that did not travel through the buffer: DPP wave sums
             T rest = T(0);
+            if constexpr (!kCoefRows && std::is_same<T, float>::value) {
+              float each[8];  // all eight at once (sum_eight_over_wave): lane c < 8 receives the total of cc[c]
 #pragma unroll
-            for (int c = kCoefRows ? 7 : 0; c < 8; ++c) {
-              const T total = sum_over_wave(zhsum(cc[c]));
-              rest = (lane == c) ? total : rest;
+              for (int c = 0; c < 8; ++c) each[c] = zhsum(cc[c]);
+              rest = sum_eight_over_wave(each, lane);
+            } else {
+#pragma unroll
+              for (int c = kCoefRows ? 7 : 0; c < 8; ++c) {
+                const T total = sum_over_wave(zhsum(cc[c]));
+                rest = (lane == c) ? total : rest;
+              }
             }
             if (lane >= (kCoefRows ? 7 : 0) && lane < 8) acc[s * 64 + 49 + lane] += rest;
           }
