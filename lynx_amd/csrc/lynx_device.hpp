@@ -1311,8 +1311,18 @@ __device__ __forceinline__ void apply_program_lane(const LatticeDev& lat, int S,
   }
 }
 
+// Occupancy asked of the compiler: wave tiles 3 waves/SIMD (their sweet spot: 4 and 5 ran 10 % slower, DESIGN.md
+// section 7); the packed-pair form of multi-step float32 programs 5 (96 VGPRs, 32 bytes of scratch outside the step
+// loop): those wait on scalar fetches of the step table, and a fifth wave hides more of that (BASELINE config 5:
+// 0.985 -> 0.961 ms; 6 waves spill into the loop: 1.07).
+template <typename T, int MOM, bool FULL, int UNROLL, bool FUSED, bool XPOSE> constexpr int track_waves_per_simd() {
+  if (XPOSE) return 3;
+  if (sizeof(T) == 4 && UNROLL == 2 && !FUSED && !FULL && (MOM == 0 || MOM == 3)) return 5;
+  return 1;
+}
+
 template <typename T, int MOM, bool FULL, int UNROLL, bool FUSED, bool XPOSE>
-__global__ __launch_bounds__(kTrackThreads, (XPOSE ? 3 : 1)) void k_track_direct(
+__global__ __launch_bounds__(kTrackThreads, (track_waves_per_simd<T, MOM, FULL, UNROLL, FUSED, XPOSE>())) void k_track_direct(
     LatticeDev lat, TrackArgs a, const T* __restrict__ energy_in, const T* p_in, T* p_out,
     T* __restrict__ energy_out, const T* __restrict__ steps_in, double* __restrict__ partials,
     double* __restrict__ obs_partials) {
