@@ -3,7 +3,8 @@
 Benchmark of the hot path: `Segment.track()` on a `ParticleBeam`, fused output moments
 included, on synthetic lattices/beams of the shapes BASELINE.json names.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torchrun)
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (same thing)
 
 A "step" is one `segment.track(beam)` over the whole per-GPU batch: the launch that builds +
 composes every sample's element maps, the launch that streams the particles through them
@@ -11,17 +12,24 @@ composes every sample's element maps, the launch that streams the particles thro
 all-gather of the per-sample moment records.
 Particles, lattice parameters and outputs are resident in HBM when the timed region starts.
 
-N > 1: one process per GPU (torchrun only LAUNCHES them: RANK / LOCAL_RANK / WORLD_SIZE /
-MASTER_* from the environment); rendezvous, barriers and the max over ranks go over
-`lynx_amd.rendezvous` (standard-library sockets) and the data exchange over RCCL -- the process
-never imports torch.  If the RCCL communicator cannot be built the run prints a line with
-`"value": null` and exits 3 (`--allow-host-gather` turns that into a host gather that says so).
+N > 1: one process per GPU.  Started plainly (`WORLD_SIZE` not in the environment) this process
+becomes the LAUNCHER: it starts N fresh children of itself with RANK / LOCAL_RANK / WORLD_SIZE and a
+shared rendezvous key BEFORE anything touches the GPU, lets rank 0 print the JSON line and leaves with
+the worst child's exit code.  Under torchrun the ranks already exist and are used as they are.
+Rendezvous, barriers and the max over ranks go over `lynx_amd.rendezvous` (standard-library
+sockets) and the data exchange over RCCL -- the process never imports torch.  If the RCCL
+communicator cannot be built the run prints a line with `"value": null` and exits 3
+(`--allow-host-gather` turns that into a host gather that says so).
 
 Workload (default `c4`): BASELINE.json config 4, the configuration the metric's target is
 quoted on ("1024-batch x 100k-particle x 128-element lattice"): 1024 lattice-parameter
 samples (k1 scan) x 128-element FODO x 100 000 particles, fp32 -- 5.73 GB of algorithmic
-traffic per step, it fits one GPU.  Scaling is weak: every GPU tracks its own 1024
-samples (global batch 1024 N), no particle ever crosses xGMI.
+traffic per step, it fits one GPU.  Scaling is STRONG, as BASELINE config 4 is worded ("1024
+lattice-parameter batches ... sharded over 8 x MI355X"): the ONE 1024-sample scan is split in
+contiguous slices, GPU g tracks samples [128 g, 128 (g + 1)) at N = 8 (SURVEY.md section 8d/e;
+`lynx_amd.parallel.shard_batch`), no particle ever crosses xGMI, the moment records are
+all-gathered.  One-sample workloads (c3) split the particles instead.  `--weak` gives every GPU
+the whole per-GPU workload (global batch 1024 N).
 
 Prints ONE JSON line on rank 0.
 """
@@ -45,7 +53,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s s
 WORKLOADS = {
     # name: (batch per GPU, particles, FODO cells (x4 elements), dtype, description)
     "c4": (1024, 100_000, 32, np.float32,
-           "BASELINE config 4: 1024 k1-scan samples x 128-element FODO x 100k particles fp32 per GPU"),
+           "BASELINE config 4: 1024 k1-scan samples x 128-element FODO x 100k particles fp32 (one scan, sharded over the GPUs)"),
     "c3": (1, 1_000_000, 32, np.float64, "BASELINE config 3: 128-element FODO x 1M particles fp64, batch 1"),
     "c3big": (1, 8_000_000, 32, np.float64, "config 3 at 8M particles (896 MB: defeats the 256 MB Infinity Cache)"),
     "c2": (1, 100_000, 0, np.float32, "BASELINE config 2: 11-element ARES-style segment x 100k particles fp32"),
@@ -54,7 +62,12 @@ WORKLOADS = {
 }
 
 
-def build_segment(lx, name, batch, cells, dtype, rank, world):
+def build_segment(lx, name, sample_ids, cells, dtype, seed):
+    """
+    The lattice of workload `name` for the GLOBAL samples `sample_ids` (this rank's slice of the scan: the k1 of a
+    sample depends on its global index only, so the N-rank job is the 1-rank job cut in N pieces).
+    """
+    batch = len(sample_ids)
     f = lambda v: np.full((batch,), v, dtype=dtype)  # noqa: E731
     if name == "c2":
         return lx.Segment([
@@ -64,25 +77,46 @@ def build_segment(lx, name, batch, cells, dtype, rank, world):
             lx.Drift(f(7.0), dtype=dtype), lx.HorizontalCorrector(f(0.3), angle=f(-1e-4), name="H12SMATCH", dtype=dtype),
             lx.Drift(f(0.05), dtype=dtype), lx.BPM(name="BPM13SMATCH")])
     if name == "c5":
-        rng = np.random.default_rng(3 + rank)
+        # every environment's parameters are drawn for the whole job and cut to this rank's environments
+        rng = np.random.default_rng(seed)
+        total = int(sample_ids.max()) + 1 if batch else 0
+        pick = lambda a: np.ascontiguousarray(a[sample_ids]).astype(dtype)  # noqa: E731
         elements = []
         for _ in range(cells):
             elements += [lx.Drift(f(0.3), dtype=dtype),
-                         lx.Quadrupole(f(0.1), k1=rng.uniform(-5, 5, batch).astype(dtype),
-                                       misalignment=rng.normal(0, 1e-4, (batch, 2)).astype(dtype), dtype=dtype),
+                         lx.Quadrupole(f(0.1), k1=pick(rng.uniform(-5, 5, total)),
+                                       misalignment=pick(rng.normal(0, 1e-4, (total, 2))), dtype=dtype),
                          lx.Drift(f(0.3), dtype=dtype),
-                         lx.Cavity(f(1.0377), voltage=rng.uniform(5e6, 2e7, batch).astype(dtype),
-                                   phase=rng.uniform(-10, 10, batch).astype(dtype), frequency=f(1.3e9), dtype=dtype)]
+                         lx.Cavity(f(1.0377), voltage=pick(rng.uniform(5e6, 2e7, total)),
+                                   phase=pick(rng.uniform(-10, 10, total)), frequency=f(1.3e9), dtype=dtype)]
         return lx.Segment(elements)
-    # k1 scan over the GLOBAL batch: sample g = rank*batch + b gets k1 = +-4.2 (0.5 + (g mod 1024)/1023)
-    g = rank * batch + np.arange(batch)
-    scale = (0.5 + (g % 1024) / 1023.0) if batch > 1 else np.ones(1)
+    # k1 scan: global sample g gets k1 = +-4.2 (0.5 + (g mod 1024)/1023)   
+    scale = (0.5 + (sample_ids % 1024) / 1023.0) if batch > 1 else np.ones(1)
     k = (4.2 * scale).astype(dtype)
     elements = []
     for _ in range(cells):
         elements += [lx.Quadrupole(f(0.2), k1=k, dtype=dtype), lx.Drift(f(0.5), dtype=dtype),
                      lx.Quadrupole(f(0.2), k1=-k, dtype=dtype), lx.Drift(f(0.5), dtype=dtype)]
     return lx.Segment(elements)
+
+
+def shard_of(batch, particles, world, rank, weak):
+    """
+    -> (global batch, sample ids of this rank, particles of this rank, total particles per sample, parallelism).
+    Strong scaling (default): ONE workload of `batch` samples x `particles` particles cut over the ranks --
+    contiguous batch slices (primary partitioning), or particle slices when there is only
+    one sample (secondary).  Weak: every rank gets the whole per-GPU workload.
+    """
+    from lynx_amd.parallel import shard_batch, shard_particles
+
+    if weak or world == 1:
+        ids = rank * batch + np.arange(batch)
+        return batch * world, ids, particles, particles, f"{'particle' if batch == 1 else 'batch'}-sharded x{world}"
+    if batch == 1:
+        a, b = shard_particles(particles, world, rank)
+        return 1, np.zeros(1, dtype=np.int64), b - a, particles, f"particle-sharded x{world}"
+    a, b = shard_batch(batch, world, rank)
+    return batch, np.arange(a, b), particles, particles, f"batch-sharded x{world}"
 
 
 def host_cores() -> int:
@@ -222,14 +256,64 @@ def bring_up_rccl(rt, rdzv, rank, world, timeout_s):
     return attempt.get("comm"), attempt.get("error"), False
 
 
+def launch_ranks(n_ranks: int) -> int:
+    """
+    `python bench.py --gpus N` without a launcher around it: become one.  N children of this very command, one
+    per GPU, each with RANK / LOCAL_RANK / WORLD_SIZE and the same rendezvous key, started BEFORE this process has
+    touched the GPU (it never does: no re-exec of a process that has opened the device).  Rank 0 inherits stdout
+    (its JSON line is the run's line), the other ranks' stdout goes to stderr.  Returns the worst exit code; when a
+    rank fails the others get a grace period to notice through the rendezvous, then they are ended by pid.
+    """
+    import secrets
+    import signal
+    import subprocess
+
+    env = dict(os.environ)
+    env.update(WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1",
+               LYNX_RDZV_KEY=f"bench-{os.getpid()}-{secrets.token_hex(8)}")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # RCCL across processes: dmabuf IPC only on this driver
+    env.setdefault("MASTER_PORT", "0")
+    children = []
+    for r in range(n_ranks):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        children.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=e,
+                                         stdout=None if r == 0 else sys.stderr))
+    worst, failed_at = 0, None
+    grace = float(os.environ.get("LYNX_LAUNCH_GRACE_S", "30"))
+    try:
+        while any(c.poll() is None for c in children):
+            for c in children:
+                rc = c.poll()
+                if rc not in (None, 0) and failed_at is None:
+                    failed_at = time.monotonic()
+            if failed_at is not None and time.monotonic() - failed_at > grace:
+                for c in children:
+                    if c.poll() is None:
+                        c.send_signal(signal.SIGTERM)  # exactly the pids started here
+                failed_at = float("inf")
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        for c in children:
+            if c.poll() is None:
+                c.send_signal(signal.SIGTERM)
+    for c in children:
+        rc = c.wait()
+        if rc != 0:
+            worst = max(worst, rc if rc > 0 else 1)
+    return worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=os.environ.get("LYNX_BENCH_WORKLOAD", "c4"), choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=None, help="override the per-GPU batch")
+    ap.add_argument("--batch", type=int, default=None, help="override the workload's batch (global; per GPU with --weak)")
     ap.add_argument("--particles", type=int, default=None)
+    ap.add_argument("--weak", action="store_true",
+                    help="N > 1: every GPU tracks the whole per-GPU workload (global batch = batch x N) instead of "
+                         "a slice of ONE workload")
     ap.add_argument("--no-moments", action="store_true", help="track without the fused moment epilogue")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shared-input", action="store_true",
@@ -245,46 +329,87 @@ def main():
                          "shows what the per-launch time stamps themselves cost a step")
     ap.add_argument("--sync-every-step", action="store_true",
                     help="latency mode: wait for the GPU after every step (no overlap between consecutive calls)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="rehearsal without a GPU: launch, rendezvous, shard plan, barriers and the max over ranks "
+                         "only; prints a line with \"value\": null and \"dry_run\": true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))  # nothing has touched the GPU yet
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world != args.gpus:
-        sys.exit(f"--gpus {args.gpus} needs torchrun with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    if world != args.gpus:
+        sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}, or without a "
+                 "launcher (bench.py starts its own ranks)")
 
     batch, particles, cells, dtype, descr = WORKLOADS[args.workload]
     batch = args.batch or batch
     particles = args.particles or particles
     dtype = np.dtype(dtype).type
+    itemsize = np.dtype(dtype).itemsize
 
     # CPU baseline first: it forks worker processes, which must happen before this process opens the GPU
     baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.rendezvous_only:
         baseline = cpu_baseline(args.workload, particles, cells, dtype)
+
+    from lynx_amd.rendezvous import Rendezvous
+
+    # this rank's piece of the job
+    global_batch, sample_ids, my_particles, total_particles, parallelism = shard_of(batch, particles, world, rank, args.weak)
+    my_batch = len(sample_ids)
+    rows = max(len(shard_of(batch, particles, world, r, args.weak)[1]) for r in range(world))  # gathered rows per rank
+    strong = world > 1 and not args.weak
+
+    rdzv = Rendezvous(rank, world)  # standard-library sockets; no second communication stack in the process
+    config = {"workload": f"{args.workload}: {descr}", "batch_per_gpu": my_batch, "global_batch": global_batch,
+              "particles": total_particles, "particles_per_gpu": my_particles, "elements": None,
+              "fused_moments": not args.no_moments, "reverse_pass": bool(args.grad),
+              "incoming_beam": "one beam shared by the batch (lazy broadcast)" if args.shared_input else "one physical beam per sample",
+              "gather": "none", "parallelism": parallelism, "pipelined_calls": not args.sync_every_step,
+              "launcher": "torchrun/external" if os.environ.get("TORCHELASTIC_RUN_ID") or "LYNX_RDZV_KEY" not in os.environ
+                          else "bench.py"}
+    scaling = "weak" if (args.weak and world > 1) else "strong"
+
+    if args.rendezvous_only:
+        # the N > 1 plumbing without a GPU: every rank reports its slice, rank 0 checks that the slices tile the job
+        import struct
+
+        first = int(sample_ids[0]) if my_batch else 0
+        parts = rdzv.all_gather(struct.pack("<qqq", first, my_batch, my_particles))
+        rdzv.barrier()
+        slowest = rdzv.max(float(rank))
+        if rank == 0:
+            plan = [struct.unpack("<qqq", p) for p in parts]
+            if strong and batch > 1:
+                assert [p[0] for p in plan] == list(np.cumsum([0] + [p[1] for p in plan[:-1]])) and sum(p[1] for p in plan) == batch
+            if strong and batch == 1:
+                assert sum(p[2] for p in plan) == particles
+            assert slowest == world - 1
+            print(json.dumps({"metric": METRIC, "value": None, "unit": "particle-element-steps/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "scaling": scaling, "dry_run": True,
+                              "config": dict(config, shard_plan=[{"first_sample": p[0], "samples": p[1], "particles": p[2]}
+                                                                 for p in plan])}))
+        rdzv.close()
+        sys.exit(int(os.environ.get("LYNX_BENCH_TEST_EXIT", "0")) if rank == int(os.environ.get("LYNX_BENCH_TEST_EXIT_RANK", "-1")) else 0)
 
     import lynx_amd as lx
     from lynx_amd.device import get_runtime
-    from lynx_amd.rendezvous import Rendezvous
 
-    rdzv = Rendezvous(rank, world)  # standard-library sockets; no second communication stack in the process
     rt = get_runtime()
     lx.config.fused_moments = not args.no_moments
 
-    segment = build_segment(lx, args.workload, batch, cells, dtype, rank, world)
+    segment = build_segment(lx, args.workload, sample_ids, cells, dtype, seed=3 + (rank if args.weak else 0))
     n_elements = len(segment.elements)
+    config["elements"] = n_elements
+    batch = my_batch        # from here on: this rank's samples and particles
+    particles = my_particles
     beam = lx.ParticleBeam.synthetic((1,) if args.shared_input else (batch,), particles,
                                      sigma=[1e-4, 1e-5, 1e-4, 1e-5, 1e-5, 1e-3],
                                      energy=6e6 if args.workload == "c5" else 1e8, seed=2 + rank, dtype=dtype)
     if args.shared_input:
         beam = beam.broadcast((batch,))
         assert beam.is_shared
-
-    config = {"workload": f"{args.workload}: {descr}", "batch_per_gpu": batch, "global_batch": batch * world,
-              "particles": particles, "elements": n_elements, "fused_moments": not args.no_moments,
-              "reverse_pass": bool(args.grad),
-              "incoming_beam": "one beam shared by the batch (lazy broadcast)" if args.shared_input else "one physical beam per sample",
-              "gather": "none", "parallelism": f"{'particle' if batch == 1 else 'batch'}-sharded x{world}",
-              "pipelined_calls": not args.sync_every_step}
 
     def finish(code):
         """Ordinary end of the process; the hard exit is only for a thread stuck inside RCCL."""
@@ -341,9 +466,16 @@ def main():
         if out._moments is None or (world == 1 and comm is None):
             return out, None
         if comm is not None:
-            return out, comm.all_gather(out._moments.device(rt).reshape(batch, 36))
-        parts = rdzv.all_gather(np.ascontiguousarray(out.moment_record().reshape(batch, 36)).tobytes())
-        return out, np.stack([np.frombuffer(p, dtype=np.float64).reshape(batch, 36) for p in parts])
+            local = out._moments.device(rt).reshape(batch, 36)
+            if batch != rows:  # uneven slices (the batch is not a multiple of N): every rank sends `rows` rows
+                padded = rt.empty((rows, 36), np.float64)
+                rt.check(rt.lib.lynx_buf_d2d(rt.ctx, padded.ptr, local.ptr, local.nbytes))
+                local = padded
+            return out, comm.all_gather(local)
+        mine = np.zeros((rows, 36))
+        mine[:batch] = out.moment_record().reshape(batch, 36)
+        parts = rdzv.all_gather(mine.tobytes())
+        return out, np.stack([np.frombuffer(p, dtype=np.float64).reshape(rows, 36) for p in parts])
 
     for _ in range(args.warmup):
         last = step()
@@ -370,14 +502,22 @@ def main():
         assert np.all(np.isfinite(rec[have])) and np.all(rec[..., 35] == particles), "bench: bad moment records"
     if gathered is not None and not args.grad:
         g = np.asarray(gathered)
-        assert g.shape == (world, batch, 36) and np.allclose(g[rank], rec.reshape(batch, 36), equal_nan=True)
-        if batch == 1 and world > 1:
+        assert g.shape == (world, rows, 36) and np.allclose(g[rank, :batch], rec.reshape(batch, 36), equal_nan=True)
+        if global_batch == 1 and world > 1:
             # one sample: the ranks hold disjoint particle slices of one beam (SURVEY.md section 8e,
             # secondary partitioning); its record is the merge of the gathered slice records
             from lynx_amd.parallel import merge_records
 
             whole = merge_records(g)
-            assert whole[0, 35] == world * particles and np.all(np.isfinite(whole[~np.isnan(whole)])), "bench: bad merged record"
+            want = total_particles if strong else world * particles
+            assert whole[0, 35] == want and np.all(np.isfinite(whole[~np.isnan(whole)])), "bench: bad merged record"
+        elif strong:
+            # the scan's records in batch order, as a single-GPU run would hold them
+            from lynx_amd.parallel import assemble_records
+
+            whole = assemble_records(g, global_batch, world)
+            assert whole.shape == (global_batch, 36) and np.all(whole[:, 35] == total_particles), "bench: bad gathered records"
+            assert np.all(np.isfinite(whole[~np.isnan(whole)])), "bench: bad gathered records"
 
     copy_gbs = None
     if rank == 0 and world == 1:
@@ -406,8 +546,9 @@ def main():
             print(f"could not read {pmc[-1]}: {exc}", file=sys.stderr)
 
     if rank == 0:
-        itemsize = np.dtype(dtype).itemsize
-        steps_per_pass = batch * world * particles * n_elements
+        # particle passes of the whole job per step: one workload cut in N (strong), or N workloads (weak)
+        passes = global_batch * total_particles if strong else batch * world * particles
+        steps_per_pass = passes * n_elements
         alg_bytes = 2 * batch * particles * 7 * itemsize  # per launch of the streaming kernel, per GPU
         if args.shared_input:  # the incoming beam is read once, every sample's outgoing beam is written
             alg_bytes = (1 + batch) * particles * 7 * itemsize
@@ -424,7 +565,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32" if itemsize == 4 else "f64",
             "data": "synthetic",
@@ -434,7 +575,7 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": kern_s * 1e3, "launches": launches},
-            "hbm_gbs_whole_step": alg_bytes * world * args.steps / elapsed / 1e9,
+            "hbm_gbs_whole_step": (alg_bytes if args.shared_input else 2 * passes * 7 * itemsize) * args.steps / elapsed / 1e9,
             # the practical ceiling: best plain-copy shape measured in this process (MI355X_MICROARCH.md: ~6.3 TB/s)
             "hbm_copy_kernel_gbs": max(copy_gbs.values()) if copy_gbs else None,
             "hbm_copy_kernel_shapes": copy_gbs,

@@ -286,10 +286,11 @@ int lynx_comm_init(lynx_ctx* ctx, int n_ranks, int rank, const char* id);
 int lynx_comm_destroy(lynx_ctx* ctx);
 /* what the communicator actually is: RCCL version code (ncclGetVersion), ranks, this rank; ranks = 0 when there is none */
 int lynx_comm_info(lynx_ctx* ctx, int32_t* rccl_version, int32_t* n_ranks, int32_t* rank);
-/* all-gather `count` float64 per rank: d_recv [n_ranks][count].  Asynchronous: enqueued behind everything
- * issued so far -- on the context's main stream, or (environment LYNX_GATHER_OVERLAP=1) on a communication
- * stream of its own underneath the next tracking call; lynx_buf_d2h and lynx_sync wait for it either way.
- * Both blocks must stay allocated until the next call of this function or lynx_sync. */
+/* all-gather `count` float64 per rank: d_recv [n_ranks][count].  Asynchronous: it starts when everything issued
+ * so far has run -- with more than one rank on a communication stream of its own, underneath the next tracking
+ * call (nothing on the main stream waits for it; environment LYNX_GATHER_OVERLAP=0: in line on the main stream,
+ * also the default of a one-rank communicator); lynx_buf_d2h and lynx_sync wait for it either way.  Both blocks
+ * may be handed to lynx_buf_free at any time: the library keeps them out of its allocator until the gather is done. */
 int lynx_gather_moments(lynx_ctx* ctx, const double* d_send, double* d_recv, int64_t count);
 
 #ifdef __cplusplus

@@ -27,16 +27,20 @@ struct lynx_ctx {
   hipStream_t stream = nullptr;
   // Second stream for k_build.  The map build of a `track` call depends on the lattice and the
   // incoming energy only, so it runs underneath the previous call's streaming kernel:
-  //   s_build:  [wait: table slot free] k_build(n) -> table[n & 1]            record ev_built
-  //   stream :  [wait ev_built] k_track_direct(n), k_finalize(n)               record ev_streamed
+  //   s_build:  [wait: table slot free] k_build(n) -> table[n % kTableSlots]   record ev_built
+  //   host   :  waits for ev_built (LYNX_BUILD_HOST_WAIT=0: the main stream does, with a barrier packet)
+  //   stream :  k_track_direct(n)                                              ev_streamed rides on its dispatch
+  // With three table slots the build of call n+1 may start as soon as the streaming kernel of call n-2 has finished,
+  // i.e. it runs underneath kernel n-1 and the host, which waits for it, stays two calls ahead of the GPU.
   // Every build is followed at once by the main stream's wait on it, so anything enqueued on the
   // main stream later (copies, other kernels, lynx_sync) is ordered after every build so far.  The
   // build stream in turn waits for the main stream when (a) it reuses a table slot (ev_streamed) or
   // (b) the main stream may have written what the build reads (`main_dirty`, `main_wrote`).
   hipStream_t s_build = nullptr;
-  hipEvent_t ev_built[2] = {nullptr, nullptr}, ev_streamed_own[2] = {nullptr, nullptr}, ev_mark = nullptr;
-  hipEvent_t ev_streamed[2] = {nullptr, nullptr};  // the slot's current "streamed" event: its own, or a profiled launch's
-  bool streamed_valid[2] = {false, false};
+  static constexpr int kTableSlots = 3;
+  hipEvent_t ev_built[kTableSlots] = {}, ev_streamed_own[kTableSlots] = {}, ev_mark = nullptr;
+  hipEvent_t ev_streamed[kTableSlots] = {};  // the slot's current "streamed" event: its own, or a profiled launch's
+  bool streamed_valid[kTableSlots] = {};
   unsigned seq = 0;
   bool main_dirty = false;            // unsynchronised device writes on the main stream (any buffer)
   const void* main_wrote = nullptr;   // energy buffer the last streaming kernel published on the main stream
@@ -48,8 +52,6 @@ struct lynx_ctx {
   std::multimap<size_t, void*> free_blocks;
   std::unordered_map<void*, size_t> live;
   // internal scratch (grown on demand, stream-ordered reuse)
-  void* scratch_partials = nullptr;
-  size_t scratch_partials_bytes = 0;
   void* scratch_level = nullptr;  // second level of the moment reduction (long beams)
   size_t scratch_level_bytes = 0;
   void* scratch_obs = nullptr;  // per-workgroup sums of x, y at the observers [B][chunks][2 * LYNX_MAX_OBSERVERS]
@@ -60,17 +62,46 @@ struct lynx_ctx {
   size_t scratch_products_bytes = 0;
   void* scratch_coefs = nullptr;     // ... and cavity coefficients [S][8][Bp]
   size_t scratch_coefs_bytes = 0;
-  void* scratch_steps[4] = {nullptr, nullptr, nullptr, nullptr};  // two alternating step tables, the reverse pass's own, the ParameterBeam lanes path's
-  size_t scratch_steps_bytes[4] = {0, 0, 0, 0};
+  static constexpr int kTableBwd = kTableSlots, kTablePb = kTableSlots + 1;
+  void* scratch_steps[kTableSlots + 2] = {};  // the ring of step tables, the reverse pass's own, the ParameterBeam lanes path's
+  size_t scratch_steps_bytes[kTableSlots + 2] = {};
   void* scratch_grad[3] = {nullptr, nullptr, nullptr};  // backward: partials, T_bar, build scratch
   size_t scratch_grad_bytes[3] = {0, 0, 0};
   ncclComm_t comm = nullptr;
   int comm_ranks = 0;
-  // the moment gather runs on a stream of its own, underneath the next streaming kernel (lynx_gather_moments)
-  hipStream_t s_comm = nullptr;
-  hipEvent_t ev_gather_in = nullptr, ev_gather_done[2] = {nullptr, nullptr};
-  unsigned gather_seq = 0;
-  bool comm_busy = false;  // s_comm may still be writing a gathered block: readers on the host wait for it
+  // The SIDE stream: what follows a streaming kernel without anything on this GPU waiting for it -- the reduction of
+  // the workgroups' moment records and, with a communicator, the RCCL gather of the result -- runs here, underneath
+  // the next call's streaming kernel, so that the main stream carries streaming kernels back to back.
+  //   * a side operation starts behind the stop event that rides on its streaming kernel's dispatch (or a marker);
+  //   * nothing on the main stream waits for it by itself: entry points that read moment records on the device
+  //     join first (`join_side`), the host sees results through lynx_buf_d2h / lynx_sync, which wait for this stream;
+  //   * the blocks it touches are kept out of the allocator until its "done" event has fired (`side_ops`);
+  //   * the workgroups' records go through a ring of kPartialRing buffers; the host checks (and, rarely, waits)
+  //     that a buffer's last reduction is done before a streaming kernel is given it again.
+  hipStream_t s_side = nullptr;
+  hipEvent_t ev_side_in = nullptr;    // side -> main (join_side)
+  hipEvent_t ev_main_mark = nullptr;  // main -> side (a side operation whose input the main stream produces)
+  struct SideOp {
+    hipEvent_t done;
+    const void* a;  // blocks the operation reads or writes (null: none)
+    void* b;
+    bool a_freed, b_freed;  // lynx_buf_free came while it was in flight: released when it is done
+    bool owned;             // `done` goes back to side_events when the operation retires (else it belongs to a ring slot)
+  };
+  std::vector<SideOp> side_ops;         // in flight, oldest first (one stream: they finish in order)
+  std::vector<hipEvent_t> side_events;  // idle "done" events
+  bool side_busy = false;               // s_side may still be writing a block: readers wait for it
+  bool level_on_side = false;           // which stream the users of scratch_level ran on last
+  const void* side_wrote = nullptr;     // moment block the last side reduction writes (a gather of it needs no marker)
+  static constexpr int kPartialRing = 4;
+  struct PartialSlot {
+    void* buf = nullptr;
+    size_t bytes = 0;
+    hipEvent_t track_done = nullptr;  // rides on the streaming kernel's dispatch
+    hipEvent_t reduced = nullptr;     // recorded on s_side behind the reduction
+    bool pending = false;             // `reduced` has been recorded and not yet seen complete
+  } partial_ring[kPartialRing];
+  unsigned partial_seq = 0;
   // per-launch profiling of k_track (lynx_profile_begin / _end)
   bool profiling = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
@@ -158,13 +189,44 @@ static int ctx_alloc(lynx_ctx* ctx, size_t bytes, void** out) {
   return LYNX_OK;
 }
 
+// caller holds ctx->mu
+static void release_block(lynx_ctx* ctx, void* p) {
+  auto it = ctx->live.find(p);
+  if (it == ctx->live.end()) return;
+  ctx->free_blocks.emplace(it->second, p);
+  ctx->live.erase(it);
+}
+
+// Side operations whose "done" event has fired leave the in-flight list (oldest first: s_side runs them in order);
+// blocks that were freed meanwhile go back to the allocator now.  `wait`: block on every one of them.  Caller holds ctx->mu.
+static void retire_side_ops(lynx_ctx* ctx, bool wait) {
+  while (!ctx->side_ops.empty()) {
+    lynx_ctx::SideOp& g = ctx->side_ops.front();
+    if (wait) (void)hipEventSynchronize(g.done);
+    else if (hipEventQuery(g.done) != hipSuccess) break;
+    if (g.a_freed) release_block(ctx, const_cast<void*>(g.a));
+    if (g.b_freed) release_block(ctx, g.b);
+    if (g.owned) ctx->side_events.push_back(g.done);
+    ctx->side_ops.erase(ctx->side_ops.begin());
+  }
+}
+
 static int ctx_free(lynx_ctx* ctx, void* p) {
   if (!p) return LYNX_OK;
   std::lock_guard<std::mutex> lock(ctx->mu);
-  auto it = ctx->live.find(p);
-  if (it == ctx->live.end()) return fail(ctx, LYNX_ERR_INVALID, "lynx_buf_free: unknown pointer");
-  ctx->free_blocks.emplace(it->second, p);
-  ctx->live.erase(it);
+  if (ctx->live.find(p) == ctx->live.end()) return fail(ctx, LYNX_ERR_INVALID, "lynx_buf_free: unknown pointer");
+  if (!ctx->side_ops.empty()) {
+    retire_side_ops(ctx, false);
+    // a block an operation on the side stream still reads or writes: stream order on the main stream does not
+    // protect it, so it stays out of the allocator until that operation is done
+    bool held = false;
+    for (auto& g : ctx->side_ops) {
+      if (g.a == p) { g.a_freed = true; held = true; }
+      if (g.b == p) { g.b_freed = true; held = true; }
+    }
+    if (held) return LYNX_OK;
+  }
+  release_block(ctx, p);
   return LYNX_OK;
 }
 
@@ -173,6 +235,7 @@ static int ensure_scratch(lynx_ctx* ctx, void** buf, size_t* have, size_t need) 
   if (*buf) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->s_build));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->s_side));
     HIP_TRY(ctx, hipFree(*buf));
     *buf = nullptr;
     *have = 0;
@@ -214,8 +277,15 @@ int lynx_ctx_create(int device, lynx_ctx** out) {
     int prio_low = 0, prio_high = 0;
     HIP_TRY(nullptr, hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
     HIP_TRY(nullptr, hipStreamCreateWithPriority(&ctx->s_build, hipStreamNonBlocking, prio_high));
+    HIP_TRY(nullptr, hipStreamCreateWithPriority(&ctx->s_side, hipStreamNonBlocking, prio_high));
   }
-  for (int i = 0; i < 2; ++i) {
+  HIP_TRY(nullptr, hipEventCreateWithFlags(&ctx->ev_side_in, hipEventDisableTiming));
+  HIP_TRY(nullptr, hipEventCreateWithFlags(&ctx->ev_main_mark, hipEventDisableTiming));
+  for (auto& slot : ctx->partial_ring) {
+    HIP_TRY(nullptr, hipEventCreateWithFlags(&slot.track_done, hipEventDisableTiming));
+    HIP_TRY(nullptr, hipEventCreateWithFlags(&slot.reduced, hipEventDisableTiming));
+  }
+  for (int i = 0; i < lynx_ctx::kTableSlots; ++i) {
     HIP_TRY(nullptr, hipEventCreateWithFlags(&ctx->ev_built[i], hipEventDisableTiming));
     HIP_TRY(nullptr, hipEventCreateWithFlags(&ctx->ev_streamed_own[i], hipEventDisableTiming));
   }
@@ -231,27 +301,33 @@ int lynx_ctx_destroy(lynx_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->s_build);
   (void)hipStreamSynchronize(ctx->stream);
-  if (ctx->s_comm) (void)hipStreamSynchronize(ctx->s_comm);
+  (void)hipStreamSynchronize(ctx->s_side);
   if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
-  if (ctx->s_comm) {
-    (void)hipEventDestroy(ctx->ev_gather_in);
-    (void)hipEventDestroy(ctx->ev_gather_done[0]);
-    (void)hipEventDestroy(ctx->ev_gather_done[1]);
-    (void)hipStreamDestroy(ctx->s_comm);
+  {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    retire_side_ops(ctx, true);
   }
+  (void)hipEventDestroy(ctx->ev_side_in);
+  (void)hipEventDestroy(ctx->ev_main_mark);
+  for (hipEvent_t e : ctx->side_events) (void)hipEventDestroy(e);
+  for (auto& slot : ctx->partial_ring) {
+    (void)hipEventDestroy(slot.track_done);
+    (void)hipEventDestroy(slot.reduced);
+    if (slot.buf) (void)hipFree(slot.buf);
+  }
+  (void)hipStreamDestroy(ctx->s_side);
   for (auto& kv : ctx->free_blocks) (void)hipFree(kv.second);
   for (auto& kv : ctx->live) (void)hipFree(kv.first);
-  if (ctx->scratch_partials) (void)hipFree(ctx->scratch_partials);
   if (ctx->scratch_level) (void)hipFree(ctx->scratch_level);
   if (ctx->scratch_obs) (void)hipFree(ctx->scratch_obs);
   if (ctx->scratch_erun) (void)hipFree(ctx->scratch_erun);
   if (ctx->scratch_products) (void)hipFree(ctx->scratch_products);
   if (ctx->scratch_coefs) (void)hipFree(ctx->scratch_coefs);
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < lynx_ctx::kTableSlots + 2; ++i)
     if (ctx->scratch_steps[i]) (void)hipFree(ctx->scratch_steps[i]);
   for (int i = 0; i < 3; ++i)
     if (ctx->scratch_grad[i]) (void)hipFree(ctx->scratch_grad[i]);
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < lynx_ctx::kTableSlots; ++i) {
     (void)hipEventDestroy(ctx->ev_built[i]);
     (void)hipEventDestroy(ctx->ev_streamed_own[i]);
   }
@@ -276,11 +352,52 @@ int lynx_device_info(lynx_ctx* ctx, lynx_device_info_t* out) {
   return LYNX_OK;
 }
 
-// s_comm is the one stream whose work nothing on the main stream waits for by itself
-static int wait_for_gathers(lynx_ctx* ctx) {
-  if (ctx->comm_busy) {
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->s_comm));
-    ctx->comm_busy = false;
+// s_side is the one stream whose work nothing on the main stream waits for by itself.
+// Host readers (lynx_buf_d2h, lynx_sync): wait until it has drained.
+static int wait_for_side(lynx_ctx* ctx) {
+  if (ctx->side_busy) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->s_side));
+    ctx->side_busy = false;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    retire_side_ops(ctx, true);
+    for (auto& slot : ctx->partial_ring) slot.pending = false;
+  }
+  return LYNX_OK;
+}
+
+// a fresh or recycled "done" event for a side operation
+static int side_event(lynx_ctx* ctx, hipEvent_t* out) {
+  *out = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    retire_side_ops(ctx, false);
+    // bounded backlog: the host blocks on the oldest operation rather than run arbitrarily far ahead
+    while (ctx->side_ops.size() >= 32) {
+      (void)hipEventSynchronize(ctx->side_ops.front().done);
+      retire_side_ops(ctx, false);
+    }
+    if (!ctx->side_events.empty()) {
+      *out = ctx->side_events.back();
+      ctx->side_events.pop_back();
+    }
+  }
+  if (!*out) HIP_TRY(ctx, hipEventCreateWithFlags(out, hipEventDisableTiming));
+  return LYNX_OK;
+}
+
+// `done` has just been recorded on s_side behind an operation that touches blocks a and b
+static void side_op_issued(lynx_ctx* ctx, hipEvent_t done, const void* a, void* b, bool owned = true) {
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  ctx->side_ops.push_back(lynx_ctx::SideOp{done, a, b, false, false, owned});
+  ctx->side_busy = true;
+}
+
+// Device readers on the main stream (anything that may be handed a moment record or a gathered block): the main
+// stream waits for what the side stream has been given so far.
+static int join_side(lynx_ctx* ctx) {
+  if (ctx->side_busy) {
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_side_in, ctx->s_side));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_side_in, 0));
   }
   return LYNX_OK;
 }
@@ -288,7 +405,7 @@ static int wait_for_gathers(lynx_ctx* ctx) {
 int lynx_sync(lynx_ctx* ctx) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  return wait_for_gathers(ctx);
+  return wait_for_side(ctx);
 }
 
 int lynx_timer_start(lynx_ctx* ctx) {
@@ -318,7 +435,7 @@ int lynx_profile_end(lynx_ctx* ctx, double* total_ms, int64_t* launches) {
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   // every build is followed by its streaming kernel on the main stream, so both streams are idle now;
   // the per-launch stop events stood in for the step-table slots' "streamed" events and go away here
-  ctx->streamed_valid[0] = ctx->streamed_valid[1] = false;
+  for (bool& v : ctx->streamed_valid) v = false;
   double total = 0.0;
   for (auto& pr : ctx->prof_events) {
     float ms = 0.f;
@@ -350,7 +467,7 @@ int lynx_buf_h2d(lynx_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
 int lynx_buf_d2h(lynx_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
   if (bytes == 0) return LYNX_OK;
   {
-    const int rc = wait_for_gathers(ctx);  // the block may be a gathered one
+    const int rc = wait_for_side(ctx);  // the block may be a moment record or a gathered block
     if (rc) return rc;
   }
   HIP_TRY(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -360,6 +477,10 @@ int lynx_buf_d2h(lynx_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
 
 int lynx_buf_d2d(lynx_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) {
   if (bytes == 0) return LYNX_OK;
+  {
+    const int rc = join_side(ctx);  // the source may be a moment record the side stream is still reducing
+    if (rc) return rc;
+  }
   HIP_TRY(ctx, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
   ctx->main_dirty = true;
   return LYNX_OK;
@@ -367,6 +488,10 @@ int lynx_buf_d2d(lynx_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) {
 
 int lynx_buf_memset(lynx_ctx* ctx, void* d_dst, int value, size_t bytes) {
   if (bytes == 0) return LYNX_OK;
+  {
+    const int rc = join_side(ctx);
+    if (rc) return rc;
+  }
   HIP_TRY(ctx, hipMemsetAsync(d_dst, value, bytes, ctx->stream));
   ctx->main_dirty = true;
   return LYNX_OK;
@@ -375,6 +500,10 @@ int lynx_buf_memset(lynx_ctx* ctx, void* d_dst, int value, size_t bytes) {
 int lynx_pool_trim(lynx_ctx* ctx) {
   HIP_TRY(ctx, hipStreamSynchronize(ctx->s_build));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  {
+    const int rc = wait_for_side(ctx);
+    if (rc) return rc;
+  }
   std::lock_guard<std::mutex> lock(ctx->mu);
   for (auto& kv : ctx->free_blocks) (void)hipFree(kv.second);
   ctx->free_blocks.clear();
@@ -556,10 +685,14 @@ static int env_int(const char* name, int dflt) {
 // Launch shape of k_build: 256 threads and chunks of <= 64 elements (<= 32 for float32 lattices, whose
 // staging area would otherwise halve the resident workgroups) when the batch fills the GPU; 1024
 // threads and chunks of <= 128 when it does not -- then the tree depth is what a call waits for.
+// The wide shape is for a build the GPU has to itself: 16 waves and ~110 KB of LDS per workgroup cannot be placed on a
+// CU before all of a streaming kernel's workgroups there have drained, so a build that runs underneath the previous
+// call's streaming kernel (`underneath`) keeps the narrow shape (128-sample shard of BASELINE config 4: 18 us alone
+// either way, 117-150 us wide vs the narrow shape's share of the GPU under the streaming kernel).
 template <typename T>
-static void build_shape(lynx_ctx* ctx, const lynx_lattice* lat, int* threads, int* chunk) {
+static void build_shape(lynx_ctx* ctx, const lynx_lattice* lat, bool underneath, int* threads, int* chunk) {
   const int64_t cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
-  const bool wide = lat->batch * 2 <= cus;
+  const bool wide = lat->batch * 2 <= cus && !(underneath && env_int("LYNX_BUILD_NARROW_UNDERNEATH", 1));
   *threads = wide ? 1024 : 256;
   int limit = wide ? 128 : (sizeof(T) == 4 ? 32 : 64);
   limit = env_int("LYNX_BUILD_CHUNK", limit);
@@ -664,7 +797,7 @@ static int launch_build_lanes(lynx_ctx* ctx, lynx_lattice* lat, hipStream_t stre
 
 template <typename T>
 static int launch_build(lynx_ctx* ctx, lynx_lattice* lat, hipStream_t stream, const void* d_energy_in,
-                        void* d_steps_out, void* d_energy_out, int merge_pairs = 0) {
+                        void* d_steps_out, void* d_energy_out, int merge_pairs = 0, bool underneath = false) {
   {
     const int rc = launch_cavity_flags<T>(ctx, lat, stream, d_energy_in);
     if (rc) return rc;
@@ -674,7 +807,7 @@ static int launch_build(lynx_ctx* ctx, lynx_lattice* lat, hipStream_t stream, co
   if (lat->n_steps > 0 && lat->batch >= env_int("LYNX_LANES_BUILD_MIN_BATCH", 256))
     return launch_build_lanes<T>(ctx, lat, stream, d_energy_in, d_steps_out, d_energy_out, merge_pairs);
   int threads, chunk;
-  build_shape<T>(ctx, lat, &threads, &chunk);
+  build_shape<T>(ctx, lat, underneath, &threads, &chunk);
   const size_t lds = build_scratch_bytes(chunk, sizeof(T)) +
                      ((size_t)lat->n_steps * LYNX_STEP_STRIDE + lat->n_steps + 1) * sizeof(T);
   int rc = allow_lds(ctx, k_build<T>, lds);
@@ -869,7 +1002,7 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
   int slot = -1;
   bool async_build = false;
   if (S > 0 && !fused) {
-    slot = (int)(ctx->seq++ & 1u);
+    slot = (int)(ctx->seq++ % (unsigned)lynx_ctx::kTableSlots);
     const size_t need = (size_t)B * S * LYNX_STEP_STRIDE * sizeof(T);
     if ((rc = ensure_scratch(ctx, &ctx->scratch_steps[slot], &ctx->scratch_steps_bytes[slot], need))) return rc;
     // [run, cavity] pairs in merged form for the packed float32 step loop (one 7x7 application
@@ -887,7 +1020,7 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
     async_build = async;
     hipStream_t bs = async ? ctx->s_build : ctx->stream;
     if (async) {
-      // the table slot was last read by the streaming kernel two calls ago
+      // the table slot was last read by the streaming kernel kTableSlots calls ago
       if (ctx->streamed_valid[slot]) HIP_TRY(ctx, hipStreamWaitEvent(bs, ctx->ev_streamed[slot], 0));
       // what the build reads (energy, lattice pool) may have been written on the main stream
       if (ctx->main_dirty || (ctx->main_wrote && ctx->main_wrote == d_energy_in)) {
@@ -897,20 +1030,39 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
         ctx->main_wrote = nullptr;
       }
     }
-    if ((rc = launch_build<T>(ctx, lat, bs, d_energy_in, ctx->scratch_steps[slot], nullptr, p.a.merged_pairs))) return rc;
+    if ((rc = launch_build<T>(ctx, lat, bs, d_energy_in, ctx->scratch_steps[slot], nullptr, p.a.merged_pairs, async))) return rc;
     if (async) {
       HIP_TRY(ctx, hipEventRecord(ctx->ev_built[slot], bs));
-      HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_built[slot], 0));
+      // The HOST waits for the build instead of the main stream: no barrier packet with a foreign signal in front of
+      // the streaming kernel (measured on the 128-sample shard of BASELINE config 4: step - kernel 18.8 -> 8.5-10 us,
+      // c3big 17.9 -> 8-14, config 4 itself 20 -> 14).  The build of this call started when the streaming kernel of
+      // call n - kTableSlots + 1 began, so by now the GPU still has about two calls queued.  Not for lattices with
+      // cavities: their build (k_cavity_flags + the lanes kernels) takes most of a streaming kernel's time next to a
+      // VALU-bound kernel, and the host's wake-up would sit on the critical path (BASELINE config 5: 0.932 -> 0.947
+      // ms/step with it).  LYNX_BUILD_HOST_WAIT=0 / 1 forces the main-stream / host wait.
+      if (env_int("LYNX_BUILD_HOST_WAIT", lat->has_cavity ? 0 : 1)) HIP_TRY(ctx, hipEventSynchronize(ctx->ev_built[slot]));
+      else HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_built[slot], 0));
     }
     d_steps = ctx->scratch_steps[slot];
   }
   if (fused && lat && (rc = launch_cavity_flags<T>(ctx, lat, ctx->stream, d_energy_in))) return rc;
   if ((int64_t)B * p.a.chunks > 0x7fffffffLL) return fail(ctx, LYNX_ERR_INVALID, "grid too large");
+  // Workgroup records: a ring of buffers, so that the reduction of call n (side stream) can still read its records
+  // while the streaming kernels of calls n+1.. write theirs.  The host makes sure the slot's previous reduction is done.
   double* d_partials = nullptr;
+  lynx_ctx::PartialSlot* ring = nullptr;
+  // The reduction leaves the main stream once the streaming kernel is long enough to hide it under (same threshold
+  // as the build's second stream: below it the extra event traffic costs more host time than it returns).
+  const bool side = moments && env_int("LYNX_SIDE_REDUCE", B * N >= (int64_t)512 << 10 ? 1 : 0) != 0;
   if (moments) {
+    ring = &ctx->partial_ring[ctx->partial_seq++ % lynx_ctx::kPartialRing];
+    if (ring->pending) {
+      if (hipEventQuery(ring->reduced) != hipSuccess) HIP_TRY(ctx, hipEventSynchronize(ring->reduced));
+      ring->pending = false;
+    }
     const size_t need = (size_t)B * p.a.chunks * kPartialStride * sizeof(double);
-    if ((rc = ensure_scratch(ctx, &ctx->scratch_partials, &ctx->scratch_partials_bytes, need))) return rc;
-    d_partials = (double*)ctx->scratch_partials;
+    if ((rc = ensure_scratch(ctx, &ring->buf, &ring->bytes, need))) return rc;
+    d_partials = (double*)ring->buf;
   }
   double* d_obs = nullptr;
   if (p.a.n_observers) {
@@ -924,6 +1076,7 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
   // bound by the host's enqueue rate) and marks the main stream dirty instead, which makes the next asynchronous
   // build wait for everything enqueued here
   p.done = (slot >= 0 && async_build) ? ctx->ev_streamed_own[slot] : nullptr;
+  if (side && !p.done) p.done = ring->track_done;  // the side stream's reduction starts behind it
   rc = launch_direct<T>(ctx, p, lv, d_energy_in, d_p_in, d_p_out, d_energy_out, d_steps, d_partials, d_obs, moments);
   if (rc) return rc;
   if (p.a.n_observers) {
@@ -942,32 +1095,63 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
     // walks up to 70 rows, more rows go through a level of <= 64 groups first (rows_per_group grows with the
     // beam).  Few samples with a few hundred rows each (BASELINE configs 2 and 3): one 1024-thread workgroup
     // per sample stages 448 rows per pass -- one launch instead of two (LYNX_REDUCE_WIDE=0: the level form).
+    hipStream_t rs = ctx->stream;
+    if (side) {
+      rs = ctx->s_side;
+      HIP_TRY(ctx, hipStreamWaitEvent(rs, ctx->last_stream_stop, 0));
+    } else {
+      // in line: the side stream may still be reducing into a block the allocator has not seen freed; the main
+      // stream's own order covers everything else
+      ctx->side_wrote = nullptr;
+    }
     int rows = p.a.chunks;
     const double* level_in = d_partials;
     const bool wide = B <= 4 && rows > kReduceStage && rows <= 3 * kReduceStageWide && env_int("LYNX_REDUCE_WIDE", 1);
     if (wide) {
       constexpr size_t lds = reduce_lds_bytes<1024, kReduceStageWide>();
       if ((rc = allow_lds(ctx, k_reduce_moments<true, 1024, kReduceStageWide>, lds))) return rc;
-      hipLaunchKernelGGL((k_reduce_moments<true, 1024, kReduceStageWide>), dim3((unsigned)B), dim3(1024), lds, ctx->stream,
+      hipLaunchKernelGGL((k_reduce_moments<true, 1024, kReduceStageWide>), dim3((unsigned)B), dim3(1024), lds, rs,
                          level_in, rows, rows, 1, d_moments_out);
       HIP_TRY(ctx, hipGetLastError());
-      return LYNX_OK;
-    }
-    constexpr size_t lds = reduce_lds_bytes<256, kReduceStage>();
-    if (rows > kReduceStage) {
-      const int rpg = (rows + 63) / 64;
-      const int groups = (rows + rpg - 1) / rpg;
-      const size_t need = (size_t)B * groups * kPartialStride * sizeof(double);
-      if ((rc = ensure_scratch(ctx, &ctx->scratch_level, &ctx->scratch_level_bytes, need))) return rc;
-      hipLaunchKernelGGL((k_reduce_moments<false, 256, kReduceStage>), dim3((unsigned)(B * groups)), dim3(256), lds, ctx->stream,
-                         level_in, rows, rpg, groups, (double*)ctx->scratch_level);
+    } else {
+      constexpr size_t lds = reduce_lds_bytes<256, kReduceStage>();
+      if (rows > kReduceStage) {
+        const int rpg = (rows + 63) / 64;
+        const int groups = (rows + rpg - 1) / rpg;
+        const size_t need = (size_t)B * groups * kPartialStride * sizeof(double);
+        // one buffer: its users follow each other on one stream (side or main), and a change of stream joins first
+        if ((rc = ensure_scratch(ctx, &ctx->scratch_level, &ctx->scratch_level_bytes, need))) return rc;
+        if (ctx->level_on_side != side) {
+          if (side) {  // earlier in-line levels ran on the main stream: the side stream waits for them
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_main_mark, ctx->stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_side, ctx->ev_main_mark, 0));
+          } else if ((rc = join_side(ctx))) {
+            return rc;
+          }
+          ctx->level_on_side = side;
+        }
+        hipLaunchKernelGGL((k_reduce_moments<false, 256, kReduceStage>), dim3((unsigned)(B * groups)), dim3(256), lds, rs,
+                           level_in, rows, rpg, groups, (double*)ctx->scratch_level);
+        HIP_TRY(ctx, hipGetLastError());
+        level_in = (const double*)ctx->scratch_level;
+        rows = groups;
+      }
+      hipLaunchKernelGGL((k_reduce_moments<true, 256, kReduceStage>), dim3((unsigned)B), dim3(256), lds, rs, level_in,
+                         rows, rows, 1, d_moments_out);
       HIP_TRY(ctx, hipGetLastError());
-      level_in = (const double*)ctx->scratch_level;
-      rows = groups;
     }
-    hipLaunchKernelGGL((k_reduce_moments<true, 256, kReduceStage>), dim3((unsigned)B), dim3(256), lds, ctx->stream, level_in,
-                       rows, rows, 1, d_moments_out);
-    HIP_TRY(ctx, hipGetLastError());
+    if (side) {
+      // one event: the ring slot's.  The host has seen its previous recording complete before this call took the
+      // slot, so whatever side operation still carries it has finished and retires on the next look.
+      {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        retire_side_ops(ctx, false);
+      }
+      HIP_TRY(ctx, hipEventRecord(ring->reduced, rs));
+      ring->pending = true;
+      side_op_issued(ctx, ring->reduced, d_moments_out, nullptr, false);
+      ctx->side_wrote = d_moments_out;
+    }
   }
   return LYNX_OK;
 }
@@ -1022,8 +1206,8 @@ static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const v
   }
   for (int u = a.n_units; u < kBwdGroup * kBwdMaxGroups; ++u) a.unit_slot[u] = 0;
   const size_t steps_bytes = (size_t)B * S * LYNX_STEP_STRIDE * sizeof(T);
-  if ((rc = ensure_scratch(ctx, &ctx->scratch_steps[2], &ctx->scratch_steps_bytes[2], steps_bytes))) return rc;
-  if ((rc = launch_build<T>(ctx, lat, ctx->stream, d_energy_in, ctx->scratch_steps[2], nullptr, merged))) return rc;
+  if ((rc = ensure_scratch(ctx, &ctx->scratch_steps[lynx_ctx::kTableBwd], &ctx->scratch_steps_bytes[lynx_ctx::kTableBwd], steps_bytes))) return rc;
+  if ((rc = launch_build<T>(ctx, lat, ctx->stream, d_energy_in, ctx->scratch_steps[lynx_ctx::kTableBwd], nullptr, merged))) return rc;
   ctx->main_dirty = true;
 
   // Z: what a lane carries -- one particle, or (float32) two as a packed pair
@@ -1050,7 +1234,7 @@ static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const v
     return rc;
   LatticeDev lv = dev_view(lat);
   hipLaunchKernelGGL((k_track_bwd<T, Z>), dim3((unsigned)(B * chunks)), dim3(kTrackThreads), lds, ctx->stream, lv, a,
-                     (const T*)d_p_in, (const T*)ctx->scratch_steps[2], d_moments_fwd, d_grad_moments,
+                     (const T*)d_p_in, (const T*)ctx->scratch_steps[lynx_ctx::kTableBwd], d_moments_fwd, d_grad_moments,
                      (T*)ctx->scratch_grad[0], (T*)d_grad_p_in);
   HIP_TRY(ctx, hipGetLastError());
   hipLaunchKernelGGL(k_reduce_tbar<T>, dim3((unsigned)(B * S)), dim3(64), 0, ctx->stream, (const T*)ctx->scratch_grad[0],
@@ -1077,6 +1261,10 @@ int lynx_track_particles_backward(lynx_ctx* ctx, lynx_lattice* lat, int64_t n_pa
     return fail(ctx, LYNX_ERR_INVALID, "null argument");
   if (n_particles <= 0 || lat->n_steps <= 0) return fail(ctx, LYNX_ERR_INVALID, "empty program or beam");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  {
+    const int rc = join_side(ctx);  // d_moments_fwd is what a reduction on the side stream writes
+    if (rc) return rc;
+  }
   return lat->dtype == LYNX_F64
              ? track_backward_t<double>(ctx, lat, n_particles, d_energy_in, d_p_in, d_moments_fwd, d_grad_moments,
                                         d_grad_params, d_grad_energy_in, d_grad_p_in)
@@ -1094,9 +1282,9 @@ static int moments_backward_t(lynx_ctx* ctx, lynx_lattice* lat, const void* d_en
   const int64_t B = lat->batch;
   const int32_t S = lat->n_steps, E = lat->n_elems;
   int rc;
-  if ((rc = ensure_scratch(ctx, &ctx->scratch_steps[2], &ctx->scratch_steps_bytes[2], (size_t)B * S * LYNX_STEP_STRIDE * sizeof(T))))
+  if ((rc = ensure_scratch(ctx, &ctx->scratch_steps[lynx_ctx::kTableBwd], &ctx->scratch_steps_bytes[lynx_ctx::kTableBwd], (size_t)B * S * LYNX_STEP_STRIDE * sizeof(T))))
     return rc;
-  if ((rc = launch_build<T>(ctx, lat, ctx->stream, d_energy_in, ctx->scratch_steps[2], nullptr))) return rc;
+  if ((rc = launch_build<T>(ctx, lat, ctx->stream, d_energy_in, ctx->scratch_steps[lynx_ctx::kTableBwd], nullptr))) return rc;
   ctx->main_dirty = true;
   if ((rc = ensure_scratch(ctx, &ctx->scratch_grad[0], &ctx->scratch_grad_bytes[0], (size_t)B * (S + 1) * 56 * sizeof(T))))
     return rc;
@@ -1106,7 +1294,7 @@ static int moments_backward_t(lynx_ctx* ctx, lynx_lattice* lat, const void* d_en
                            (size_t)B * (2 * E + S + 1) * 49 * sizeof(T))))
     return rc;
   LatticeDev lv = dev_view(lat);
-  hipLaunchKernelGGL(k_moments_bwd<T>, dim3((unsigned)B), dim3(64), 0, ctx->stream, lv, (const T*)ctx->scratch_steps[2],
+  hipLaunchKernelGGL(k_moments_bwd<T>, dim3((unsigned)B), dim3(64), 0, ctx->stream, lv, (const T*)ctx->scratch_steps[lynx_ctx::kTableBwd],
                      (const T*)d_mu_in, (const T*)d_cov_in, (const T*)d_mu_bar, (const T*)d_cov_bar,
                      (T*)ctx->scratch_grad[0], (T*)ctx->scratch_grad[1], (T*)d_grad_mu_in, (T*)d_grad_cov_in);
   HIP_TRY(ctx, hipGetLastError());
@@ -1166,10 +1354,10 @@ static int launch_track_moments(lynx_ctx* ctx, lynx_lattice* lat, const void* d_
   if (lat->n_steps > 0 && lat->batch >= env_int("LYNX_LANES_BUILD_MIN_BATCH", 256)) {
     // large batches: lanes = samples all the way (step table from the lanes build, then one lane per sample)
     const size_t need = (size_t)lat->batch * lat->n_steps * LYNX_STEP_STRIDE * sizeof(T);
-    if ((rc = ensure_scratch(ctx, &ctx->scratch_steps[3], &ctx->scratch_steps_bytes[3], need))) return rc;
-    if ((rc = launch_build<T>(ctx, lat, ctx->stream, d_energy_in, ctx->scratch_steps[3], nullptr, 0))) return rc;
+    if ((rc = ensure_scratch(ctx, &ctx->scratch_steps[lynx_ctx::kTablePb], &ctx->scratch_steps_bytes[lynx_ctx::kTablePb], need))) return rc;
+    if ((rc = launch_build<T>(ctx, lat, ctx->stream, d_energy_in, ctx->scratch_steps[lynx_ctx::kTablePb], nullptr, 0))) return rc;
     hipLaunchKernelGGL(k_apply_moments_lanes<T>, dim3((unsigned)((lat->batch + 63) / 64)), dim3(64), apply_moments_lds<T>(),
-                       ctx->stream, dev_view(lat), (const T*)ctx->scratch_steps[3], (const T*)d_mu_in, (const T*)d_cov_in,
+                       ctx->stream, dev_view(lat), (const T*)ctx->scratch_steps[lynx_ctx::kTablePb], (const T*)d_mu_in, (const T*)d_cov_in,
                        (T*)d_mu_out, (T*)d_cov_out, (T*)d_energy_out);
     HIP_TRY(ctx, hipGetLastError());
     return LYNX_OK;
@@ -1373,8 +1561,9 @@ int lynx_comm_init(lynx_ctx* ctx, int n_ranks, int rank, const char* id) {
 
 int lynx_comm_destroy(lynx_ctx* ctx) {
   if (ctx && ctx->comm) {
-    if (ctx->s_comm) HIP_TRY(ctx, hipStreamSynchronize(ctx->s_comm));
-    ctx->comm_busy = false;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    int rc = wait_for_side(ctx);
+    if (rc) return rc;
     NCCL_TRY(ctx, ncclCommDestroy(ctx->comm));
     ctx->comm = nullptr;
     ctx->comm_ranks = 0;
@@ -1402,32 +1591,34 @@ int lynx_comm_info(lynx_ctx* ctx, int32_t* rccl_version, int32_t* n_ranks, int32
 int lynx_gather_moments(lynx_ctx* ctx, const double* d_send, double* d_recv, int64_t count) {
   if (!ctx || !ctx->comm) return fail(ctx, LYNX_ERR_INVALID, "communicator not initialised");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  if (env_int("LYNX_GATHER_OVERLAP", 0) == 0) {  // default: in line, on the main stream
+  // Default with more than one rank: the side stream.  With one rank (LYNX_FORCE_COMM rehearsals) the "gather" is
+  // a copy; it follows the reduction wherever that ran.
+  const bool produced_on_side = ctx->side_wrote && ctx->side_wrote == (const void*)d_send;
+  if (env_int("LYNX_GATHER_OVERLAP", (ctx->comm_ranks > 1 || produced_on_side) ? 1 : 0) == 0) {  // in line, on the main stream
+    int rc = join_side(ctx);  // the records may come from a reduction on the side stream
+    if (rc) return rc;
     NCCL_TRY(ctx, ncclAllGather(d_send, d_recv, (size_t)count, ncclDouble, ctx->comm, ctx->stream));
     return LYNX_OK;
   }
-  // LYNX_GATHER_OVERLAP=1.  The gather is latency (a few hundred KB over xGMI) and nothing on this GPU waits for
-  // its result but the host: it can run on a stream of its own, underneath the next call's streaming kernel,
-  // instead of between two of them.  Opt-in: on the one-GPU box (world size 1, scripts/gpu/r2_gather.sh) the
-  // in-line gather costs nothing measurable and the overlapped one 5-8 us of event traffic per step; whether it
-  // pays at 8 ranks can only be measured on a node this build has no access to.  Order: it starts when everything enqueued on the main stream so far has run (the records are
-  // final), and the main stream waits for the PREVIOUS gather before it goes on -- by then long finished -- so
-  // that no later kernel can be handed a block a gather still reads or writes.  The host sees the result through
-  // lynx_buf_d2h / lynx_sync, which wait for this stream.
-  if (!ctx->s_comm) {
-    int prio_low = 0, prio_high = 0;
-    HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
-    HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->s_comm, hipStreamNonBlocking, prio_high));
-    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_gather_in, hipEventDisableTiming));
-    for (int i = 0; i < 2; ++i) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_gather_done[i], hipEventDisableTiming));
+  // The gather is latency (a few hundred KB over xGMI, and it couples this GPU to the slowest rank of the step) and
+  // nothing on this GPU waits for its result but the host: it runs on the side stream, underneath the next call's
+  // streaming kernel, instead of between two of them.  In line every rank would run in lockstep with the slowest
+  // one, step by step; decoupled only the end of the job waits for everybody.
+  //   start : when the records are final -- stream order when the side stream reduced them itself, else a marker
+  //           behind everything enqueued on the main stream so far;
+  //   end   : a "done" event; the main stream never waits for it.  The two blocks stay out of the allocator until it
+  //           has fired (ctx_free defers them), the host sees the result through lynx_buf_d2h / lynx_sync, which
+  //           wait for this stream.
+  if (!produced_on_side) {
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_main_mark, ctx->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_side, ctx->ev_main_mark, 0));
   }
-  const unsigned n = ctx->gather_seq++;
-  HIP_TRY(ctx, hipEventRecord(ctx->ev_gather_in, ctx->stream));
-  HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_comm, ctx->ev_gather_in, 0));
-  NCCL_TRY(ctx, ncclAllGather(d_send, d_recv, (size_t)count, ncclDouble, ctx->comm, ctx->s_comm));
-  HIP_TRY(ctx, hipEventRecord(ctx->ev_gather_done[n & 1], ctx->s_comm));
-  if (n > 0) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_gather_done[(n - 1) & 1], 0));
-  ctx->comm_busy = true;
+  hipEvent_t done = nullptr;
+  int rc = side_event(ctx, &done);
+  if (rc) return rc;
+  NCCL_TRY(ctx, ncclAllGather(d_send, d_recv, (size_t)count, ncclDouble, ctx->comm, ctx->s_side));
+  HIP_TRY(ctx, hipEventRecord(done, ctx->s_side));
+  side_op_issued(ctx, done, d_send, d_recv);
   return LYNX_OK;
 }
 

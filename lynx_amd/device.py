@@ -37,12 +37,17 @@ class Runtime:
             device = int(os.environ.get("LYNX_DEVICE", os.environ.get("LOCAL_RANK", "0")))
             count = C.c_int(0)
             self.lib.lynx_device_count(C.byref(count))
-            if 0 < count.value <= device and os.environ.get("LYNX_ALLOW_GPU_SHARING") == "1":
+            isolated = any(os.environ.get(v) for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+            if 0 < count.value <= device and "LYNX_DEVICE" not in os.environ and isolated and count.value == 1:
+                device = 0  # the launcher gave this rank ONE GPU of its own (*_VISIBLE_DEVICES per rank): that one
+            elif 0 < count.value <= device and os.environ.get("LYNX_ALLOW_GPU_SHARING") == "1":
                 device %= count.value  # rehearsals on a box with fewer GPUs than ranks (no RCCL there)
             elif 0 < count.value <= device:
                 raise _ffi.LynxError(
-                    f"rank-local device ordinal {device} but only {count.value} GPU(s) visible: one process "
-                    "drives one GPU (set LYNX_DEVICE, or LYNX_ALLOW_GPU_SHARING=1 for a rehearsal)")
+                    f"rank-local device ordinal {device} (LYNX_DEVICE / LOCAL_RANK) but only {count.value} GPU(s) visible "
+                    f"(HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES')!r}, "
+                    f"ROCR_VISIBLE_DEVICES={os.environ.get('ROCR_VISIBLE_DEVICES')!r}): one process drives one GPU "
+                    "(set LYNX_DEVICE, or LYNX_ALLOW_GPU_SHARING=1 for a rehearsal)")
         handle = C.c_void_p()
         _ffi.check(self.lib.lynx_ctx_create(int(device), C.byref(handle)))
         self.ctx = handle

@@ -18,8 +18,8 @@ Two partitionings:
   slice's (count, mean, covariance).
 
 Rendezvous: the 128-byte RCCL unique id made by rank 0 has to reach every rank.  The
-package does not choose how (`exchange` callable); bench.py uses torch.distributed's
-store, tests use a gloo broadcast.
+package does not choose how (`exchange` callable); bench.py sends it over `lynx_amd.rendezvous`
+(standard-library sockets: no torch in the process), tests use a gloo broadcast.
 """
 
 from __future__ import annotations
@@ -115,16 +115,16 @@ class RcclCommunicator:
 
     def all_gather(self, local: DeviceArray) -> DeviceArray:
         """
-        (rows, 36) float64 per rank -> (n_ranks, rows, 36) on every rank.  Asynchronous: enqueued on the main
-        stream (default) or, with `LYNX_GATHER_OVERLAP=1`, on the context's communication stream underneath
-        whatever is tracked next; reading the result (`np.asarray`, `rt.sync()`) waits for it either way.
+        (rows, 36) float64 per rank -> (n_ranks, rows, 36) on every rank.  Asynchronous: with more than one rank
+        it runs on the context's communication stream underneath whatever is tracked next and nothing on the main
+        stream waits for it (`LYNX_GATHER_OVERLAP=0`: in line on the main stream); reading the result
+        (`np.asarray`, `rt.sync()`) waits for it either way.  Neither array has to be kept alive by the caller:
+        the library holds a freed block back until the gather that touches it is done.
         """
         assert local.dtype == np.float64
         out = self.rt.empty((self.n_ranks, *local.shape), np.float64)
         self.rt.check(self.rt.lib.lynx_gather_moments(self.rt.ctx, C.c_void_p(local.ptr), C.c_void_p(out.ptr),
                                                       local.size))
-        # both blocks stay out of the allocator until the next gather has made the main stream wait for this one
-        self._in_flight = (local, out)
         return out
 
     def close(self):
@@ -132,4 +132,3 @@ class RcclCommunicator:
         if not self.rt.closed and not getattr(self, "_closed", False):
             self._closed = True
             self.rt.check(self.rt.lib.lynx_comm_destroy(self.rt.ctx))  # waits for the communication stream
-            self._in_flight = None

@@ -10,8 +10,12 @@ Topology: a star.  Rank 0 listens on an ephemeral loopback port and publishes th
 a file under the temp directory whose name is derived from what all ranks of one launch share --
 `MASTER_ADDR`, `MASTER_PORT` and the launcher's pid (`torchrun` exports the first two and is the
 parent of every rank; `MASTER_PORT` itself is taken by the launcher's own store) -- or from
-`LYNX_RDZV_KEY`.  Every other rank polls for the file, connects and says who it is.  A collective
-is one message up and one message down per rank; payloads are a few hundred bytes.
+`LYNX_RDZV_KEY` (what `bench.py`'s own launcher and any launcher whose ranks are not direct children
+of one process should set).  The file holds the port, a random nonce and rank 0's pid; it is created
+exclusively with mode 0600 after any leftover of a crashed launch with the same key has been removed.
+Every other rank polls for the file, connects, says who it is and checks that the answer carries the
+nonce it read -- a stale file cannot lead it to somebody else's rank 0.  A collective is one message up
+and one message down per rank; payloads are a few hundred bytes.
 
 The reference has no counterpart (it is single-process).
 """
@@ -19,6 +23,7 @@ The reference has no counterpart (it is single-process).
 from __future__ import annotations
 
 import os
+import secrets
 import socket
 import struct
 import tempfile
@@ -83,9 +88,16 @@ class Rendezvous:
         listener.settimeout(self.timeout_s)
         self._listener = listener
         port = listener.getsockname()[1]
+        self._nonce = secrets.token_hex(16)
+        try:
+            self.path.unlink()  # a leftover of a crashed launch with the same key is not this launch's rank 0
+        except FileNotFoundError:
+            pass
         tmp = self.path.with_suffix(f".{os.getpid()}.tmp")
-        tmp.write_text(f"{port}\n")
-        os.replace(tmp, self.path)  # atomic: a reader sees the whole number or no file
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+        with os.fdopen(fd, "w") as fh:
+            fh.write(f"{port} {self._nonce} {os.getpid()}\n")
+        os.replace(tmp, self.path)  # atomic: a reader sees the whole line or no file
         try:
             while len(self.peers) < self.world - 1:
                 conn, _ = listener.accept()
@@ -97,31 +109,36 @@ class Rendezvous:
                     continue
                 (peer,) = struct.unpack("<I", hello[len(_MAGIC):])
                 assert 0 < peer < self.world and peer not in self.peers, f"unexpected rank {peer}"
-                _send(conn, _MAGIC + self.path.name.encode())  # the joiner checks it reached ITS rank 0
+                _send(conn, _MAGIC + self._nonce.encode())  # the joiner checks it reached ITS rank 0
                 self.peers[peer] = conn
         except socket.timeout:
             raise TimeoutError(f"rendezvous: only {len(self.peers) + 1} of {self.world} ranks showed up "
-                               f"within {self.timeout_s:.0f} s") from None
+                               f"within {self.timeout_s:.0f} s at {self.path} (key from "
+                               f"{'LYNX_RDZV_KEY' if os.environ.get('LYNX_RDZV_KEY') else 'MASTER_ADDR-MASTER_PORT-parent pid'}: "
+                               "ranks that are not children of one launcher must share LYNX_RDZV_KEY)") from None
 
     def _join(self) -> None:
         deadline = time.monotonic() + self.timeout_s
         last = None
         while time.monotonic() < deadline:
             try:
-                port = int(self.path.read_text())
-                sock = socket.create_connection(("127.0.0.1", port), timeout=5.0)
+                port, nonce = self.path.read_text().split()[:2]
+                sock = socket.create_connection(("127.0.0.1", int(port)), timeout=5.0)
                 sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                sock.settimeout(self.timeout_s)
+                sock.settimeout(3.0)  # the handshake only: a stale file may lead to a listener that never answers
                 _send(sock, _MAGIC + struct.pack("<I", self.rank))
-                if _recv(sock) != _MAGIC + self.path.name.encode():  # a stale file led somewhere else
+                if _recv(sock) != _MAGIC + nonce.encode():  # a stale file led somewhere else
                     sock.close()
                     raise ConnectionError("not this launch's rank 0")
+                sock.settimeout(self.timeout_s)
                 self.hub = sock
                 return
             except (FileNotFoundError, ValueError, ConnectionError, OSError) as exc:  # not published yet / stale
                 last = exc
                 time.sleep(0.05)
-        raise TimeoutError(f"rendezvous: rank {self.rank} found no rank 0 at {self.path} ({last})")
+        raise TimeoutError(f"rendezvous: rank {self.rank} found no rank 0 at {self.path} within {self.timeout_s:.0f} s "
+                           f"({last}); LYNX_RDZV_KEY={os.environ.get('LYNX_RDZV_KEY')!r}, computed key file above -- "
+                           "ranks that are not children of one launcher must share LYNX_RDZV_KEY")
 
     # -- collectives ------------------------------------------------------------------------
     def all_gather(self, payload: bytes) -> list:

@@ -219,3 +219,98 @@ def test_stdlib_rendezvous_broadcast_barrier_max_gather(world, tmp_path):
     from pathlib import Path
 
     assert not (Path(tempfile.gettempdir()) / f"lynx-rdzv-{key}.port").exists()
+
+
+def test_a_stale_port_file_of_a_crashed_launch_is_not_mistaken_for_rank_0(tmp_path):
+    """Same key, leftover file pointing at a port where somebody else listens: the joiner must end up at the
+    real rank 0 (nonce in the file and in the hello reply; rank 0 removes the leftover before it publishes)."""
+    import tempfile
+    from pathlib import Path
+
+    key = f"test-stale-{os.getpid()}"
+    stale = Path(tempfile.gettempdir()) / f"lynx-rdzv-{key}.port"
+    with socket.socket() as other:  # a listener that is not a rendezvous
+        other.bind(("127.0.0.1", 0))
+        other.listen(1)
+        stale.write_text(f"{other.getsockname()[1]} {'0' * 32} 1\n")
+        ctx = mp.get_context("spawn")
+        queue = ctx.Queue()
+        procs = [ctx.Process(target=_rdzv_rank, args=(r, 2, key, queue)) for r in range(2)]
+        for p in reversed(procs):
+            p.start()
+        results = sorted(queue.get(timeout=120) for _ in range(2))
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    assert [r[0] for r in results] == [0, 1] and all(r[1] == bytes(range(128)) for r in results)
+    assert not stale.exists()
+
+
+# ---------------------------------------------------------------------------------------------
+# bench.py --gpus N started plainly: it launches its own ranks (no GPU needed for the rehearsal mode)
+# ---------------------------------------------------------------------------------------------
+
+
+def _bench(*args, env=None):
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LYNX_RDZV_KEY")}
+    # the launcher and the rehearsal ranks must not need the HIP library (nothing may touch the GPU before the ranks exist)
+    e["LYNX_HIP_LIBRARY"] = "/nonexistent/liblynxhip.so"
+    e.update(env or {})
+    run = subprocess.run([sys.executable, str(root / "bench.py"), *args], env=e, capture_output=True, text=True, timeout=120)
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    return run.returncode, [json.loads(ln) for ln in lines], run.stderr
+
+
+def test_bench_launches_its_own_ranks_and_shards_config_4_strongly():
+    rc, lines, err = _bench("--gpus", "8", "--rendezvous-only")
+    assert rc == 0, err
+    assert len(lines) == 1  # rank 0's line only
+    line = lines[0]
+    assert line["n_gpus"] == 8 and line["scaling"] == "strong" and line["value"] is None and line["dry_run"] is True
+    plan = line["config"]["shard_plan"]
+    # SURVEY.md section 8d: batches [128 g, 128 (g + 1)) on GPU g, all 100 000 particles of a sample on its GPU
+    assert [(p["first_sample"], p["samples"], p["particles"]) for p in plan] == [(128 * g, 128, 100_000) for g in range(8)]
+    assert line["config"]["global_batch"] == 1024 and line["config"]["batch_per_gpu"] == 128
+    assert line["config"]["launcher"] == "bench.py"
+
+
+def test_bench_weak_scaling_and_particle_sharding_are_still_there():
+    rc, lines, err = _bench("--gpus", "2", "--rendezvous-only", "--weak")
+    assert rc == 0, err
+    assert lines[0]["scaling"] == "weak" and lines[0]["config"]["global_batch"] == 2048
+    rc, lines, err = _bench("--gpus", "3", "--rendezvous-only", "--workload", "c3")
+    assert rc == 0, err
+    assert [p["particles"] for p in lines[0]["config"]["shard_plan"]] == [333_334, 333_333, 333_333]
+    assert lines[0]["config"]["parallelism"] == "particle-sharded x3"
+
+
+def test_bench_launcher_reports_a_failing_rank():
+    rc, lines, err = _bench("--gpus", "2", "--rendezvous-only", env={"LYNX_BENCH_TEST_EXIT": "3", "LYNX_BENCH_TEST_EXIT_RANK": "1"})
+    assert rc == 3, (rc, err)
+
+
+def test_bench_under_an_external_launcher_uses_the_ranks_it_is_given():
+    # what torchrun does, without torch: two processes with RANK / WORLD_SIZE and a common parent
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    base = {k: v for k, v in os.environ.items() if k != "LYNX_RDZV_KEY"}
+    base.update(WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29599", LYNX_HIP_LIBRARY="/nonexistent/liblynxhip.so")
+    procs = [subprocess.Popen([sys.executable, str(root / "bench.py"), "--gpus", "2", "--rendezvous-only"],
+                              env=dict(base, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, text=True)
+             for r in (1, 0)]
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs)
+    assert outs[0].strip() == "" and '"n_gpus": 2' in outs[1]  # rank 1 prints nothing, rank 0 the line
+    # a mismatch between --gpus and the launcher's world size is an error, not a silent single-rank run
+    one = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "4", "--rendezvous-only"],
+                         env=dict(base, RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=60)
+    assert one.returncode != 0 and "WORLD_SIZE=2" in one.stderr
