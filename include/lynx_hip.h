@@ -28,7 +28,11 @@ enum lynx_status {
   LYNX_ERR_INVALID = -1, /* bad argument / shape mismatch */
   LYNX_ERR_HIP = -2,     /* HIP runtime error            */
   LYNX_ERR_RCCL = -3,    /* RCCL error                   */
-  LYNX_ERR_NOMEM = -4
+  LYNX_ERR_NOMEM = -4,
+  /* a beam reached a cavity with energy <= 0 (or NaN): the reference's `assert Ei > 0` (lynx/accelerator/cavity.py:260).
+   * Found on the device while the cavities' whole-batch predicates are evaluated (no read-back per call) and reported
+   * by the next call that waits for the GPU anyway: lynx_sync, lynx_buf_d2h.  The Python layer raises AssertionError. */
+  LYNX_ERR_ENERGY = -5
 };
 
 enum lynx_dtype { LYNX_F32 = 0, LYNX_F64 = 1 };

@@ -130,8 +130,13 @@ def load():
     return lib
 
 
+ERR_ENERGY = -5
+
+
 def check(status: int, ctx=None):
     if status != 0:
         lib = load()
         msg = lib.lynx_last_error(ctx)
+        if status == ERR_ENERGY:  # the reference's `assert torch.all(Ei > 0)` (cavity.py:260), found on the device
+            raise AssertionError(msg.decode() if msg else "Initial energy must be larger than 0")
         raise LynxError(f"liblynxhip status {status}: {msg.decode() if msg else '?'}")

@@ -258,9 +258,14 @@ constexpr int kCavMask = LYNX_FLAG_CAV_BETA | LYNX_FLAG_CAV_GAIN | LYNX_FLAG_CAV
 
 constexpr int kFlagsPerThread = 8;  // samples whose energy a thread of k_cavity_flags keeps in registers
 
+// `status` (host-mapped, two words): cavity.py:260 asserts that every sample reaches every cavity with Ei > 0.  A
+// sample that does not sets word 0 and leaves the element's index in word 1; the host looks at it when it waits for
+// the GPU next (lynx_sync, lynx_buf_d2h) -- no read-back per call, and a beam whose energy lives in HBM only (the
+// output of an earlier cavity program) is checked like any other.
 template <typename T>
 __global__ __launch_bounds__(1024) void k_cavity_flags(LatticeDev lat, lynx_elem* elems, lynx_step* steps,
-                                                       const T* __restrict__ energy_in, T* __restrict__ e_run) {
+                                                       const T* __restrict__ energy_in, T* __restrict__ e_run,
+                                                       int32_t* __restrict__ status) {
   const T* pool = static_cast<const T*>(lat.pool);
   const int64_t B = lat.batch;
   // every sample's energy on its way through the cavities: in registers for batches of up to 8192, in
@@ -282,8 +287,10 @@ __global__ __launch_bounds__(1024) void k_cavity_flags(LatticeDev lat, lynx_elem
       if (el.kind != LYNX_KIND_CAVITY) continue;  // uniform
       const bool is_step = st.kind == LYNX_STEP_CAVITY;
       int mine = 0;
+      constexpr int kBadEnergy = 1 << 30;
       T de_reg[kFlagsPerThread];
       auto look = [&](T energy, int64_t b) -> T {
+        if (!(energy > T(0))) mine |= kBadEnergy;  // cavity.py:260 (NaN fails the assertion too)
         const T* p = pool + el.param_offset + b * (int64_t)el.batch_stride;
         const T voltage = p[1];
         const T d_energy = voltage * t_cos(p[2] * T(LYNX_PI / 180.0));
@@ -307,6 +314,10 @@ __global__ __launch_bounds__(1024) void k_cavity_flags(LatticeDev lat, lynx_elem
       if (__syncthreads_or(mine & LYNX_FLAG_CAV_BETA)) f |= LYNX_FLAG_CAV_BETA;
       if (__syncthreads_or(mine & LYNX_FLAG_CAV_GAIN)) f |= LYNX_FLAG_CAV_GAIN;
       if (__syncthreads_or(mine & LYNX_FLAG_CAV_T5XX)) f |= LYNX_FLAG_CAV_T5XX;
+      if (__syncthreads_or(mine & kBadEnergy) && threadIdx.x == 0 && status) {
+        if (__hip_atomic_exchange(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0)
+          __hip_atomic_store(status + 1, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // the first one found
+      }
       if (threadIdx.x == 0) {
         elems[e].flags = (el.flags & ~kCavMask) | f;
         if (is_step) steps[s].flags = (st.flags & ~kCavMask) | f;

@@ -46,6 +46,10 @@ struct lynx_ctx {
   const void* main_wrote = nullptr;   // energy buffer the last streaming kernel published on the main stream
   std::mutex mu;                      // allocator maps: finalizers may run on other threads
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  // host-mapped status words the kernels can raise a flag in (k_cavity_flags: energy <= 0 at a cavity); the host
+  // looks at them whenever it has waited for the GPU anyway
+  int32_t* h_status = nullptr;
+  int32_t* d_status = nullptr;
   std::string err;
   hipDeviceProp_t prop;
   // caching allocator: size class -> free blocks; live pointer -> size class
@@ -292,6 +296,9 @@ int lynx_ctx_create(int device, lynx_ctx** out) {
   HIP_TRY(nullptr, hipEventCreateWithFlags(&ctx->ev_mark, hipEventDisableTiming));
   HIP_TRY(nullptr, hipEventCreate(&ctx->ev_start));
   HIP_TRY(nullptr, hipEventCreate(&ctx->ev_stop));
+  HIP_TRY(nullptr, hipHostMalloc((void**)&ctx->h_status, 2 * sizeof(int32_t), hipHostMallocMapped));
+  ctx->h_status[0] = ctx->h_status[1] = 0;
+  HIP_TRY(nullptr, hipHostGetDevicePointer((void**)&ctx->d_status, ctx->h_status, 0));
   *out = ctx;
   return LYNX_OK;
 }
@@ -331,6 +338,7 @@ int lynx_ctx_destroy(lynx_ctx* ctx) {
     (void)hipEventDestroy(ctx->ev_built[i]);
     (void)hipEventDestroy(ctx->ev_streamed_own[i]);
   }
+  if (ctx->h_status) (void)hipHostFree(ctx->h_status);
   (void)hipEventDestroy(ctx->ev_mark);
   (void)hipEventDestroy(ctx->ev_start);
   (void)hipEventDestroy(ctx->ev_stop);
@@ -392,6 +400,19 @@ static void side_op_issued(lynx_ctx* ctx, hipEvent_t done, const void* a, void* 
   ctx->side_busy = true;
 }
 
+// What the kernels flagged since the last look; the caller has just waited for the GPU.
+static int check_status(lynx_ctx* ctx) {
+  if (ctx->h_status && __atomic_load_n(&ctx->h_status[0], __ATOMIC_ACQUIRE) != 0) {
+    const int elem = __atomic_load_n(&ctx->h_status[1], __ATOMIC_ACQUIRE);
+    __atomic_store_n(&ctx->h_status[0], 0, __ATOMIC_RELEASE);
+    __atomic_store_n(&ctx->h_status[1], 0, __ATOMIC_RELEASE);
+    return fail(ctx, LYNX_ERR_ENERGY,
+                "Initial energy must be larger than 0 (a beam reached the cavity at element " + std::to_string(elem) +
+                    " of its program with energy <= 0 or NaN; lynx/accelerator/cavity.py:260)");
+  }
+  return LYNX_OK;
+}
+
 // Device readers on the main stream (anything that may be handed a moment record or a gathered block): the main
 // stream waits for what the side stream has been given so far.
 static int join_side(lynx_ctx* ctx) {
@@ -405,7 +426,8 @@ static int join_side(lynx_ctx* ctx) {
 int lynx_sync(lynx_ctx* ctx) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  return wait_for_side(ctx);
+  const int rc = wait_for_side(ctx);
+  return rc ? rc : check_status(ctx);
 }
 
 int lynx_timer_start(lynx_ctx* ctx) {
@@ -421,6 +443,14 @@ int lynx_timer_stop(lynx_ctx* ctx, float* elapsed_ms) {
 }
 
 int lynx_profile_begin(lynx_ctx* ctx) {
+  // events of an earlier, unfinished profile may still stand in for step-table slots' "streamed" events: nothing may
+  // wait on them once they are destroyed
+  if (!ctx->prof_events.empty()) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->s_build));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (bool& v : ctx->streamed_valid) v = false;
+    ctx->last_stream_stop = nullptr;
+  }
   for (auto& pr : ctx->prof_events) {
     (void)hipEventDestroy(pr.first);
     (void)hipEventDestroy(pr.second);
@@ -472,7 +502,7 @@ int lynx_buf_d2h(lynx_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
   }
   HIP_TRY(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  return LYNX_OK;
+  return check_status(ctx);  // what came back may be the result of a program that met a cavity with energy <= 0
 }
 
 int lynx_buf_d2d(lynx_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) {
@@ -709,7 +739,7 @@ static int launch_cavity_flags(lynx_ctx* ctx, lynx_lattice* lat, hipStream_t str
   int rc;
   if ((rc = ensure_scratch(ctx, &ctx->scratch_erun, &ctx->scratch_erun_bytes, (size_t)lat->batch * sizeof(T)))) return rc;
   hipLaunchKernelGGL(k_cavity_flags<T>, dim3(1), dim3(1024), 0, stream, dev_view(lat), lat->d_elems, lat->d_steps,
-                     (const T*)d_energy_in, (T*)ctx->scratch_erun);
+                     (const T*)d_energy_in, (T*)ctx->scratch_erun, ctx->d_status);
   HIP_TRY(ctx, hipGetLastError());
   return LYNX_OK;
 }
@@ -1045,7 +1075,10 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
     }
     d_steps = ctx->scratch_steps[slot];
   }
-  if (fused && lat && (rc = launch_cavity_flags<T>(ctx, lat, ctx->stream, d_energy_in))) return rc;
+  if (fused && lat) {
+    if ((rc = launch_cavity_flags<T>(ctx, lat, ctx->stream, d_energy_in))) return rc;
+    ctx->main_dirty = true;  // it rewrote the lattice's flags on the main stream: a later build on s_build waits
+  }
   if ((int64_t)B * p.a.chunks > 0x7fffffffLL) return fail(ctx, LYNX_ERR_INVALID, "grid too large");
   // Workgroup records: a ring of buffers, so that the reduction of call n (side stream) can still read its records
   // while the streaming kernels of calls n+1.. write theirs.  The host makes sure the slot's previous reduction is done.

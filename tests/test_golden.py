@@ -12,7 +12,7 @@ import pytest
 from oracle import lynx_oracle as o
 from tests.golden import make_golden as mg
 
-from .helpers import map_err, rel_err
+from .helpers import assert_parameter_beam, map_err, rel_err
 
 G = np.load(Path(__file__).parent / "golden" / "lynx_golden.npz")
 DTYPES = [np.float32, np.float64]
@@ -94,7 +94,10 @@ def test_gpu_reproduces_golden(dtype, built_library):
     pb = lx.ParameterBeam.from_parameters(sigma_x=np.full(3, 1e-4, dtype), sigma_xp=np.full(3, 1e-5, dtype),
                                           mu_x=np.asarray([1e-4, -2e-4, 0.0], dtype), energy=np.full(3, 6e6, dtype), dtype=dtype)
     pout = seg.track(pb)
-    assert rel_err(pout._mu, G[f"mixed/mu_out/{tag}"]) < (3e-3 if dtype == np.float32 else 1e-9)
+    # mu AND the covariance, entry by entry at north_star's tolerance (measured, scripts/gpu/r3_pb_study.py: 2.4e-6 / 1.8e-5
+    # from the float32 fixture; the float32 reference itself sits 6e-3 from float64 in mu_p here: phase + float32 cos)
+    assert_parameter_beam(pout, {"mu": G[f"mixed/mu_out/{tag}"], "cov": G[f"mixed/cov_out/{tag}"]},
+                          1e-4 if dtype == np.float32 else 1e-9)
     # C2 moments at N = 100k
     P2 = o.gaussian_particles((1,), 100_000, seed=0, dtype=dtype)
     out2 = lx.Segment(ares).track(lx.ParticleBeam(P2, np.array([1e8], dtype), dtype=dtype))

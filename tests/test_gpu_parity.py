@@ -12,7 +12,7 @@ import pytest
 
 from oracle import lynx_oracle as o
 
-from .helpers import make_lattice, map_err, rel_err
+from .helpers import assert_parameter_beam, make_lattice, map_err, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -327,6 +327,49 @@ def test_c4_shape_moments_match_the_reference_chain(lx):
         assert rel_err(got[..., c], ref["particles"][..., c]) < 1e-4, c
 
 
+def test_the_bench_plan_of_config_4_against_the_oracle(lx):
+    """
+    The kernel / launch combination `bench.py`'s headline number runs on, end to end against the oracle: FODO k1
+    scan, float32, B = 320 (>= 256: lanes = samples build; not a multiple of 64: a cut wave of samples), N = 100 000
+    (wave tiles with a cut last tile; B N >= 512 k: build on the second stream into the ring of step tables, host-side
+    build wait, moment reduction on the side stream), two-tile workgroups, default environment, beam generated in HBM
+    like the bench's.  THREE consecutive `track` calls, so that the builds of calls two and three run underneath the
+    previous streaming kernel and every step-table slot is used.  Oracle: `o.segment_track` on the k1 values of
+    samples {0, 63, 64, 255, 319} -- moments at north_star's 1e-4, particles of every one of them at 1e-4 of the
+    coordinate's scale.  (segment.py:329-342, element.py:83-92.)
+    """
+    B, N = 320, 100_000
+    dtype = np.float32
+    desc = _fodo_scan(B)
+    elements, _ = make_lattice(desc, dtype, lx)
+    segment = lx.Segment(elements)
+    beam = lx.ParticleBeam.synthetic((B,), N, sigma=[1e-4, 1e-5, 1e-4, 1e-5, 1e-5, 1e-3], energy=1e8, seed=2, dtype=dtype)
+    outs = [segment.track(beam) for _ in range(3)]
+    P = np.asarray(beam.particles)
+    pick = [0, 63, 64, 255, 319]
+    sub = [(kind, {k: np.asarray(v)[pick] for k, v in kw.items()}) for kind, kw in desc]
+    _, specs = make_lattice(sub, dtype)
+    e = np.full(len(pick), 1e8, dtype=dtype)
+    ref = o.segment_track(specs, o.particle_beam(P[pick], e, dtype), dtype)
+    m = o.beam_moments(ref, ddof=1)
+    records = [np.asarray(out.moment_record()) for out in outs]
+    tracked = np.asarray(outs[-1].particles)
+    for call, out in enumerate(outs):
+        for key in ("mu_x", "mu_xp", "mu_y", "mu_yp", "mu_s", "mu_p"):
+            sig = m["sigma" + key[2:]]
+            got = np.asarray(getattr(out, key))[pick]
+            assert np.all(np.abs(got - m[key]) <= 1e-4 * (np.abs(m[key]) + sig)), (call, key)
+        for key in ("sigma_x", "sigma_xp", "sigma_y", "sigma_yp", "sigma_s", "sigma_p"):
+            assert np.allclose(np.asarray(getattr(out, key))[pick], m[key], rtol=1e-4, atol=0), (call, key)
+        for key, a, b in (("sigma_xxp", "sigma_x", "sigma_xp"), ("sigma_yyp", "sigma_y", "sigma_yp")):
+            assert np.all(np.abs(np.asarray(getattr(out, key))[pick] - m[key]) <= 1e-4 * m[a] * m[b]), (call, key)
+        assert np.array_equal(records[call], records[0], equal_nan=True), call  # same input, same plan: bit for bit
+    for c in range(7):
+        assert rel_err(tracked[pick][..., c], ref["particles"][..., c]) < 1e-4, c
+    assert np.array_equal(tracked, np.asarray(outs[0].particles))
+    assert np.all(records[0][:, 35] == N)
+
+
 def test_c4_shape_composed_map_is_the_exact_product_of_its_float32_element_maps(lx):
     """The float32 build multiplies in float64: the composed map equals the float64 product of the
     GPU's own float32 element maps to float32 rounding, whatever the association.  (Against the
@@ -517,6 +560,47 @@ def test_kat1_parameter_beam_drift(lx):
     assert np.allclose(out.sigma_xp, beam.sigma_xp) and np.allclose(out.sigma_yp, beam.sigma_yp)
 
 
+def test_energy_not_above_zero_at_a_cavity_is_the_references_assertion(lx):
+    """
+    cavity.py:260 (`assert torch.all(Ei > 0)`) for energies the host never sees: the check runs on the device while
+    the cavities' whole-batch predicates are evaluated (k_cavity_flags) and surfaces as AssertionError at the next
+    read-back or sync.  (a) a beam whose energy exists in HBM only -- the output of an earlier program -- and is
+    negative; (b) one sample of a batch decelerated through zero by the first cavity of the SAME program;
+    (c) the incoming energy of a host-resident beam is still refused at once.
+    """
+    from lynx_amd.device import get_runtime
+
+    dtype = np.float32
+    f = lambda *v: np.asarray(v, dtype=dtype)  # noqa: E731
+    P = o.gaussian_particles((2,), 4096, seed=4, dtype=dtype, sigma=[1e-4, 1e-5, 1e-4, 1e-5, 1e-5, 1e-3])
+    brake = lx.Cavity(f(1.0, 1.0), voltage=f(2e7, 2e7), phase=f(0.0, 180.0), frequency=f(1.3e9, 1.3e9), dtype=dtype)
+    boost = lx.Cavity(f(1.0, 1.0), voltage=f(1e7, 1e7), phase=f(0.0, 0.0), frequency=f(1.3e9, 1.3e9), dtype=dtype)
+    beam = lx.ParticleBeam(P, f(6e6, 6e6), dtype=dtype)
+    # (a) sample 1 leaves the first segment with 6 MeV - 20 MeV < 0 (the batch moves on: sample 0 gains)
+    mid = lx.Segment([lx.Drift(f(0.1, 0.1), dtype=dtype), brake]).track(beam)
+    assert mid._energy._host is None  # lives in HBM only: nothing was read back
+    out = lx.Segment([lx.Drift(f(0.1, 0.1), dtype=dtype), boost]).track(mid)  # enqueued without complaint ...
+    with pytest.raises(AssertionError, match="Initial energy must be larger than 0"):
+        np.asarray(out.particles)  # ... and refused when the result is looked at
+    get_runtime().sync()  # the flag was consumed: the runtime is usable again
+    # (b) both cavities in one program
+    out = lx.Segment([brake, lx.Drift(f(0.1, 0.1), dtype=dtype), boost]).track(beam)
+    with pytest.raises(AssertionError, match="Initial energy must be larger than 0"):
+        get_runtime().sync()
+    # a healthy program afterwards is not affected
+    good = lx.Segment([boost, lx.Drift(f(0.1, 0.1), dtype=dtype), boost]).track(beam)
+    assert np.allclose(good.energy, 6e6 + 2e7)
+    # (c) host-resident incoming energy: at once, as before
+    with pytest.raises(AssertionError, match="Initial energy must be larger than 0"):
+        lx.Segment([boost]).track(lx.ParticleBeam(P, f(6e6, -1.0), dtype=dtype))
+    # ParameterBeam path, same rule
+    pb = lx.ParameterBeam.from_parameters(energy=f(6e6, 6e6), dtype=dtype)
+    pmid = lx.Segment([brake]).track(pb)
+    pout = lx.Segment([boost]).track(pmid)
+    with pytest.raises(AssertionError, match="Initial energy must be larger than 0"):
+        np.asarray(pout._mu)
+
+
 def test_kat4_cavity_bmad_twiss(lx):
     """reference tests/test_compare_ocelot.py:627-654 (Bmad-confirmed Twiss after the cavity)."""
     beam = lx.ParameterBeam.from_twiss(
@@ -552,12 +636,10 @@ def test_parameter_beam_through_mixed_lattice(lx, dtype):
     ref_in = o.parameter_beam_from_parameters(dtype=dtype, **kw)
     out = lx.Segment(elements).track(beam)
     ref = o.segment_track(specs, ref_in, dtype)
-    tol = 2e-3 if dtype == np.float32 else 1e-9
-    assert rel_err(out._mu, ref["mu"]) < tol
-    for i in range(6):
-        for j in range(6):
-            s = np.sqrt(np.abs(ref["cov"][..., i, i] * ref["cov"][..., j, j])) + 1e-300
-            assert np.max(np.abs(out._cov[..., i, j] - ref["cov"][..., i, j]) / s) < tol * 10, (i, j)
+    # north_star's tolerances, entry by entry.  Measured on MI355X (scripts/gpu/r3_pb_study.py, float32): product vs
+    # float32 oracle 2.8e-5 (mu) / 4.0e-6 (cov), float32 oracle vs float64 oracle 7.9e-7 / 3.1e-5 -- nothing in
+    # cavity.py:134-140, 202-218 cancels in float32 on this lattice.
+    assert_parameter_beam(out, ref, 1e-4 if dtype == np.float32 else 1e-9)
     assert rel_err(out.energy, ref["energy"]) < 1e-6
 
 
@@ -589,12 +671,9 @@ def test_parameter_beam_lanes_path_agrees_with_the_workgroup_path(lx, monkeypatc
         outs[name] = (np.array(out._mu), np.array(out._cov), np.array(out.energy))
     ref = o.segment_track(specs, o.parameter_beam_from_parameters(dtype=dtype, **kw), dtype)
     for name, (mu, cov, energy) in outs.items():
-        assert rel_err(mu, ref["mu"]) < 2e-3, name
+        # measured (scripts/gpu/r3_pb_study.py): 3.4e-5 (mu) / 5.5e-6 (cov) from the float32 oracle on either path
+        assert_parameter_beam((mu, cov), ref, 1e-4, name)
         assert rel_err(energy, ref["energy"]) < 1e-6, name
-        for i in range(6):
-            for j in range(6):
-                sc = np.sqrt(np.abs(ref["cov"][..., i, i] * ref["cov"][..., j, j])) + 1e-300
-                assert np.max(np.abs(cov[..., i, j] - ref["cov"][..., i, j]) / sc) < 2e-2, (name, i, j)
     a, b = outs["workgroup"], outs["lanes"]
     assert rel_err(b[0], a[0]) < 1e-5 and np.array_equal(a[2], b[2])
     sc = np.sqrt(np.abs(np.einsum("bii,bjj->bij", a[1][..., :6, :6], a[1][..., :6, :6]))) + 1e-300
