@@ -262,23 +262,117 @@ constexpr int kFlagsPerThread = 8;  // samples whose energy a thread of k_cavity
 // sample that does not sets word 0 and leaves the element's index in word 1; the host looks at it when it waits for
 // the GPU next (lynx_sync, lynx_buf_d2h) -- no read-back per call, and a beam whose energy lives in HBM only (the
 // output of an earlier cavity program) is checked like any other.
+//
+// Two kernels.  The walk is serial in the cavities only through `any(E + dE > 0)`: when it holds -- as good as always
+// -- every sample simply moves on with E + dE.  k_cavity_flags_spec ASSUMES that: one lane per sample, any number of
+// workgroups, every lane walks its own sample through the cavities and the predicates are OR-ed into one word per
+// cavity (wave ballot + one atomic per wave).  k_cavity_flags (ONE workgroup of 256) then checks the assumption on
+// those words; if every step cavity's batch gains energy it only has to copy the bits into the element / step flags,
+// otherwise it redoes the walk the serial way.  (One workgroup of 1024 walking 8 cavities through four block-wide
+// reductions each took 45 us alone and 500 us underneath BASELINE config 5's streaming kernel: sixteen waves on one
+// CU do not find room next to it.  The pair takes a few microseconds and its waves fit anywhere.)
+constexpr int kBadEnergy = 1 << 30;
+
 template <typename T>
-__global__ __launch_bounds__(1024) void k_cavity_flags(LatticeDev lat, lynx_elem* elems, lynx_step* steps,
-                                                       const T* __restrict__ energy_in, T* __restrict__ e_run,
-                                                       int32_t* __restrict__ status) {
+__device__ __forceinline__ T cavity_look(const T* pool, const lynx_elem& el, bool is_step, T energy, int64_t b, int& mine) {
+  if (!(energy > T(0))) mine |= kBadEnergy;  // cavity.py:260 (NaN fails the assertion too)
+  const T* p = pool + el.param_offset + b * (int64_t)el.batch_stride;
+  const T voltage = p[1];
+  const T d_energy = voltage * t_cos(p[2] * T(LYNX_PI / 180.0));
+  if (voltage != T(0) && energy != T(0)) mine |= LYNX_FLAG_CAV_BETA;
+  if (is_step) {
+    if (energy + d_energy > T(0)) mine |= LYNX_FLAG_CAV_GAIN;
+    if (d_energy > T(0)) mine |= LYNX_FLAG_CAV_T5XX;
+  }
+  return d_energy;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_cavity_flags_spec(LatticeDev lat, const T* __restrict__ energy_in,
+                                                           int32_t* __restrict__ words) {
+  const T* pool = static_cast<const T*>(lat.pool);
+  const int64_t b_raw = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = b_raw < lat.batch;
+  const int64_t b = live ? b_raw : lat.batch - 1;
+  T energy = energy_in[b];
+  int c = 0;
+  for (int s = 0; s < lat.n_steps; ++s) {
+    const lynx_step st = lat.steps[s];
+    for (int e = st.first; e < st.last; ++e) {
+      const lynx_elem el = lat.elems[e];
+      if (el.kind != LYNX_KIND_CAVITY) continue;  // uniform
+      const bool is_step = st.kind == LYNX_STEP_CAVITY;
+      int mine = 0;
+      const T d_energy = cavity_look<T>(pool, el, is_step, energy, b, mine);
+      if (!live) mine = 0;
+      int bits = 0;
+      if (__builtin_amdgcn_ballot_w64((mine & LYNX_FLAG_CAV_BETA) != 0)) bits |= LYNX_FLAG_CAV_BETA;
+      if (__builtin_amdgcn_ballot_w64((mine & LYNX_FLAG_CAV_GAIN) != 0)) bits |= LYNX_FLAG_CAV_GAIN;
+      if (__builtin_amdgcn_ballot_w64((mine & LYNX_FLAG_CAV_T5XX) != 0)) bits |= LYNX_FLAG_CAV_T5XX;
+      if (__builtin_amdgcn_ballot_w64((mine & kBadEnergy) != 0)) bits |= kBadEnergy;
+      if ((threadIdx.x & 63) == 0 && bits) atomicOr(&words[c], bits);
+      if (is_step) energy = energy + d_energy;  // the assumption: this cavity's batch gains energy (cavity.py:128-130)
+      ++c;
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_cavity_flags(LatticeDev lat, lynx_elem* elems, lynx_step* steps,
+                                                      const T* __restrict__ energy_in, T* __restrict__ e_run,
+                                                      int32_t* __restrict__ status, int32_t* __restrict__ words) {
   const T* pool = static_cast<const T*>(lat.pool);
   const int64_t B = lat.batch;
-  // every sample's energy on its way through the cavities: in registers for batches of up to 8192, in
+  const int nt = blockDim.x;
+  if (words) {
+    // what k_cavity_flags_spec found: valid if every step cavity's batch gains energy
+    __shared__ int s_valid;
+    if (threadIdx.x == 0) {
+      int c = 0, valid = 1;
+      for (int s = 0; s < lat.n_steps; ++s) {
+        const lynx_step st = steps[s];
+        for (int e = st.first; e < st.last; ++e) {
+          if (elems[e].kind != LYNX_KIND_CAVITY) continue;
+          if (st.kind == LYNX_STEP_CAVITY && !(words[c] & LYNX_FLAG_CAV_GAIN)) valid = 0;
+          ++c;
+        }
+      }
+      if (valid) {
+        c = 0;
+        for (int s = 0; s < lat.n_steps; ++s) {
+          const lynx_step st = steps[s];
+          for (int e = st.first; e < st.last; ++e) {
+            const lynx_elem el = elems[e];
+            if (el.kind != LYNX_KIND_CAVITY) continue;
+            const int w = words[c];
+            const int f = w & kCavMask;
+            elems[e].flags = (el.flags & ~kCavMask) | f;
+            if (st.kind == LYNX_STEP_CAVITY) steps[s].flags = (st.flags & ~kCavMask) | f;
+            if ((w & kBadEnergy) && status) {
+              if (__hip_atomic_exchange(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0)
+                __hip_atomic_store(status + 1, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // the first one found
+            }
+            ++c;
+          }
+        }
+      }
+      for (int k = 0; k < c; ++k) words[k] = 0;  // ready for the next call
+      s_valid = valid;
+    }
+    __syncthreads();
+    if (s_valid) return;
+  }
+  // every sample's energy on its way through the cavities: in registers for batches of up to 8 per thread, in
   // `e_run` beyond (hundreds of thousands of ParameterBeam settings)
-  const bool in_regs = B <= (int64_t)kFlagsPerThread * 1024;
+  const bool in_regs = B <= (int64_t)kFlagsPerThread * nt;
   T e_reg[kFlagsPerThread];
 #pragma unroll
   for (int q = 0; q < kFlagsPerThread; ++q) {
-    const int64_t b = threadIdx.x + (int64_t)q * 1024;
+    const int64_t b = threadIdx.x + (int64_t)q * nt;
     e_reg[q] = b < B ? energy_in[b] : T(1);
   }
   if (!in_regs)
-    for (int64_t b = threadIdx.x; b < B; b += blockDim.x) e_run[b] = energy_in[b];
+    for (int64_t b = threadIdx.x; b < B; b += nt) e_run[b] = energy_in[b];
   __syncthreads();
   for (int s = 0; s < lat.n_steps; ++s) {
     const lynx_step st = steps[s];
@@ -287,28 +381,15 @@ __global__ __launch_bounds__(1024) void k_cavity_flags(LatticeDev lat, lynx_elem
       if (el.kind != LYNX_KIND_CAVITY) continue;  // uniform
       const bool is_step = st.kind == LYNX_STEP_CAVITY;
       int mine = 0;
-      constexpr int kBadEnergy = 1 << 30;
       T de_reg[kFlagsPerThread];
-      auto look = [&](T energy, int64_t b) -> T {
-        if (!(energy > T(0))) mine |= kBadEnergy;  // cavity.py:260 (NaN fails the assertion too)
-        const T* p = pool + el.param_offset + b * (int64_t)el.batch_stride;
-        const T voltage = p[1];
-        const T d_energy = voltage * t_cos(p[2] * T(LYNX_PI / 180.0));
-        if (voltage != T(0) && energy != T(0)) mine |= LYNX_FLAG_CAV_BETA;
-        if (is_step) {
-          if (energy + d_energy > T(0)) mine |= LYNX_FLAG_CAV_GAIN;
-          if (d_energy > T(0)) mine |= LYNX_FLAG_CAV_T5XX;
-        }
-        return d_energy;
-      };
       if (in_regs) {
 #pragma unroll
         for (int q = 0; q < kFlagsPerThread; ++q) {
-          const int64_t b = threadIdx.x + (int64_t)q * 1024;
-          de_reg[q] = b < B ? look(e_reg[q], b) : T(0);
+          const int64_t b = threadIdx.x + (int64_t)q * nt;
+          de_reg[q] = b < B ? cavity_look<T>(pool, el, is_step, e_reg[q], b, mine) : T(0);
         }
       } else {
-        for (int64_t b = threadIdx.x; b < B; b += blockDim.x) (void)look(e_run[b], b);
+        for (int64_t b = threadIdx.x; b < B; b += nt) (void)cavity_look<T>(pool, el, is_step, e_run[b], b, mine);
       }
       int f = 0;
       if (__syncthreads_or(mine & LYNX_FLAG_CAV_BETA)) f |= LYNX_FLAG_CAV_BETA;
@@ -327,7 +408,7 @@ __global__ __launch_bounds__(1024) void k_cavity_flags(LatticeDev lat, lynx_elem
 #pragma unroll
           for (int q = 0; q < kFlagsPerThread; ++q) e_reg[q] = e_reg[q] + de_reg[q];
         } else {
-          for (int64_t b = threadIdx.x; b < B; b += blockDim.x) {
+          for (int64_t b = threadIdx.x; b < B; b += nt) {
             const T* p = pool + el.param_offset + b * (int64_t)el.batch_stride;
             e_run[b] = e_run[b] + p[1] * t_cos(p[2] * T(LYNX_PI / 180.0));
           }
@@ -397,8 +478,12 @@ __device__ __forceinline__ T energy_before_step(const LatticeDev& lat, int64_t b
 // kernel has to fit next to the streaming kernel's waves to run underneath it.
 template <typename T> constexpr size_t build_pieces_lds() { return 49 * 64 * sizeof(double) + 64 * 49 * sizeof(T); }
 
+// (at most 128 registers per lane: the build runs underneath the previous call's streaming kernel, whose waves hold
+// 96 of a SIMD's 512 registers each at five per SIMD -- one of them retiring must make room for a build wave.  At the
+// 160 registers the compiler would take, a build wave waited for TWO to retire on the same SIMD and the kernel that
+// takes 31 us alone took 710 us next to BASELINE config 5's streaming kernel: the whole step waited for the build.)
 template <typename T>
-__global__ __launch_bounds__(64) void k_build_pieces(LatticeDev lat, const BuildPiece* __restrict__ pieces,
+__global__ __launch_bounds__(64, 4) void k_build_pieces(LatticeDev lat, const BuildPiece* __restrict__ pieces,
                                                      const T* __restrict__ energy_in, int64_t Bp,
                                                      double* __restrict__ products, T* __restrict__ coefs) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -511,7 +596,7 @@ __device__ __forceinline__ void emit_row(const double* src, int64_t Bp, int i, b
 }
 
 template <typename T>
-__global__ __launch_bounds__(64) void k_emit_steps(LatticeDev lat, const int32_t* __restrict__ step_slot,
+__global__ __launch_bounds__(64, 4) void k_emit_steps(LatticeDev lat, const int32_t* __restrict__ step_slot,
                                                    const T* __restrict__ energy_in, int64_t Bp,
                                                    const double* __restrict__ products, const T* __restrict__ coefs,
                                                    int merge_pairs, T* __restrict__ steps_out, T* __restrict__ energy_out) {
@@ -1229,6 +1314,61 @@ struct LaneSums {
   }
 };
 
+// Workgroup reduction of the lane sums of a streaming kernel into ONE partial record (epilogue of k_track_direct and
+// k_track_units; 256 threads, `s_scratch` >= the slab of kMomSlabScalars* scalars, reused).
+template <typename T, int MOM, bool FULL>
+__device__ __forceinline__ void workgroup_moment_record(const LaneSums<T, MOM, FULL>& sums, const T (&shift)[6],
+                                                        unsigned char* s_scratch, double* __restrict__ out) {
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  {
+    // Workgroup reduction of the 29 sums through LDS: every lane parks its values in a
+    // [29][65] slab of its wave (row pitch 65 -> conflict-free both ways), lanes 0..28 then
+    // each add up one row in float64.  A 64-lane shuffle tree of 29 values costs ~350
+    // ds_bpermute per wave; this costs 29 stores and 64 loads per lane and is the larger part
+    // of a workgroup's fixed cost when it only owns a few thousand particles.
+    using R = typename MomScratch<MOM>::type;
+    using Sums = LaneSums<T, MOM, FULL>;
+    constexpr int kRows = Sums::kRows;  // 29 with the whole covariance, 16 with the property set
+    __syncthreads();  // the scratch (build scratch / wave tiles) is reused
+    R* slab = reinterpret_cast<R*>(s_scratch) + wave * (kRows * 65);
+    sums.park(slab, lane);
+    __syncthreads();
+    double tot = 0.0;
+    if (lane < kRows) {
+      const R* row = slab + lane * 65;
+#pragma unroll 8
+      for (int k = 0; k < 64; ++k) tot += (double)row[k];
+    }
+    __syncthreads();
+    // one record per wave (layout of moment_slot_moved), then the four are moved to wave 0's
+    // reference point and added in wave order
+    double* s_red = reinterpret_cast<double*>(s_scratch);  // [4][36]
+    if (lane < kPartialStride) s_red[wave * kPartialStride + lane] = 0.0;
+    __syncthreads();
+    if (lane < kRows) s_red[wave * kPartialStride + Sums::slot_of_row(lane)] = tot;
+    // lane 0 publishes the reference point: it was assigned inside the loop, where lanes beyond the
+    // end of the sample are no longer active and so never received it
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) s_red[wave * kPartialStride + 28 + k] = (double)shift[k];
+      s_red[wave * kPartialStride + 34] = FULL ? 1.0 : 0.0;  // which second moments the record carries
+    }
+    __syncthreads();
+    if (tid < kPartialStride) {
+      double v;
+      if (tid >= 28 && tid < 35) {
+        v = s_red[tid];
+      } else {
+        v = 0.0;
+#pragma unroll
+        for (int w = 0; w < kTrackThreads / 64; ++w) v += moment_slot_moved(s_red + w * kPartialStride, s_red + 28, tid);
+      }
+      out[tid] = v;
+    }
+  }
+}
+
 // the whole program on the UNROLL particles a lane holds in registers: steps outermost, so that each
 // step's map is fetched once per iteration (fp32: 57 scalar loads into SGPRs; fp64: read from LDS) for
 // all of them; fp32 with an even UNROLL runs the particles as packed pairs
@@ -1562,53 +1702,7 @@ __global__ __launch_bounds__(kTrackThreads, (track_waves_per_simd<T, MOM, FULL, 
     }
   }
 
-  if (MOM) {
-    // Workgroup reduction of the 29 sums through LDS: every lane parks its values in a
-    // [29][65] slab of its wave (row pitch 65 -> conflict-free both ways), lanes 0..28 then
-    // each add up one row in float64.  A 64-lane shuffle tree of 29 values costs ~350
-    // ds_bpermute per wave; this costs 29 stores and 64 loads per lane and is the larger part
-    // of a workgroup's fixed cost when it only owns a few thousand particles.
-    using R = typename MomScratch<MOM>::type;
-    using Sums = LaneSums<T, MOM, FULL>;
-    constexpr int kRows = Sums::kRows;  // 29 with the whole covariance, 16 with the property set
-    __syncthreads();  // the scratch (build scratch / wave tiles) is reused
-    R* slab = reinterpret_cast<R*>(s_scratch) + wave * (kRows * 65);
-    sums.park(slab, lane);
-    __syncthreads();
-    double tot = 0.0;
-    if (lane < kRows) {
-      const R* row = slab + lane * 65;
-#pragma unroll 8
-      for (int k = 0; k < 64; ++k) tot += (double)row[k];
-    }
-    __syncthreads();
-    // one record per wave (layout of moment_slot_moved), then the four are moved to wave 0's
-    // reference point and added in wave order
-    double* s_red = reinterpret_cast<double*>(s_scratch);  // [4][36]
-    if (lane < kPartialStride) s_red[wave * kPartialStride + lane] = 0.0;
-    __syncthreads();
-    if (lane < kRows) s_red[wave * kPartialStride + Sums::slot_of_row(lane)] = tot;
-    // lane 0 publishes the reference point: it was assigned inside the loop, where lanes beyond the
-    // end of the sample are no longer active and so never received it
-    if (lane == 0) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) s_red[wave * kPartialStride + 28 + k] = (double)shift[k];
-      s_red[wave * kPartialStride + 34] = FULL ? 1.0 : 0.0;  // which second moments the record carries
-    }
-    __syncthreads();
-    double* out = partials + ((int64_t)b * a.chunks + chunk) * kPartialStride;
-    if (tid < kPartialStride) {
-      double v;
-      if (tid >= 28 && tid < 35) {
-        v = s_red[tid];
-      } else {
-        v = 0.0;
-#pragma unroll
-        for (int w = 0; w < kTrackThreads / 64; ++w) v += moment_slot_moved(s_red + w * kPartialStride, s_red + 28, tid);
-      }
-      out[tid] = v;
-    }
-  }
+  if (MOM) workgroup_moment_record<T, MOM, FULL>(sums, shift, s_scratch, partials + ((int64_t)b * a.chunks + chunk) * kPartialStride);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -19,6 +19,7 @@
 
 #include "lynx_device.hpp"
 #include "lynx_grad.hpp"
+#include "lynx_units.hpp"
 
 using namespace lynx;
 
@@ -69,6 +70,8 @@ struct lynx_ctx {
   static constexpr int kTableBwd = kTableSlots, kTablePb = kTableSlots + 1;
   void* scratch_steps[kTableSlots + 2] = {};  // the ring of step tables, the reverse pass's own, the ParameterBeam lanes path's
   size_t scratch_steps_bytes[kTableSlots + 2] = {};
+  void* scratch_units[2 * kTableSlots] = {};  // compact unit records of multi-step float32 programs (lynx_units.hpp) and their class-D extras, per table slot
+  size_t scratch_units_bytes[2 * kTableSlots] = {};
   void* scratch_grad[3] = {nullptr, nullptr, nullptr};  // backward: partials, T_bar, build scratch
   size_t scratch_grad_bytes[3] = {0, 0, 0};
   ncclComm_t comm = nullptr;
@@ -119,6 +122,8 @@ struct lynx_lattice {
   int32_t n_elems = 0, n_steps = 0;
   int32_t n_observers = 0;  // steps with LYNX_STEP_FLAG_OBSERVE (kept current by lynx_lattice_set_flags)
   bool has_cavity = false;  // any cavity element: its whole-batch predicates are evaluated on the device
+  int32_t n_cavities = 0;
+  int32_t* d_cav_words = nullptr;  // one word per cavity: the predicates OR-ed over the batch (k_cavity_flags_spec); kept zero between calls
   int64_t pool_count = 0;
   std::vector<lynx_elem> h_elems;
   std::vector<lynx_step> h_steps;
@@ -332,6 +337,8 @@ int lynx_ctx_destroy(lynx_ctx* ctx) {
   if (ctx->scratch_coefs) (void)hipFree(ctx->scratch_coefs);
   for (int i = 0; i < lynx_ctx::kTableSlots + 2; ++i)
     if (ctx->scratch_steps[i]) (void)hipFree(ctx->scratch_steps[i]);
+  for (int i = 0; i < 2 * lynx_ctx::kTableSlots; ++i)
+    if (ctx->scratch_units[i]) (void)hipFree(ctx->scratch_units[i]);
   for (int i = 0; i < 3; ++i)
     if (ctx->scratch_grad[i]) (void)hipFree(ctx->scratch_grad[i]);
   for (int i = 0; i < lynx_ctx::kTableSlots; ++i) {
@@ -621,7 +628,8 @@ int lynx_lattice_create(lynx_ctx* ctx, int dtype, int64_t batch, int32_t n_elems
   lat->pool_count = pool_count;
   lat->h_elems.assign(elems, elems + n_elems);
   lat->h_steps.assign(steps, steps + n_steps);
-  for (int32_t e = 0; e < n_elems; ++e) lat->has_cavity |= elems[e].kind == LYNX_KIND_CAVITY;
+  for (int32_t e = 0; e < n_elems; ++e) lat->n_cavities += elems[e].kind == LYNX_KIND_CAVITY ? 1 : 0;
+  lat->has_cavity = lat->n_cavities > 0;
   const size_t es = dtype_size(dtype);
   int rc;
   if ((rc = count_observers(ctx, lat))) {
@@ -639,6 +647,13 @@ int lynx_lattice_create(lynx_ctx* ctx, int dtype, int64_t batch, int32_t n_elems
   HIP_TRY(ctx, hipMemcpyAsync(lat->d_steps, steps, n_steps * sizeof(lynx_step), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(lat->d_elem_step, elem_step.data(), n_elems * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(lat->d_pool, pool, pool_count * es, hipMemcpyHostToDevice, ctx->stream));
+  if (lat->has_cavity) {
+    if ((rc = ctx_alloc(ctx, (size_t)lat->n_cavities * sizeof(int32_t), (void**)&lat->d_cav_words))) {
+      delete lat;
+      return rc;
+    }
+    HIP_TRY(ctx, hipMemsetAsync(lat->d_cav_words, 0, (size_t)lat->n_cavities * sizeof(int32_t), ctx->stream));
+  }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   *out = lat;
   return LYNX_OK;
@@ -675,6 +690,7 @@ int lynx_lattice_destroy(lynx_lattice* lat) {
   ctx_free(ctx, lat->d_steps);
   ctx_free(ctx, lat->d_elem_step);
   ctx_free(ctx, lat->d_pool);
+  if (lat->d_cav_words) ctx_free(ctx, lat->d_cav_words);
   if (lat->d_pieces) ctx_free(ctx, lat->d_pieces);
   if (lat->d_tasks) ctx_free(ctx, lat->d_tasks);
   if (lat->d_step_slot) ctx_free(ctx, lat->d_step_slot);
@@ -738,8 +754,16 @@ static int launch_cavity_flags(lynx_ctx* ctx, lynx_lattice* lat, hipStream_t str
   if (!lat->has_cavity || lat->n_steps == 0) return LYNX_OK;
   int rc;
   if ((rc = ensure_scratch(ctx, &ctx->scratch_erun, &ctx->scratch_erun_bytes, (size_t)lat->batch * sizeof(T)))) return rc;
-  hipLaunchKernelGGL(k_cavity_flags<T>, dim3(1), dim3(1024), 0, stream, dev_view(lat), lat->d_elems, lat->d_steps,
-                     (const T*)d_energy_in, (T*)ctx->scratch_erun, ctx->d_status);
+  // the predicates for every cavity at once, assuming every batch gains energy (one lane per sample), then one small
+  // workgroup that checks the assumption, publishes the bits and -- should it not hold -- walks the serial way
+  const bool spec = env_int("LYNX_CAVITY_FLAGS_SPEC", 1) != 0;
+  if (spec) {
+    hipLaunchKernelGGL(k_cavity_flags_spec<T>, dim3((unsigned)((lat->batch + 255) / 256)), dim3(256), 0, stream, dev_view(lat),
+                       (const T*)d_energy_in, lat->d_cav_words);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  hipLaunchKernelGGL(k_cavity_flags<T>, dim3(1), dim3(256), 0, stream, dev_view(lat), lat->d_elems, lat->d_steps,
+                     (const T*)d_energy_in, (T*)ctx->scratch_erun, ctx->d_status, spec ? lat->d_cav_words : (int32_t*)nullptr);
   HIP_TRY(ctx, hipGetLastError());
   return LYNX_OK;
 }
@@ -1007,6 +1031,80 @@ static int launch_direct(LYNX_LAUNCH_PARAMS, bool moments) {
 #undef LYNX_LAUNCH_ARGS
 #undef LYNX_LAUNCH_PARAMS
 
+// ---- multi-step float32 programs as units (lynx_units.hpp) ------------------------------------
+
+// Class a unit's map is expected to have, from the kinds and whole-batch flags of its elements (the numbers are checked
+// per sample by k_pack_units; a wrong guess costs speed, never correctness).
+static int proposed_class(const lynx_lattice* lat, int32_t first, int32_t last) {
+  int rank = 1;  // 1 = U, 2 = D, 3 = dense
+  for (int32_t e = first; e < last; ++e) {
+    const lynx_elem& el = lat->h_elems[e];
+    switch (el.kind) {
+      case LYNX_KIND_IDENTITY:
+      case LYNX_KIND_DRIFT:
+      case LYNX_KIND_HCOR:
+      case LYNX_KIND_VCOR:
+      case LYNX_KIND_CAVITY:
+      case LYNX_KIND_UNDULATOR: break;
+      case LYNX_KIND_QUADRUPOLE: rank = std::max(rank, (el.flags & LYNX_FLAG_TILT) ? 3 : 1); break;
+      case LYNX_KIND_DIPOLE: rank = std::max(rank, 2); break;  // a tilted one fails the numeric check
+      default: rank = 3; break;                                // solenoid, custom map, helper kinds
+    }
+  }
+  return rank == 1 ? kClassU : rank == 2 ? kClassD : kClassDense;
+}
+
+// The program as units: a step, or (merged) a run together with the active cavity behind it.  False if it does not fit.
+static bool plan_units(const lynx_lattice* lat, bool merged, UnitPlan* plan) {
+  const int32_t S = lat->n_steps;
+  plan->n_units = 0;
+  for (int32_t s = 0; s < S; ++s) {
+    const lynx_step& st = lat->h_steps[s];
+    if (st.flags & LYNX_STEP_FLAG_OBSERVE) return false;
+    const bool pair = merged && s + 1 < S && st.kind == LYNX_STEP_RUN && lat->h_steps[s + 1].kind == LYNX_STEP_CAVITY;
+    const int32_t last = pair ? lat->h_steps[s + 1].last : st.last;
+    if (pair) ++s;
+    if (plan->n_units >= kMaxUnits || s > 255) return false;
+    const int u = plan->n_units++;
+    plan->slot[u] = (unsigned char)s;
+    plan->pair[u] = pair ? 1 : 0;
+    plan->cls[u] = (unsigned char)proposed_class(lat, st.first, last);
+  }
+  for (int u = plan->n_units; u < kMaxUnits; ++u) plan->slot[u] = plan->cls[u] = plan->pair[u] = 0;
+  return plan->n_units > 0;
+}
+
+template <int MOM, bool FULL>
+static int launch_units_inst(lynx_ctx* ctx, const TrackPlan& p, int32_t U, int32_t S, const void* d_p_in, void* d_p_out,
+                             void* d_energy_out, const void* d_steps, const void* d_units, const void* d_extras,
+                             double* d_partials) {
+  const size_t lds = units_lds_bytes((size_t)p.a.lds_scratch_bytes, U);
+  int rc = allow_lds(ctx, k_track_units<MOM, FULL>, lds);
+  if (rc) return rc;
+  hipEvent_t e0 = nullptr, e1 = p.done;
+  if (ctx->profiling) {  // every profiled launch needs time stamps of its own
+    HIP_TRY(ctx, hipEventCreate(&e0));
+    HIP_TRY(ctx, hipEventCreate(&e1));
+  }
+  hipExtLaunchKernelGGL((k_track_units<MOM, FULL>), dim3(p.grid), dim3(kTrackThreads), (std::uint32_t)lds, ctx->stream, e0, e1,
+                        0u, p.a, U, S, (const float*)d_p_in, (float*)d_p_out, (float*)d_energy_out, (const float*)d_steps,
+                        (const float*)d_units, (const float*)d_extras, d_partials);
+  HIP_TRY(ctx, hipGetLastError());
+  if (ctx->profiling) ctx->prof_events.emplace_back(e0, e1);
+  ctx->last_stream_stop = e1;
+  return LYNX_OK;
+}
+
+static int launch_units(lynx_ctx* ctx, const TrackPlan& p, int32_t U, int32_t S, const void* d_p_in, void* d_p_out,
+                        void* d_energy_out, const void* d_steps, const void* d_units, const void* d_extras,
+                        double* d_partials, bool moments) {
+#define LYNX_UNITS_ARGS ctx, p, U, S, d_p_in, d_p_out, d_energy_out, d_steps, d_units, d_extras, d_partials
+  if (!moments) return launch_units_inst<0, false>(LYNX_UNITS_ARGS);
+  if (p.mom_mode == 3) return p.full_cov ? launch_units_inst<3, true>(LYNX_UNITS_ARGS) : launch_units_inst<3, false>(LYNX_UNITS_ARGS);
+  return p.full_cov ? launch_units_inst<2, true>(LYNX_UNITS_ARGS) : launch_units_inst<2, false>(LYNX_UNITS_ARGS);
+#undef LYNX_UNITS_ARGS
+}
+
 template <typename T>
 static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev& lv, int64_t B, int64_t N,
                              const void* d_energy_in, const void* d_p_in, void* d_p_out, void* d_energy_out,
@@ -1028,6 +1126,10 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
   p.a.in_stride = shared_in ? 0 : N * 7;
   p.a.merged_pairs = 0;
   const void* d_steps = nullptr;
+  const void* d_units = nullptr;
+  const void* d_extras = nullptr;
+  UnitPlan units;
+  bool use_units = false;
   int rc;
   int slot = -1;
   bool async_build = false;
@@ -1061,6 +1163,28 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
       }
     }
     if ((rc = launch_build<T>(ctx, lat, bs, d_energy_in, ctx->scratch_steps[slot], nullptr, p.a.merged_pairs, async))) return rc;
+    if constexpr (sizeof(T) == 4) {
+      // multi-step programs: walked as units with structured maps (lynx_units.hpp); LYNX_TRACK_UNITS=0 keeps the
+      // dense step loop of k_track_direct
+      // (LYNX_TRACK_UNITS=2: insist -- an error if this call cannot take the structured loop; for tests)
+      const int want_units = env_int("LYNX_TRACK_UNITS", 1);
+      use_units = S > 1 && p.unroll == 2 && !p.xpose && p.a.n_observers == 0 && !p.a.interleave && want_units &&
+                  plan_units(lat, p.a.merged_pairs != 0, &units) && B * units.n_units * kUnitStride < 0x7fffffffLL;
+      if (want_units == 2 && !use_units)
+        return fail(ctx, LYNX_ERR_INVALID, "LYNX_TRACK_UNITS=2: this call does not take the structured step loop");
+      if (use_units) {
+        const int64_t n = B * units.n_units;
+        const int xs = lynx_ctx::kTableSlots + slot;
+        if ((rc = ensure_scratch(ctx, &ctx->scratch_units[slot], &ctx->scratch_units_bytes[slot], (size_t)n * kUnitStride * sizeof(float))) ||
+            (rc = ensure_scratch(ctx, &ctx->scratch_units[xs], &ctx->scratch_units_bytes[xs], (size_t)n * kUnitExtraStride * sizeof(float))))
+          return rc;
+        hipLaunchKernelGGL(k_pack_units, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, bs, units, B, S,
+                           (const float*)ctx->scratch_steps[slot], (float*)ctx->scratch_units[slot], (float*)ctx->scratch_units[xs]);
+        HIP_TRY(ctx, hipGetLastError());
+        d_units = ctx->scratch_units[slot];
+        d_extras = ctx->scratch_units[xs];
+      }
+    }
     if (async) {
       HIP_TRY(ctx, hipEventRecord(ctx->ev_built[slot], bs));
       // The HOST waits for the build instead of the main stream: no barrier packet with a foreign signal in front of
@@ -1110,7 +1234,8 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
   // build wait for everything enqueued here
   p.done = (slot >= 0 && async_build) ? ctx->ev_streamed_own[slot] : nullptr;
   if (side && !p.done) p.done = ring->track_done;  // the side stream's reduction starts behind it
-  rc = launch_direct<T>(ctx, p, lv, d_energy_in, d_p_in, d_p_out, d_energy_out, d_steps, d_partials, d_obs, moments);
+  if (use_units) rc = launch_units(ctx, p, units.n_units, S, d_p_in, d_p_out, d_energy_out, d_steps, d_units, d_extras, d_partials, moments);
+  else rc = launch_direct<T>(ctx, p, lv, d_energy_in, d_p_in, d_p_out, d_energy_out, d_steps, d_partials, d_obs, moments);
   if (rc) return rc;
   if (p.a.n_observers) {
     hipLaunchKernelGGL(k_reduce_observers, dim3((unsigned)B), dim3(64), 0, ctx->stream, d_obs, p.a.chunks,

@@ -1,0 +1,413 @@
+// Multi-step float32 programs (cavities between runs: BASELINE config 5), structure-aware.
+// Included only by lynx_hip.hip, after lynx_device.hpp.
+//
+// k_track_direct applies every step as a dense 7x7 (49 multiply-adds per particle), whatever the step is.  The maps
+// of the path are far from dense: a run of drifts, quadrupoles, correctors and misaligned quadrupoles couples x with
+// x', y with y', s with delta and nothing else, plus the affine column (track_methods.py:86-98, quadrupole.py:75-79,
+// *_corrector.py); a cavity's map is three 2x2 blocks (cavity.py:311-323); the last row of every map of the path is
+// e6.  A [run, cavity] pair of such elements has 16 entries that are not structurally zero, a run with untilted
+// dipoles 24.  Here the program is walked as UNITS (a step, or a merged [run, cavity] pair) whose maps come from a
+// COMPACT record holding exactly those entries:
+//
+//   class U  (uncoupled)        rows 0,1: cols {0,1,6}    rows 2,3: cols {2,3,6}    rows 4,5: cols {4,5}    16 entries
+//   class D  (+ x dispersion)   rows 0,1: cols {0,1,5,6}  rows 2,3: cols {2,3,6}    rows 4,5: cols {0,1,4,5,6}  24
+//   dense                       the step table's 7x7, as k_track_direct applies it
+//
+// The class of a unit is proposed by the host from the kinds and whole-batch flags of its elements (the same for
+// every sample: it selects code) and CHECKED against the numbers by k_pack_units per sample and unit: every entry
+// outside the pattern exactly zero, row 6 = e6, all 49 entries finite -- otherwise that sample takes the dense form
+// for that unit.  Skipping a term m * z with m = +-0 is exact for finite z (it adds +-0: the only trace is the sign of
+// an exactly-zero sum), so on finite beams the results are those of the dense chain, bit for bit.  A NON-FINITE
+// particle is different -- 0 * inf = NaN spreads along the row in the reference's `P @ T^T` (element.py:85) -- so a
+// wave whose tile holds a non-finite value, going in or coming out, (re)does the tile with the dense form.
+//
+// k_pack_units: step table [B][S][64] -> unit records [B][U][32] (+ [B][U][8] for class D), on the build's stream.
+// k_track_units: the streaming kernel.  Same launch geometry, particle accesses, moment sums and epilogue as the
+// two-particles-per-lane form of k_track_direct; what differs is the step loop.  k_track_direct fetches every step's
+// 61 scalars from the step table with scalar loads, per unit and tile -- two dependent L2 round trips per unit, which
+// is what that loop is bound by (measured: with structured maps but the same fetches it ran in the same time).  Here a
+// workgroup copies its sample's unit records into LDS once (1 KB for BASELINE config 5) and the step loop reads them
+// from there with wave-uniform 16-byte LDS loads: ~100 cycles instead of a trip to L2, no scalar-register pressure;
+// 16 / 24 packed multiply-adds instead of 49, the 2x2 blocks updated in place.
+#pragma once
+
+#include "lynx_device.hpp"
+
+namespace lynx {
+
+constexpr int kMaxUnits = 64;
+// A unit's compact record: 32 floats = 128 bytes, every one of them used by class U.
+constexpr int kUnitStride = 32;
+// record layout (floats; integers are stored as raw bits)
+// first half: what the kick needs; second half: the linear map
+constexpr int kUnitDesc = 0;    // bits: kUnit* below
+constexpr int kUnitSlot = 1;    // step-table slot of the unit's (dense) record
+constexpr int kUnitCoef = 4;    // 8 cavity coefficients (LYNX_C_*)
+constexpr int kUnitInv = 12;    // 4: inverse of the cavity's (s, delta) block (merged pairs)
+constexpr int kUnitMap = 16;    // 16 entries of class U, in the order of unit_entry_u()
+constexpr int kUnitExtraStride = 8;  // second array [B][U][8]: the 8 additional entries of class D, order of unit_entry_d()
+
+constexpr int kUnitKick = 1;      // active cavity: non-linear kick behind the linear map
+constexpr int kUnitInverse = 2;   // ... driven by the entry inverse (merged pair) instead of the unit's own s, delta
+constexpr int kUnitPair = 4;      // merged [run, cavity] pair
+constexpr int kUnitClassShift = 4;  // bits 4-5: the class this sample's map was found to have (dense if the check failed)
+
+enum { kClassDense = 0, kClassU = 1, kClassD = 2 };
+
+struct UnitPlan {
+  int32_t n_units;
+  unsigned char slot[kMaxUnits];  // step-table slot whose record the unit applies (the cavity's, for a merged pair)
+  unsigned char cls[kMaxUnits];   // proposed class (whole batch)
+  unsigned char pair[kMaxUnits];  // 1: merged [run, cavity] pair
+};
+
+// (row, col) of compact entry k of class U and of the 8 additional ones of class D
+__host__ __device__ constexpr int unit_entry_u(int k) {
+  constexpr int rc[16] = {0 * 7 + 0, 0 * 7 + 1, 0 * 7 + 6, 1 * 7 + 0, 1 * 7 + 1, 1 * 7 + 6, 2 * 7 + 2, 2 * 7 + 3,
+                          2 * 7 + 6, 3 * 7 + 2, 3 * 7 + 3, 3 * 7 + 6, 4 * 7 + 4, 4 * 7 + 5, 5 * 7 + 4, 5 * 7 + 5};
+  return rc[k];
+}
+__host__ __device__ constexpr int unit_entry_d(int k) {
+  constexpr int rc[8] = {0 * 7 + 5, 1 * 7 + 5, 4 * 7 + 0, 4 * 7 + 1, 4 * 7 + 6, 5 * 7 + 0, 5 * 7 + 1, 5 * 7 + 6};
+  return rc[k];
+}
+
+__host__ __device__ inline bool unit_pattern_has(int cls, int q) {
+  if (cls == kClassDense) return true;
+  for (int k = 0; k < 16; ++k)
+    if (unit_entry_u(k) == q) return true;
+  if (cls == kClassD)
+    for (int k = 0; k < 8; ++k)
+      if (unit_entry_d(k) == q) return true;
+  return false;
+}
+
+// ---------------------------------------------------------------------------------------
+// k_pack_units: one thread per (sample, unit).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_units(UnitPlan plan, int64_t B, int32_t S, const float* __restrict__ steps,
+                                                    float* __restrict__ units, float* __restrict__ extras) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int U = plan.n_units;
+  if (i >= B * U) return;
+  const int64_t b = i / U;
+  const int u = (int)(i - b * U);
+  const int slot = plan.slot[u], cls = plan.cls[u];
+  const float* rec = steps + (b * S + slot) * LYNX_STEP_STRIDE;
+  float m[49];
+#pragma unroll
+  for (int q = 0; q < 49; ++q) m[q] = rec[q];
+  const int desc = (int)rec[LYNX_FLAGS_OFFSET];
+  const bool kick = ((desc >> LYNX_DESC_KIND_SHIFT) & 3) == LYNX_STEP_CAVITY && (desc & LYNX_FLAG_CAV_GAIN);
+  bool ok = cls != kClassDense;
+  for (int q = 0; q < 49 && ok; ++q) {
+    const float v = m[q];
+    if (!(__builtin_fabsf(v) <= 3.4028234664e38f)) ok = false;  // NaN or Inf anywhere: dense
+    if (q >= 42) {
+      if (v != (q == 48 ? 1.0f : 0.0f)) ok = false;  // row 6 must be e6
+    } else if (!unit_pattern_has(cls, q) && v != 0.0f) {
+      ok = false;
+    }
+  }
+  float* out = units + i * kUnitStride;
+  const int bits = (kick ? kUnitKick : 0) | ((kick && plan.pair[u]) ? kUnitInverse : 0) | (plan.pair[u] ? kUnitPair : 0) |
+                   ((ok ? cls : kClassDense) << kUnitClassShift);
+  out[kUnitDesc] = __int_as_float(bits);
+  out[kUnitSlot] = __int_as_float(slot);
+  out[2] = 0.f;
+  out[3] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) out[kUnitMap + k] = m[unit_entry_u(k)];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) out[kUnitCoef + k] = rec[LYNX_COEF_OFFSET + k];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) out[kUnitInv + k] = rec[LYNX_ENTRY_OFFSET + k];
+  float* ex = extras + i * kUnitExtraStride;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) ex[k] = m[unit_entry_d(k)];
+}
+
+// ---------------------------------------------------------------------------------------
+// the step loop's pieces
+// ---------------------------------------------------------------------------------------
+
+// The cavity's non-linear kick on a pair of particles: the expressions of apply_step_pair (lynx_device.hpp), which
+// are device_cavity_kick's (cavity.py:141-161, 219-226), operation for operation.
+__device__ __forceinline__ void unit_kick(const float (&coef)[8], lynx_f32x2 s_in, lynx_f32x2 d_in, lynx_f32x2& o4,
+                                          lynx_f32x2& o5) {
+  const lynx_f32x2 arg = -1.0f * s_in * coef[LYNX_C_BK] + coef[LYNX_C_PHI];
+  const lynx_f32x2 ca = phase_cos(arg);
+  o5 = d_in * coef[LYNX_C_DSCALE] + coef[LYNX_C_DKICK] * (ca - coef[LYNX_C_COSPHI]);
+  o4 = o4 + (coef[LYNX_C_T566] * (d_in * d_in) + coef[LYNX_C_T556] * s_in * d_in + coef[LYNX_C_T555] * (s_in * s_in));
+}
+
+// one 2-row block with up to four columns: (za, zb) <- rows (ra, rb) applied to the given columns, in ascending
+// column order like the dense chain
+template <int N>
+__device__ __forceinline__ lynx_f32x2 row_dot(const float (&m)[N], const lynx_f32x2 (&v)[N]) {
+  lynx_f32x2 acc = v[0] * m[0];
+#pragma unroll
+  for (int k = 1; k < N; ++k) acc = pk_fma(v[k], m[k], acc);
+  return acc;
+}
+
+// true if any of the 14 values of the pair is NaN or Inf: 0 * x is +-0 for finite x and NaN otherwise
+__device__ __forceinline__ bool pair_not_finite(const lynx_f32x2 (&z)[7]) {
+  lynx_f32x2 acc = z[0] * 0.0f;
+#pragma unroll
+  for (int k = 1; k < 7; ++k) acc = pk_fma(z[k], 0.0f, acc);
+  return (acc.x != acc.x) || (acc.y != acc.y);
+}
+
+template <int MOM, bool FULL> constexpr int units_waves_per_simd() { return (!FULL && (MOM == 0 || MOM == 3)) ? 5 : 1; }
+
+// half a unit record (16 scalars) from the workgroup's copy in LDS: four wave-uniform 16-byte loads, every lane gets
+// the same values (they are used as the broadcast operand of the packed multiply-adds)
+struct UnitHalf {
+  float v[16];
+};
+__device__ __forceinline__ void unit_fetch(const float* __restrict__ half, UnitHalf& r) {
+#pragma unroll
+  for (int k = 0; k < 16; ++k) r.v[k] = uniform_value(half[k]);
+}
+
+// the linear map of a unit of class CLS on a pair of particles; `ex`: the class-D extras of this unit (fetched here:
+// that class pays a second round trip)
+template <int CLS>
+__device__ __forceinline__ void unit_linear(const UnitHalf& map, const float* ex, lynx_f32x2 (&z)[7]) {
+  const float* m = map.v;
+  if constexpr (CLS == kClassU) {
+    {
+      const lynx_f32x2 v[3] = {z[0], z[1], z[6]};
+      const float r0[3] = {m[0], m[1], m[2]}, r1[3] = {m[3], m[4], m[5]};
+      const lynx_f32x2 o0 = row_dot<3>(r0, v), o1 = row_dot<3>(r1, v);
+      z[0] = o0;
+      z[1] = o1;
+    }
+    {
+      const lynx_f32x2 v[3] = {z[2], z[3], z[6]};
+      const float r2[3] = {m[6], m[7], m[8]}, r3[3] = {m[9], m[10], m[11]};
+      const lynx_f32x2 o2 = row_dot<3>(r2, v), o3 = row_dot<3>(r3, v);
+      z[2] = o2;
+      z[3] = o3;
+    }
+    {
+      const lynx_f32x2 v[2] = {z[4], z[5]};
+      const float r4[2] = {m[12], m[13]}, r5[2] = {m[14], m[15]};
+      const lynx_f32x2 o4 = row_dot<2>(r4, v), o5 = row_dot<2>(r5, v);
+      z[4] = o4;
+      z[5] = o5;
+    }
+  } else {
+    static_assert(CLS == kClassD, "dense programs take units_dense_program");
+    float md[8];
+    {
+      const lynx_f32x4* q = reinterpret_cast<const lynx_f32x4*>(ex);
+      const lynx_f32x4 a = q[0], c = q[1];
+      md[0] = a.x; md[1] = a.y; md[2] = a.z; md[3] = a.w;
+      md[4] = c.x; md[5] = c.y; md[6] = c.z; md[7] = c.w;
+    }
+    const lynx_f32x2 vx[4] = {z[0], z[1], z[5], z[6]};
+    const lynx_f32x2 vs[5] = {z[0], z[1], z[4], z[5], z[6]};
+    const float r0[4] = {m[0], m[1], md[0], m[2]}, r1[4] = {m[3], m[4], md[1], m[5]};
+    const float r4[5] = {md[2], md[3], m[12], m[13], md[4]}, r5[5] = {md[5], md[6], m[14], m[15], md[7]};
+    const lynx_f32x2 o0 = row_dot<4>(r0, vx), o1 = row_dot<4>(r1, vx);
+    const lynx_f32x2 o4 = row_dot<5>(r4, vs), o5 = row_dot<5>(r5, vs);
+    {
+      const lynx_f32x2 v[3] = {z[2], z[3], z[6]};
+      const float r2[3] = {m[6], m[7], m[8]}, r3[3] = {m[9], m[10], m[11]};
+      const lynx_f32x2 o2 = row_dot<3>(r2, v), o3 = row_dot<3>(r3, v);
+      z[2] = o2;
+      z[3] = o3;
+    }
+    z[0] = o0;
+    z[1] = o1;
+    z[4] = o4;
+    z[5] = o5;
+  }
+}
+
+// the non-linear part of a unit, if it has one; (s_own, d_own): the s and delta that entered the unit
+__device__ __forceinline__ void unit_nonlinear(const UnitHalf& kick, int bits, lynx_f32x2 s_own, lynx_f32x2 d_own,
+                                               lynx_f32x2 (&z)[7]) {
+  if (bits & kUnitKick) {  // uniform
+    lynx_f32x2 s_in = s_own, d_in = d_own;
+    if (bits & kUnitInverse) {
+      const float* inv = kick.v + kUnitInv;
+      s_in = pk_fma(z[5], inv[1], z[4] * inv[0]);
+      d_in = pk_fma(z[5], inv[3], z[4] * inv[2]);
+    }
+    float coef[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) coef[k] = kick.v[kUnitCoef + k];
+    unit_kick(coef, s_in, d_in, z[4], z[5]);
+  }
+}
+
+// the linear map of a unit in its dense form, from the step table's 7x7: one row of scalars at a time (this is the
+// rarely taken path -- a sample whose map lacks the structure, or a tile with a non-finite particle -- and must not
+// cost the structured loop its registers).  Same operations in the same order as apply_step_pair's.
+__device__ __forceinline__ void unit_linear_dense(const float* __restrict__ tab, lynx_f32x2 (&z)[7]) {
+  lynx_f32x2 o[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    float row[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) row[j] = uniform_value(tab[i * 7 + j]);
+    lynx_f32x2 acc = z[0] * row[0];
+#pragma unroll
+    for (int j = 1; j < 7; ++j) acc = pk_fma(z[j], row[j], acc);
+    o[i] = acc;
+  }
+#pragma unroll
+  for (int i = 0; i < 7; ++i) z[i] = o[i];
+}
+
+// The program on a pair of particles.  `s_units` / `s_extras`: the sample's records in LDS; `all_dense`: every unit in
+// its dense form.
+__device__ __forceinline__ void units_program(int U, const float* __restrict__ s_units, const float* s_extras,
+                                              const float* __restrict__ g_steps, bool all_dense, lynx_f32x2 (&z)[7]) {
+#pragma unroll 1
+  for (int u = 0; u < U; ++u) {
+    const float* rec = s_units + u * kUnitStride;
+    UnitHalf kick, map;
+    unit_fetch(rec + kUnitMap, map);
+    unit_fetch(rec, kick);
+    const lynx_f32x2 s_own = z[4], d_own = z[5];
+    const int bits = __builtin_amdgcn_readfirstlane(__float_as_int(kick.v[kUnitDesc]));  // wave-uniform: scalar branches
+    const int cls = all_dense ? (int)kClassDense : ((bits >> kUnitClassShift) & 3);
+    if (cls == kClassU) {
+      unit_linear<kClassU>(map, nullptr, z);
+    } else if (cls == kClassD) {
+      unit_linear<kClassD>(map, s_extras + u * kUnitExtraStride, z);
+    } else {
+      const int slot = __builtin_amdgcn_readfirstlane(__float_as_int(kick.v[kUnitSlot]));
+      unit_linear_dense(g_steps + slot * LYNX_STEP_STRIDE, z);
+    }
+    unit_nonlinear(kick, bits, s_own, d_own, z);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_track_units: grid.x = B * chunks, 256 threads, two particles per lane (tid and tid + 256 of a 512-particle tile).
+// ---------------------------------------------------------------------------------------
+template <int MOM, bool FULL>
+__global__ __launch_bounds__(kTrackThreads, (units_waves_per_simd<MOM, FULL>())) void k_track_units(
+    TrackArgs a, int32_t U, int32_t S, const float* p_in, float* p_out, float* __restrict__ energy_out,
+    const float* __restrict__ steps_in, const float* __restrict__ units_in, const float* __restrict__ extras_in,
+    double* __restrict__ partials) {
+  using T = float;
+  constexpr int UNROLL = 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int tid = threadIdx.x;
+  // sample and chunk of this workgroup, in scalar registers (the division runs on the vector unit): everything that
+  // is derived from them -- the record addresses of the step loop above all -- then stays scalar
+  const int64_t b = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / a.chunks));
+  const int chunk = __builtin_amdgcn_readfirstlane((int)(blockIdx.x % a.chunks));
+  const int64_t end = a.n_particles;
+  constexpr int64_t kTile = (int64_t)kTrackThreads * UNROLL;
+  const T* src = p_in + b * a.in_stride;
+  T* dst = p_out + b * end * 7;
+  const float* g_steps = steps_in + b * (int64_t)S * LYNX_STEP_STRIDE;
+  // this sample's unit records -> LDS (behind the moment slab), once per workgroup
+  float* s_units = reinterpret_cast<float*>(smem_raw + a.lds_scratch_bytes);
+  float* s_extras = s_units + U * kUnitStride;
+  {
+    const float* g_units = units_in + b * (int64_t)U * kUnitStride;
+    const float* g_extras = extras_in + b * (int64_t)U * kUnitExtraStride;
+    for (int i = tid; i < U * kUnitStride; i += kTrackThreads) s_units[i] = g_units[i];
+    for (int i = tid; i < U * kUnitExtraStride; i += kTrackThreads) s_extras[i] = g_extras[i];
+  }
+
+  // the first tile's loads go out before anything else
+  T zn[UNROLL][7];
+  {
+    const int64_t i0 = (int64_t)chunk * a.tiles_per_wg * kTile + tid;
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int64_t i = i0 + (int64_t)u * kTrackThreads;
+      load_particle(src + (i < end ? i : (i0 < end ? i0 : 0)) * 7, zn[u]);
+    }
+  }
+  if (energy_out && chunk == 0 && tid == 0 && S > 0) energy_out[b] = g_steps[(S - 1) * LYNX_STEP_STRIDE + LYNX_ENERGY_OFFSET];
+
+  LaneSums<T, MOM, FULL> sums;
+  sums.init();
+  T shift[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) shift[i] = T(0);
+  __syncthreads();  // the records are in LDS
+
+  for (int it = 0; it < a.tiles_per_wg; ++it) {
+    const int64_t tile = (int64_t)chunk * a.tiles_per_wg + it;
+    const int64_t i0 = tile * kTile + tid;
+    // (uniform: the whole workgroup leaves together.  A per-lane `i0 >= end` here makes the loop's control flow
+    // divergent, and the compiler then keeps every loop-carried scalar -- record registers, addresses -- in VECTOR
+    // registers; lanes beyond the end of the sample ride along on a clamped address and are masked where it counts)
+    if (tile * kTile >= end) break;
+    sums.begin_iteration();
+    lynx_f32x2 z[7];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) {
+      z[c].x = zn[0][c];
+      z[c].y = zn[1][c];
+    }
+    if (it + 1 < a.tiles_per_wg) {  // prefetch the next tile of this workgroup
+      const int64_t j0 = (tile + 1) * kTile + tid;
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        const int64_t j = j0 + (int64_t)u * kTrackThreads;
+        load_particle(src + (j < end ? j : 0) * 7, zn[u]);
+      }
+    }
+    // a non-finite particle anywhere in the wave: the dense chain, whose zero entries spread it like the reference's
+    bool all_dense = __builtin_amdgcn_ballot_w64(pair_not_finite(z)) != 0;  // wave-uniform
+    for (;;) {
+      units_program(U, units_in + b * (int64_t)U * kUnitStride, s_extras, g_steps, all_dense, z);
+      // what came out: a value that overflowed on the way (or met a non-finite coefficient) would have spread through
+      // the dense chain's zero entries -- then the tile is done again, densely
+      if (all_dense || __builtin_amdgcn_ballot_w64(pair_not_finite(z)) == 0) break;
+      all_dense = true;
+      // reload the tile; the outgoing beam has not been written yet, so in-place tracking is safe
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        const int64_t i = i0 + (int64_t)u * kTrackThreads;
+        T t[7];
+        load_particle(src + (i < end ? i : 0) * 7, t);
+#pragma unroll
+        for (int c = 0; c < 7; ++c) {
+          if (u == 0) z[c].x = t[c];
+          else z[c].y = t[c];
+        }
+      }
+    }
+
+    T zo[UNROLL][7];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) {
+      zo[0][c] = z[c].x;
+      zo[1][c] = z[c].y;
+    }
+    if (MOM && it == 0) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) shift[k] = wave_first(zo[0][k]);
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int64_t i = i0 + (int64_t)u * kTrackThreads;
+      if (i < end) {
+        if (a.store) store_particle(dst + i * 7, zo[u]);
+        if (MOM) sums.add(zo[u], shift);
+      }
+    }
+    sums.end_iteration();
+  }
+  if (MOM) workgroup_moment_record<T, MOM, FULL>(sums, shift, smem_raw, partials + ((int64_t)b * a.chunks + chunk) * kPartialStride);
+}
+
+// LDS of k_track_units: the moment slab (TrackArgs.lds_scratch_bytes) + the sample's unit records and class-D extras
+inline size_t units_lds_bytes(size_t slab_bytes, int n_units) {
+  return slab_bytes + (size_t)n_units * (kUnitStride + kUnitExtraStride) * sizeof(float);
+}
+
+}  // namespace lynx

@@ -560,6 +560,90 @@ def test_kat1_parameter_beam_drift(lx):
     assert np.allclose(out.sigma_xp, beam.sigma_xp) and np.allclose(out.sigma_yp, beam.sigma_yp)
 
 
+def _same_bits(a, b):
+    """bit-identical up to the sign of zero; NaNs in the same places"""
+    a, b = np.asarray(a), np.asarray(b)
+    return a.shape == b.shape and np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(
+        np.where(np.isnan(a), 0, a) + 0.0, np.where(np.isnan(b), 0, b) + 0.0)
+
+
+@pytest.mark.parametrize("case", ["uncoupled", "dispersive", "coupled", "nan_map", "sequential"])
+def test_structured_units_equal_the_dense_step_loop_bit_for_bit(lx, monkeypatch, case):
+    """
+    Multi-step float32 programs are walked as units whose maps hold only the entries that are not structurally zero
+    (lynx_units.hpp: 16 for [drift, quadrupole, corrector, cavity] runs, 24 with untilted dipoles); LYNX_TRACK_UNITS=0
+    keeps the dense 7x7 step loop.  On finite beams the two must agree bit for bit (a skipped term adds +-0: signed
+    zeros aside) -- particles, energy and moment records -- for every class: uncoupled, dispersive, a tilted quadrupole
+    (the numeric check sends every sample to the dense form), a zero-voltage cavity row (NaN in the map: that sample
+    dense, cavity.py:269), and with every step on its own.  (track_methods.py:86-98, quadrupole.py:75-79, cavity.py:311-323.)
+    """
+    B, N = 6, 90_000  # large enough for two particles per lane, the form large beams get
+    rng = np.random.default_rng(21)
+    f = lambda v: np.full(B, v)  # noqa: E731
+    volts = rng.uniform(5e6, 2e7, B)
+    if case == "nan_map":
+        volts[2] = 0.0
+    cell = lambda: [("drift", dict(length=f(0.3))),  # noqa: E731
+                    ("quadrupole", dict(length=f(0.1), k1=rng.uniform(-5, 5, B), misalignment=rng.normal(0, 1e-4, (B, 2)),
+                                        **({"tilt": rng.uniform(-0.5, 0.5, B)} if case == "coupled" else {}))),
+                    ("hcor", dict(length=f(0.1), angle=rng.normal(0, 1e-4, B))),
+                    *([("dipole", dict(length=f(0.4), angle=rng.uniform(-0.1, 0.1, B), e1=f(0.02), e2=f(0.01)))] if case == "dispersive" else []),
+                    ("drift", dict(length=f(0.3))),
+                    ("cavity", dict(length=f(1.0377), voltage=volts, phase=rng.uniform(-10, 10, B), frequency=f(1.3e9)))]
+    desc = cell() + cell() + cell() + [("drift", dict(length=f(0.2))), ("vcor", dict(length=f(0.1), angle=f(1e-4)))]
+    elements, _ = make_lattice(desc, np.float32, lx)
+    segment = lx.Segment(elements)
+    P = o.gaussian_particles((B,), N, seed=5, dtype=np.float32, sigma=[1e-4, 1e-5, 1e-4, 1e-5, 1e-4, 1e-3])
+    beam = lx.ParticleBeam(P, np.full(B, 6e6, np.float32), dtype=np.float32)
+    if case == "sequential":
+        monkeypatch.setattr(lx.config, "merge_steps", False)
+    outs = {}
+    for units in ("2", "0"):  # 2 = the structured loop or an error
+        monkeypatch.setenv("LYNX_TRACK_UNITS", units)
+        out = segment.track(beam)
+        outs["1" if units == "2" else "0"] = (np.asarray(out.particles), np.asarray(out.energy), np.asarray(out.moment_record()))
+    for k in range(3):
+        assert _same_bits(outs["1"][k], outs["0"][k]), (case, k)
+    if case != "nan_map":
+        assert np.all(np.isfinite(outs["1"][0]))
+    else:
+        assert np.all(np.isnan(outs["1"][0][2, :, :4])) and np.all(np.isfinite(outs["1"][0][[0, 1, 3, 4, 5]]))
+
+
+def test_structured_units_spread_a_non_finite_particle_like_the_dense_chain(lx, monkeypatch):
+    """
+    0 * inf = NaN: in the reference's `particles @ tm^T` (element.py:85) an infinite y makes every coordinate of that
+    particle NaN, zero entries of the map or not.  The structured step loop skips those entries, so a wave that holds
+    a non-finite value -- going in, or coming out after an overflow on the way -- redoes its tile with the dense form:
+    the outcome must be the dense loop's, for the particle itself and for everybody else.
+    """
+    B, N = 2, 270_000
+    rng = np.random.default_rng(22)
+    f = lambda v: np.full(B, v)  # noqa: E731
+    desc = []
+    for _ in range(3):
+        desc += [("drift", dict(length=f(0.3))), ("quadrupole", dict(length=f(0.1), k1=rng.uniform(-5, 5, B))),
+                 ("drift", dict(length=f(0.3))),
+                 ("cavity", dict(length=f(1.0377), voltage=rng.uniform(5e6, 2e7, B), phase=rng.uniform(-10, 10, B), frequency=f(1.3e9)))]
+    elements, specs = make_lattice(desc, np.float32, lx)
+    segment = lx.Segment(elements)
+    P = o.gaussian_particles((B,), N, seed=6, dtype=np.float32, sigma=[1e-4, 1e-5, 1e-4, 1e-5, 1e-4, 1e-3])
+    P[0, 17, 2] = np.inf        # y of one particle
+    P[1, 4000, 1] = np.nan      # x' of another
+    P[1, 123, 0] = 3e38         # finite going in, overflows in the first quadrupole's product
+    P[1, 123, 1] = 3e38
+    beam = lx.ParticleBeam(P, np.full(B, 6e6, np.float32), dtype=np.float32)
+    outs = {}
+    for units in ("2", "0"):
+        monkeypatch.setenv("LYNX_TRACK_UNITS", units)
+        outs["1" if units == "2" else "0"] = np.asarray(segment.track(beam).particles)
+    assert _same_bits(outs["1"], outs["0"])
+    ref = o.segment_track(specs, o.particle_beam(P, np.full(B, 6e6, np.float32), np.float32), np.float32)["particles"]
+    assert np.array_equal(np.isnan(outs["1"]), np.isnan(ref))           # the reference's NaN pattern
+    assert np.all(np.isnan(outs["1"][0, 17, :6])) and np.all(np.isnan(outs["1"][1, 4000, :6]))
+    assert np.isfinite(outs["1"][0, 16]).all() and np.isfinite(outs["1"][1, 4001]).all()
+
+
 def test_energy_not_above_zero_at_a_cavity_is_the_references_assertion(lx):
     """
     cavity.py:260 (`assert torch.all(Ei > 0)`) for energies the host never sees: the check runs on the device while
@@ -1012,6 +1096,25 @@ def test_cavity_predicates_are_evaluated_on_the_device(lx, dtype):
         desc = steps.numpy()[:, :, 62].astype(np.int64)  # flags | kind << 16 (| pair bit)
         assert np.all(desc[:, 1] & 0xFFFF == want) and np.all(desc[:, 1] >> 16 == _ffi.STEP_CAVITY), (kw, desc)
         assert np.all(desc[:, 0] == 0) and np.all(desc[:, 2] == 0)
+    # The predicates of all cavities are first evaluated side by side under the assumption that every batch gains
+    # energy (k_cavity_flags_spec).  Here it does not hold: the first cavity would take every sample below zero, so
+    # nobody moves on (cavity.py:128-130) and the second cavity sees the INCOMING energy -- the serial walk must take
+    # over: second cavity BETA | GAIN | T5XX, and no complaint about its energy (the assumed one was negative).
+    brake = lx.Cavity(f(1.0), frequency=f(1.3e9), voltage=f(-2e8), phase=f(0.0), dtype=dtype)
+    boost = lx.Cavity(f(1.0), frequency=f(1.3e9), voltage=f(1e7), phase=f(10.0), dtype=dtype)
+    seg = lx.Segment([brake, lx.Drift(f(0.5), dtype=dtype), boost])
+    program = engine.plan(seg, seg.elements, False)[0]
+    lat = engine._ready(seg.__dict__.setdefault("_lattice_cache", engine.LatticeCache()), program, (B,), dtype, None)
+    e_in = rt.to_device(f(1e8))
+    for _ in range(2):  # twice: the words the first kernel accumulates into must be clean again
+        steps = rt.empty((B, len(program.steps), _ffi.STEP_STRIDE), dtype)
+        rt.check(rt.lib.lynx_build_compose(rt.ctx, lat.handle, engine._ptr(e_in), engine._ptr(steps), None))
+        table = steps.numpy()
+        desc = table[:, :, 62].astype(np.int64)
+        assert np.all(desc[:, 0] & 0xFFFF == _ffi.FLAG_CAV_BETA), desc
+        assert np.all(desc[:, 2] & 0xFFFF == (_ffi.FLAG_CAV_BETA | _ffi.FLAG_CAV_GAIN | _ffi.FLAG_CAV_T5XX)), desc
+        assert np.allclose(table[:, 2, 63], 1e8 + 1e7 * np.cos(np.deg2rad(10.0)), rtol=1e-6)  # outgoing energy
+        rt.sync()  # would raise if the assumed (negative) energy had been reported
     # chained programs: the first one's outgoing energy stays in HBM, the second evaluates its predicates from it
     seg = lx.Segment([lx.Cavity(f(1.0), voltage=f(1e7), phase=f(0.0), frequency=f(1.3e9), dtype=dtype), lx.Drift(f(0.3), dtype=dtype)])
     P = o.gaussian_particles((B,), 2000, seed=1, dtype=dtype, sigma=[1e-4, 1e-5, 1e-4, 1e-5, 1e-4, 1e-3])
