@@ -142,11 +142,22 @@ def _cpu_sample(name, particles, cells, dtype, bs, seed):
     n = particles if name != "c3big" else 1_000_000
     if name == "c2":
         specs = o.ares_like_segment(dtype, (bs,))
+    elif name == "c5":
+        rng = np.random.default_rng(seed)
+        f = lambda v: np.full((bs,), v, dtype=dtype)  # noqa: E731
+        specs = []
+        for _ in range(cells):
+            specs += [o.Drift(f(0.3)),
+                      o.Quadrupole(f(0.1), k1=rng.uniform(-5, 5, bs).astype(dtype),
+                                   misalignment=rng.normal(0, 1e-4, (bs, 2)).astype(dtype)),
+                      o.Drift(f(0.3)),
+                      o.Cavity(f(1.0377), voltage=rng.uniform(5e6, 2e7, bs).astype(dtype),
+                               phase=rng.uniform(-10, 10, bs).astype(dtype), frequency=f(1.3e9))]
     else:
         scale = 0.5 + np.arange(bs) / max(bs - 1, 1) if bs > 1 else None
         specs = o.fodo_segment(cells, np.dtype(dtype).type, (bs,), scale)
     P = o.gaussian_particles((bs,), n, seed=seed, dtype=dtype, sigma=[1e-4, 1e-5, 1e-4, 1e-5, 1e-5, 1e-3])
-    beam = o.particle_beam(P, np.full((bs,), 1e8, dtype=dtype), dtype)
+    beam = o.particle_beam(P, np.full((bs,), 6e6 if name == "c5" else 1e8, dtype=dtype), dtype)
 
     def run():
         o.beam_moments(o.segment_track(specs, beam, dtype))
@@ -185,13 +196,11 @@ def cpu_baseline(name, particles, cells, dtype, budget_s=10.0):
     """
     import multiprocessing as mp
 
-    if name == "c5":
-        return None
     try:
         from threadpoolctl import threadpool_limits
     except Exception:  # pragma: no cover
         threadpool_limits = None
-    bs = 8 if name == "c4" else 1
+    bs = 8 if name == "c4" else (64 if name == "c5" else 1)
     run, steps_per_pass, E, n = _cpu_sample(name, particles, cells, dtype, bs, 2)
     limiter = threadpool_limits(limits=1) if threadpool_limits else None
     try:
@@ -209,7 +218,7 @@ def cpu_baseline(name, particles, cells, dtype, budget_s=10.0):
     one = steps_per_pass * reps / dt
 
     cores = min(host_cores(), 64)
-    per_worker = 2 if name == "c4" else 1
+    per_worker = 2 if name == "c4" else (16 if name == "c5" else 1)
     t_start = time.time() + 3.0 + 0.05 * cores  # every worker has built its sample by then
     jobs = [(name, particles, cells, dtype, per_worker, 100 + w, t_start, t_start + budget_s) for w in range(cores)]
     with mp.get_context("fork").Pool(cores) as pool:

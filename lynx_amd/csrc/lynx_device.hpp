@@ -23,6 +23,7 @@
 #include <type_traits>
 
 #include "lynx_maps.hpp"
+#include "lynx_unit_record.hpp"
 
 namespace lynx {
 
@@ -287,80 +288,71 @@ __device__ __forceinline__ T cavity_look(const T* pool, const lynx_elem& el, boo
   return d_energy;
 }
 
+// `cavs`: the lattice's cavities in lattice order, (element, its step if it is a step of its own else -1) -- made by
+// the host once per lattice, so that neither kernel has to walk the step and element tables to find them
 template <typename T>
-__global__ __launch_bounds__(256) void k_cavity_flags_spec(LatticeDev lat, const T* __restrict__ energy_in,
-                                                           int32_t* __restrict__ words) {
+__global__ __launch_bounds__(256) void k_cavity_flags_spec(LatticeDev lat, const int2* __restrict__ cavs, int n_cavs,
+                                                           const T* __restrict__ energy_in, int32_t* __restrict__ words) {
   const T* pool = static_cast<const T*>(lat.pool);
   const int64_t b_raw = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = b_raw < lat.batch;
   const int64_t b = live ? b_raw : lat.batch - 1;
   T energy = energy_in[b];
-  int c = 0;
-  for (int s = 0; s < lat.n_steps; ++s) {
-    const lynx_step st = lat.steps[s];
-    for (int e = st.first; e < st.last; ++e) {
-      const lynx_elem el = lat.elems[e];
-      if (el.kind != LYNX_KIND_CAVITY) continue;  // uniform
-      const bool is_step = st.kind == LYNX_STEP_CAVITY;
-      int mine = 0;
-      const T d_energy = cavity_look<T>(pool, el, is_step, energy, b, mine);
-      if (!live) mine = 0;
-      int bits = 0;
-      if (__builtin_amdgcn_ballot_w64((mine & LYNX_FLAG_CAV_BETA) != 0)) bits |= LYNX_FLAG_CAV_BETA;
-      if (__builtin_amdgcn_ballot_w64((mine & LYNX_FLAG_CAV_GAIN) != 0)) bits |= LYNX_FLAG_CAV_GAIN;
-      if (__builtin_amdgcn_ballot_w64((mine & LYNX_FLAG_CAV_T5XX) != 0)) bits |= LYNX_FLAG_CAV_T5XX;
-      if (__builtin_amdgcn_ballot_w64((mine & kBadEnergy) != 0)) bits |= kBadEnergy;
-      if ((threadIdx.x & 63) == 0 && bits) atomicOr(&words[c], bits);
-      if (is_step) energy = energy + d_energy;  // the assumption: this cavity's batch gains energy (cavity.py:128-130)
-      ++c;
-    }
+  for (int c = 0; c < n_cavs; ++c) {
+    const int2 cv = cavs[c];
+    const lynx_elem el = lat.elems[cv.x];
+    const bool is_step = cv.y >= 0;
+    int mine = 0;
+    const T d_energy = cavity_look<T>(pool, el, is_step, energy, b, mine);
+    if (!live) mine = 0;
+    int bits = 0;
+    if (__builtin_amdgcn_ballot_w64((mine & LYNX_FLAG_CAV_BETA) != 0)) bits |= LYNX_FLAG_CAV_BETA;
+    if (__builtin_amdgcn_ballot_w64((mine & LYNX_FLAG_CAV_GAIN) != 0)) bits |= LYNX_FLAG_CAV_GAIN;
+    if (__builtin_amdgcn_ballot_w64((mine & LYNX_FLAG_CAV_T5XX) != 0)) bits |= LYNX_FLAG_CAV_T5XX;
+    if (__builtin_amdgcn_ballot_w64((mine & kBadEnergy) != 0)) bits |= kBadEnergy;
+    if ((threadIdx.x & 63) == 0 && bits) atomicOr(&words[c], bits);
+    if (is_step) energy = energy + d_energy;  // the assumption: this cavity's batch gains energy (cavity.py:128-130)
   }
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_cavity_flags(LatticeDev lat, lynx_elem* elems, lynx_step* steps,
                                                       const T* __restrict__ energy_in, T* __restrict__ e_run,
-                                                      int32_t* __restrict__ status, int32_t* __restrict__ words) {
+                                                      int32_t* __restrict__ status, const int2* __restrict__ cavs, int n_cavs,
+                                                      int32_t* __restrict__ words) {
   const T* pool = static_cast<const T*>(lat.pool);
   const int64_t B = lat.batch;
   const int nt = blockDim.x;
   if (words) {
-    // what k_cavity_flags_spec found: valid if every step cavity's batch gains energy
-    __shared__ int s_valid;
-    if (threadIdx.x == 0) {
-      int c = 0, valid = 1;
-      for (int s = 0; s < lat.n_steps; ++s) {
-        const lynx_step st = steps[s];
-        for (int e = st.first; e < st.last; ++e) {
-          if (elems[e].kind != LYNX_KIND_CAVITY) continue;
-          if (st.kind == LYNX_STEP_CAVITY && !(words[c] & LYNX_FLAG_CAV_GAIN)) valid = 0;
-          ++c;
-        }
-      }
-      if (valid) {
-        c = 0;
-        for (int s = 0; s < lat.n_steps; ++s) {
-          const lynx_step st = steps[s];
-          for (int e = st.first; e < st.last; ++e) {
-            const lynx_elem el = elems[e];
-            if (el.kind != LYNX_KIND_CAVITY) continue;
-            const int w = words[c];
-            const int f = w & kCavMask;
-            elems[e].flags = (el.flags & ~kCavMask) | f;
-            if (st.kind == LYNX_STEP_CAVITY) steps[s].flags = (st.flags & ~kCavMask) | f;
-            if ((w & kBadEnergy) && status) {
-              if (__hip_atomic_exchange(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0)
-                __hip_atomic_store(status + 1, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // the first one found
-            }
-            ++c;
-          }
-        }
-      }
-      for (int k = 0; k < c; ++k) words[k] = 0;  // ready for the next call
-      s_valid = valid;
+    // what k_cavity_flags_spec found: valid if every step cavity's batch gains energy.  One thread per cavity.
+    int ok = 1, first_bad = 0x7fffffff;
+    for (int c = threadIdx.x; c < n_cavs; c += nt) {
+      const int w = words[c];
+      if (cavs[c].y >= 0 && !(w & LYNX_FLAG_CAV_GAIN)) ok = 0;
+      if ((w & kBadEnergy) && c < first_bad) first_bad = c;
     }
-    __syncthreads();
-    if (s_valid) return;
+    const int valid = __syncthreads_and(ok);
+    if (valid) {
+      for (int c = threadIdx.x; c < n_cavs; c += nt) {
+        const int2 cv = cavs[c];
+        const int f = words[c] & kCavMask;
+        elems[cv.x].flags = (elems[cv.x].flags & ~kCavMask) | f;
+        if (cv.y >= 0) steps[cv.y].flags = (steps[cv.y].flags & ~kCavMask) | f;
+      }
+      // the first cavity (in lattice order) that a sample reached with energy <= 0, if any
+      __shared__ int s_bad;
+      if (threadIdx.x == 0) s_bad = 0x7fffffff;
+      __syncthreads();
+      if (first_bad != 0x7fffffff) atomicMin(&s_bad, first_bad);
+      __syncthreads();
+      if (threadIdx.x == 0 && s_bad != 0x7fffffff && status) {
+        if (__hip_atomic_exchange(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0)
+          __hip_atomic_store(status + 1, cavs[s_bad].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    __syncthreads();  // everybody has read its words
+    for (int c = threadIdx.x; c < n_cavs; c += nt) words[c] = 0;  // ready for the next call
+    if (valid) return;
   }
   // every sample's energy on its way through the cavities: in registers for batches of up to 8 per thread, in
   // `e_run` beyond (hundreds of thousands of ParameterBeam settings)
@@ -599,7 +591,9 @@ template <typename T>
 __global__ __launch_bounds__(64, 4) void k_emit_steps(LatticeDev lat, const int32_t* __restrict__ step_slot,
                                                    const T* __restrict__ energy_in, int64_t Bp,
                                                    const double* __restrict__ products, const T* __restrict__ coefs,
-                                                   int merge_pairs, T* __restrict__ steps_out, T* __restrict__ energy_out) {
+                                                   int merge_pairs, T* __restrict__ steps_out, T* __restrict__ energy_out,
+                                                   const int32_t* __restrict__ step_unit, int n_units,
+                                                   float* __restrict__ units_out, float* __restrict__ extras_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* row = reinterpret_cast<T*>(smem_raw) + threadIdx.x * 68;
   const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
@@ -690,6 +684,18 @@ __global__ __launch_bounds__(64, 4) void k_emit_steps(LatticeDev lat, const int3
     const V* from = reinterpret_cast<const V*>(row);
 #pragma unroll 4
     for (int v = 0; v < LYNX_STEP_STRIDE / W; ++v) dst[v] = from[v];
+    // the compact record of the unit that applies this step's map (multi-step float32 programs, lynx_units.hpp):
+    // packed here, from the row the lane still holds, instead of by a kernel of its own behind this one
+    if constexpr (sizeof(T) == 4) {
+      if (units_out) {
+        const int code = step_unit[s];
+        if (code >= 0) {
+          const int64_t i = b * n_units + (code & 0xff);
+          pack_unit_record<T>(row, s, (code >> 8) & 3, (code >> 10) & 1, units_out + i * kUnitStride,
+                              extras_out + i * kUnitExtraStride);
+        }
+      }
+    }
   }
 }
 

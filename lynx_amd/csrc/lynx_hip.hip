@@ -124,6 +124,7 @@ struct lynx_lattice {
   bool has_cavity = false;  // any cavity element: its whole-batch predicates are evaluated on the device
   int32_t n_cavities = 0;
   int32_t* d_cav_words = nullptr;  // one word per cavity: the predicates OR-ed over the batch (k_cavity_flags_spec); kept zero between calls
+  int2* d_cavs = nullptr;          // the cavities in lattice order: (element, its step if it is one of its own else -1)
   int64_t pool_count = 0;
   std::vector<lynx_elem> h_elems;
   std::vector<lynx_step> h_steps;
@@ -139,6 +140,12 @@ struct lynx_lattice {
   BuildPiece* d_pieces = nullptr;
   PairTask* d_tasks = nullptr;
   int32_t* d_step_slot = nullptr;
+  // multi-step float32 programs as units (lynx_units.hpp): the plan for `units_key` (-1: none yet; else the `merged`
+  // flag it was made for), whether the program fits it, and what k_emit_steps is told about every step
+  UnitPlan units;
+  int units_key = -1;
+  bool units_ok = false;
+  int32_t* d_step_unit = nullptr;
 };
 
 static thread_local std::string g_err;
@@ -359,8 +366,10 @@ const char* lynx_last_error(lynx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_e
 
 int lynx_device_info(lynx_ctx* ctx, lynx_device_info_t* out) {
   memset(out, 0, sizeof(*out));
-  snprintf(out->name, sizeof(out->name), "%s", ctx->prop.name);
   snprintf(out->arch, sizeof(out->arch), "%s", ctx->prop.gcnArchName);
+  // some driver stacks report no marketing name: the architecture then stands in for it
+  if (ctx->prop.name[0]) snprintf(out->name, sizeof(out->name), "%s", ctx->prop.name);
+  else snprintf(out->name, sizeof(out->name), "AMD GPU (%s)", ctx->prop.gcnArchName);
   out->compute_units = ctx->prop.multiProcessorCount;
   out->lds_bytes_per_cu = (int32_t)ctx->prop.maxSharedMemoryPerMultiProcessor;
   out->hbm_bytes = (int64_t)ctx->prop.totalGlobalMem;
@@ -653,6 +662,15 @@ int lynx_lattice_create(lynx_ctx* ctx, int dtype, int64_t batch, int32_t n_elems
       return rc;
     }
     HIP_TRY(ctx, hipMemsetAsync(lat->d_cav_words, 0, (size_t)lat->n_cavities * sizeof(int32_t), ctx->stream));
+    std::vector<int2> cavs;
+    for (int32_t e = 0; e < n_elems; ++e)
+      if (elems[e].kind == LYNX_KIND_CAVITY) cavs.push_back(make_int2(e, steps[elem_step[e]].kind == LYNX_STEP_CAVITY ? elem_step[e] : -1));
+    if ((rc = ctx_alloc(ctx, cavs.size() * sizeof(int2), (void**)&lat->d_cavs))) {
+      delete lat;
+      return rc;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(lat->d_cavs, cavs.data(), cavs.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // `cavs` goes out of scope
   }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   *out = lat;
@@ -673,6 +691,7 @@ int lynx_lattice_set_flags(lynx_lattice* lat, const int32_t* elem_flags, const i
   lynx_ctx* ctx = lat->ctx;
   for (int32_t e = 0; e < lat->n_elems; ++e) lat->h_elems[e].flags = elem_flags[e];
   for (int32_t s = 0; s < lat->n_steps; ++s) lat->h_steps[s].flags = step_flags[s];
+  lat->units_key = -1;  // the proposed classes depend on the elements' flags
   {
     const int rc = count_observers(ctx, lat);
     if (rc) return rc;
@@ -691,6 +710,8 @@ int lynx_lattice_destroy(lynx_lattice* lat) {
   ctx_free(ctx, lat->d_elem_step);
   ctx_free(ctx, lat->d_pool);
   if (lat->d_cav_words) ctx_free(ctx, lat->d_cav_words);
+  if (lat->d_cavs) ctx_free(ctx, lat->d_cavs);
+  if (lat->d_step_unit) ctx_free(ctx, lat->d_step_unit);
   if (lat->d_pieces) ctx_free(ctx, lat->d_pieces);
   if (lat->d_tasks) ctx_free(ctx, lat->d_tasks);
   if (lat->d_step_slot) ctx_free(ctx, lat->d_step_slot);
@@ -759,11 +780,12 @@ static int launch_cavity_flags(lynx_ctx* ctx, lynx_lattice* lat, hipStream_t str
   const bool spec = env_int("LYNX_CAVITY_FLAGS_SPEC", 1) != 0;
   if (spec) {
     hipLaunchKernelGGL(k_cavity_flags_spec<T>, dim3((unsigned)((lat->batch + 255) / 256)), dim3(256), 0, stream, dev_view(lat),
-                       (const T*)d_energy_in, lat->d_cav_words);
+                       lat->d_cavs, lat->n_cavities, (const T*)d_energy_in, lat->d_cav_words);
     HIP_TRY(ctx, hipGetLastError());
   }
   hipLaunchKernelGGL(k_cavity_flags<T>, dim3(1), dim3(256), 0, stream, dev_view(lat), lat->d_elems, lat->d_steps,
-                     (const T*)d_energy_in, (T*)ctx->scratch_erun, ctx->d_status, spec ? lat->d_cav_words : (int32_t*)nullptr);
+                     (const T*)d_energy_in, (T*)ctx->scratch_erun, ctx->d_status, lat->d_cavs, lat->n_cavities,
+                     spec ? lat->d_cav_words : (int32_t*)nullptr);
   HIP_TRY(ctx, hipGetLastError());
   return LYNX_OK;
 }
@@ -823,7 +845,8 @@ static int plan_lanes_build(lynx_ctx* ctx, lynx_lattice* lat, int L) {
 
 template <typename T>
 static int launch_build_lanes(lynx_ctx* ctx, lynx_lattice* lat, hipStream_t stream, const void* d_energy_in,
-                              void* d_steps_out, void* d_energy_out, int merge_pairs) {
+                              void* d_steps_out, void* d_energy_out, int merge_pairs, float* d_units = nullptr,
+                              float* d_extras = nullptr) {
   int rc;
   if ((rc = plan_lanes_build(ctx, lat, std::max(1, env_int("LYNX_PIECE", 8))))) return rc;
   const int64_t groups = (lat->batch + 63) / 64, Bp = groups * 64;
@@ -844,14 +867,18 @@ static int launch_build_lanes(lynx_ctx* ctx, lynx_lattice* lat, hipStream_t stre
   }
   hipLaunchKernelGGL(k_emit_steps<T>, dim3((unsigned)groups, (unsigned)lat->n_steps), dim3(64), emit_steps_lds<T>(), stream, lv,
                      lat->d_step_slot, (const T*)d_energy_in, Bp, (const double*)ctx->scratch_products,
-                     (const T*)ctx->scratch_coefs, merge_pairs, (T*)d_steps_out, (T*)d_energy_out);
+                     (const T*)ctx->scratch_coefs, merge_pairs, (T*)d_steps_out, (T*)d_energy_out,
+                     d_units ? lat->d_step_unit : (const int32_t*)nullptr, lat->units.n_units, d_units, d_extras);
   HIP_TRY(ctx, hipGetLastError());
   return LYNX_OK;
 }
 
+// `d_units` / `d_extras`: also pack the unit records of a multi-step float32 program (lat->units must be current);
+// the lanes build does it while it writes the table, the workgroup build with k_pack_units behind it
 template <typename T>
 static int launch_build(lynx_ctx* ctx, lynx_lattice* lat, hipStream_t stream, const void* d_energy_in,
-                        void* d_steps_out, void* d_energy_out, int merge_pairs = 0, bool underneath = false) {
+                        void* d_steps_out, void* d_energy_out, int merge_pairs = 0, bool underneath = false,
+                        float* d_units = nullptr, float* d_extras = nullptr) {
   {
     const int rc = launch_cavity_flags<T>(ctx, lat, stream, d_energy_in);
     if (rc) return rc;
@@ -859,7 +886,7 @@ static int launch_build(lynx_ctx* ctx, lynx_lattice* lat, hipStream_t stream, co
   // large batches: lanes = samples (an order of magnitude fewer wave-instructions); small ones: one
   // workgroup per sample, whose tree is shallower than a chain of launches
   if (lat->n_steps > 0 && lat->batch >= env_int("LYNX_LANES_BUILD_MIN_BATCH", 256))
-    return launch_build_lanes<T>(ctx, lat, stream, d_energy_in, d_steps_out, d_energy_out, merge_pairs);
+    return launch_build_lanes<T>(ctx, lat, stream, d_energy_in, d_steps_out, d_energy_out, merge_pairs, d_units, d_extras);
   int threads, chunk;
   build_shape<T>(ctx, lat, underneath, &threads, &chunk);
   const size_t lds = build_scratch_bytes(chunk, sizeof(T)) +
@@ -869,6 +896,14 @@ static int launch_build(lynx_ctx* ctx, lynx_lattice* lat, hipStream_t stream, co
   hipLaunchKernelGGL(k_build<T>, dim3((unsigned)lat->batch), dim3((unsigned)threads), lds, stream, dev_view(lat),
                      (const T*)d_energy_in, (T*)d_steps_out, (T*)d_energy_out, chunk, merge_pairs);
   HIP_TRY(ctx, hipGetLastError());
+  if constexpr (sizeof(T) == 4) {
+    if (d_units) {
+      const int64_t n = lat->batch * lat->units.n_units;
+      hipLaunchKernelGGL(k_pack_units, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, lat->units, lat->batch,
+                         lat->n_steps, (const float*)d_steps_out, d_units, d_extras);
+      HIP_TRY(ctx, hipGetLastError());
+    }
+  }
   return LYNX_OK;
 }
 
@@ -1074,6 +1109,24 @@ static bool plan_units(const lynx_lattice* lat, bool merged, UnitPlan* plan) {
   return plan->n_units > 0;
 }
 
+// The lattice's unit plan for `merged`, made once per lattice and flag change; with it the table k_emit_steps reads.
+static int ensure_units_plan(lynx_ctx* ctx, lynx_lattice* lat, bool merged) {
+  if (lat->units_key == (merged ? 1 : 0)) return LYNX_OK;
+  lat->units_ok = plan_units(lat, merged, &lat->units) && lat->batch * lat->units.n_units * kUnitStride < 0x7fffffffLL;
+  lat->units_key = merged ? 1 : 0;
+  if (!lat->units_ok) return LYNX_OK;
+  std::vector<int32_t> code((size_t)lat->n_steps, -1);
+  for (int u = 0; u < lat->units.n_units; ++u)
+    code[lat->units.slot[u]] = step_unit_code(u, lat->units.cls[u], lat->units.pair[u]);
+  int rc;
+  if (!lat->d_step_unit && (rc = ctx_alloc(ctx, code.size() * sizeof(int32_t), (void**)&lat->d_step_unit))) return rc;
+  // rare (new lattice, or its flags changed): nothing may still be reading the old table
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->s_build));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipMemcpy(lat->d_step_unit, code.data(), code.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  return LYNX_OK;
+}
+
 template <int MOM, bool FULL>
 static int launch_units_inst(lynx_ctx* ctx, const TrackPlan& p, int32_t U, int32_t S, const void* d_p_in, void* d_p_out,
                              void* d_energy_out, const void* d_steps, const void* d_units, const void* d_extras,
@@ -1128,7 +1181,7 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
   const void* d_steps = nullptr;
   const void* d_units = nullptr;
   const void* d_extras = nullptr;
-  UnitPlan units;
+  int n_units = 0;
   bool use_units = false;
   int rc;
   int slot = -1;
@@ -1162,29 +1215,32 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
         ctx->main_wrote = nullptr;
       }
     }
-    if ((rc = launch_build<T>(ctx, lat, bs, d_energy_in, ctx->scratch_steps[slot], nullptr, p.a.merged_pairs, async))) return rc;
+    float* d_units_w = nullptr;
+    float* d_extras_w = nullptr;
     if constexpr (sizeof(T) == 4) {
       // multi-step programs: walked as units with structured maps (lynx_units.hpp); LYNX_TRACK_UNITS=0 keeps the
       // dense step loop of k_track_direct
       // (LYNX_TRACK_UNITS=2: insist -- an error if this call cannot take the structured loop; for tests)
       const int want_units = env_int("LYNX_TRACK_UNITS", 1);
-      use_units = S > 1 && p.unroll == 2 && !p.xpose && p.a.n_observers == 0 && !p.a.interleave && want_units &&
-                  plan_units(lat, p.a.merged_pairs != 0, &units) && B * units.n_units * kUnitStride < 0x7fffffffLL;
+      if (S > 1 && p.unroll == 2 && !p.xpose && p.a.n_observers == 0 && !p.a.interleave && want_units) {
+        if ((rc = ensure_units_plan(ctx, lat, p.a.merged_pairs != 0))) return rc;
+        use_units = lat->units_ok;
+      }
       if (want_units == 2 && !use_units)
         return fail(ctx, LYNX_ERR_INVALID, "LYNX_TRACK_UNITS=2: this call does not take the structured step loop");
       if (use_units) {
-        const int64_t n = B * units.n_units;
+        const int64_t n = B * lat->units.n_units;
         const int xs = lynx_ctx::kTableSlots + slot;
         if ((rc = ensure_scratch(ctx, &ctx->scratch_units[slot], &ctx->scratch_units_bytes[slot], (size_t)n * kUnitStride * sizeof(float))) ||
             (rc = ensure_scratch(ctx, &ctx->scratch_units[xs], &ctx->scratch_units_bytes[xs], (size_t)n * kUnitExtraStride * sizeof(float))))
           return rc;
-        hipLaunchKernelGGL(k_pack_units, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, bs, units, B, S,
-                           (const float*)ctx->scratch_steps[slot], (float*)ctx->scratch_units[slot], (float*)ctx->scratch_units[xs]);
-        HIP_TRY(ctx, hipGetLastError());
-        d_units = ctx->scratch_units[slot];
-        d_extras = ctx->scratch_units[xs];
+        d_units = d_units_w = (float*)ctx->scratch_units[slot];
+        d_extras = d_extras_w = (float*)ctx->scratch_units[xs];
+        n_units = lat->units.n_units;
       }
     }
+    if ((rc = launch_build<T>(ctx, lat, bs, d_energy_in, ctx->scratch_steps[slot], nullptr, p.a.merged_pairs, async, d_units_w, d_extras_w)))
+      return rc;
     if (async) {
       HIP_TRY(ctx, hipEventRecord(ctx->ev_built[slot], bs));
       // The HOST waits for the build instead of the main stream: no barrier packet with a foreign signal in front of
@@ -1234,7 +1290,7 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
   // build wait for everything enqueued here
   p.done = (slot >= 0 && async_build) ? ctx->ev_streamed_own[slot] : nullptr;
   if (side && !p.done) p.done = ring->track_done;  // the side stream's reduction starts behind it
-  if (use_units) rc = launch_units(ctx, p, units.n_units, S, d_p_in, d_p_out, d_energy_out, d_steps, d_units, d_extras, d_partials, moments);
+  if (use_units) rc = launch_units(ctx, p, n_units, S, d_p_in, d_p_out, d_energy_out, d_steps, d_units, d_extras, d_partials, moments);
   else rc = launch_direct<T>(ctx, p, lv, d_energy_in, d_p_in, d_p_out, d_energy_out, d_steps, d_partials, d_obs, moments);
   if (rc) return rc;
   if (p.a.n_observers) {

@@ -24,66 +24,24 @@
 // k_pack_units: step table [B][S][64] -> unit records [B][U][32] (+ [B][U][8] for class D), on the build's stream.
 // k_track_units: the streaming kernel.  Same launch geometry, particle accesses, moment sums and epilogue as the
 // two-particles-per-lane form of k_track_direct; what differs is the step loop.  k_track_direct fetches every step's
-// 61 scalars from the step table with scalar loads, per unit and tile -- two dependent L2 round trips per unit, which
-// is what that loop is bound by (measured: with structured maps but the same fetches it ran in the same time).  Here a
-// workgroup copies its sample's unit records into LDS once (1 KB for BASELINE config 5) and the step loop reads them
-// from there with wave-uniform 16-byte LDS loads: ~100 cycles instead of a trip to L2, no scalar-register pressure;
-// 16 / 24 packed multiply-adds instead of 49, the 2x2 blocks updated in place.
+// 61 scalars from the 256-byte records of the step table, per unit and tile, behind a first fetch of the descriptor
+// that tells a merged pair from a step -- dependent trips to L2 (a sample's 4 KB of records does not stay in the 16 KB
+// scalar cache next to nine other workgroups'), which is what that loop is bound by (measured: with structured maps but
+// the same fetches it ran in the same time).  Here a unit is ONE group of wave-uniform scalar loads from a 128-byte
+// record -- 1 KB per sample for BASELINE config 5, which the scalar cache keeps -- followed by 16 / 24 packed
+// multiply-adds instead of 49, the 2x2 blocks updated in place.  (The records in LDS, read with wave-uniform 16-byte
+// loads, were tried first: 0.75 ms against 0.67 -- eight 1-KB LDS returns per unit and wave keep the LDS pipe three
+// quarters as busy as the vector unit.)
 #pragma once
 
 #include "lynx_device.hpp"
+#include "lynx_unit_record.hpp"
 
 namespace lynx {
 
-constexpr int kMaxUnits = 64;
-// A unit's compact record: 32 floats = 128 bytes, every one of them used by class U.
-constexpr int kUnitStride = 32;
-// record layout (floats; integers are stored as raw bits)
-// first half: what the kick needs; second half: the linear map
-constexpr int kUnitDesc = 0;    // bits: kUnit* below
-constexpr int kUnitSlot = 1;    // step-table slot of the unit's (dense) record
-constexpr int kUnitCoef = 4;    // 8 cavity coefficients (LYNX_C_*)
-constexpr int kUnitInv = 12;    // 4: inverse of the cavity's (s, delta) block (merged pairs)
-constexpr int kUnitMap = 16;    // 16 entries of class U, in the order of unit_entry_u()
-constexpr int kUnitExtraStride = 8;  // second array [B][U][8]: the 8 additional entries of class D, order of unit_entry_d()
-
-constexpr int kUnitKick = 1;      // active cavity: non-linear kick behind the linear map
-constexpr int kUnitInverse = 2;   // ... driven by the entry inverse (merged pair) instead of the unit's own s, delta
-constexpr int kUnitPair = 4;      // merged [run, cavity] pair
-constexpr int kUnitClassShift = 4;  // bits 4-5: the class this sample's map was found to have (dense if the check failed)
-
-enum { kClassDense = 0, kClassU = 1, kClassD = 2 };
-
-struct UnitPlan {
-  int32_t n_units;
-  unsigned char slot[kMaxUnits];  // step-table slot whose record the unit applies (the cavity's, for a merged pair)
-  unsigned char cls[kMaxUnits];   // proposed class (whole batch)
-  unsigned char pair[kMaxUnits];  // 1: merged [run, cavity] pair
-};
-
-// (row, col) of compact entry k of class U and of the 8 additional ones of class D
-__host__ __device__ constexpr int unit_entry_u(int k) {
-  constexpr int rc[16] = {0 * 7 + 0, 0 * 7 + 1, 0 * 7 + 6, 1 * 7 + 0, 1 * 7 + 1, 1 * 7 + 6, 2 * 7 + 2, 2 * 7 + 3,
-                          2 * 7 + 6, 3 * 7 + 2, 3 * 7 + 3, 3 * 7 + 6, 4 * 7 + 4, 4 * 7 + 5, 5 * 7 + 4, 5 * 7 + 5};
-  return rc[k];
-}
-__host__ __device__ constexpr int unit_entry_d(int k) {
-  constexpr int rc[8] = {0 * 7 + 5, 1 * 7 + 5, 4 * 7 + 0, 4 * 7 + 1, 4 * 7 + 6, 5 * 7 + 0, 5 * 7 + 1, 5 * 7 + 6};
-  return rc[k];
-}
-
-__host__ __device__ inline bool unit_pattern_has(int cls, int q) {
-  if (cls == kClassDense) return true;
-  for (int k = 0; k < 16; ++k)
-    if (unit_entry_u(k) == q) return true;
-  if (cls == kClassD)
-    for (int k = 0; k < 8; ++k)
-      if (unit_entry_d(k) == q) return true;
-  return false;
-}
-
 // ---------------------------------------------------------------------------------------
-// k_pack_units: one thread per (sample, unit).
+// k_pack_units: one thread per (sample, unit) -- for step tables that were not written by k_emit_steps (the workgroup
+// build of small batches); the lanes build packs the records while it writes the table.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pack_units(UnitPlan plan, int64_t B, int32_t S, const float* __restrict__ steps,
                                                     float* __restrict__ units, float* __restrict__ extras) {
@@ -92,39 +50,9 @@ __global__ __launch_bounds__(256) void k_pack_units(UnitPlan plan, int64_t B, in
   if (i >= B * U) return;
   const int64_t b = i / U;
   const int u = (int)(i - b * U);
-  const int slot = plan.slot[u], cls = plan.cls[u];
-  const float* rec = steps + (b * S + slot) * LYNX_STEP_STRIDE;
-  float m[49];
-#pragma unroll
-  for (int q = 0; q < 49; ++q) m[q] = rec[q];
-  const int desc = (int)rec[LYNX_FLAGS_OFFSET];
-  const bool kick = ((desc >> LYNX_DESC_KIND_SHIFT) & 3) == LYNX_STEP_CAVITY && (desc & LYNX_FLAG_CAV_GAIN);
-  bool ok = cls != kClassDense;
-  for (int q = 0; q < 49 && ok; ++q) {
-    const float v = m[q];
-    if (!(__builtin_fabsf(v) <= 3.4028234664e38f)) ok = false;  // NaN or Inf anywhere: dense
-    if (q >= 42) {
-      if (v != (q == 48 ? 1.0f : 0.0f)) ok = false;  // row 6 must be e6
-    } else if (!unit_pattern_has(cls, q) && v != 0.0f) {
-      ok = false;
-    }
-  }
-  float* out = units + i * kUnitStride;
-  const int bits = (kick ? kUnitKick : 0) | ((kick && plan.pair[u]) ? kUnitInverse : 0) | (plan.pair[u] ? kUnitPair : 0) |
-                   ((ok ? cls : kClassDense) << kUnitClassShift);
-  out[kUnitDesc] = __int_as_float(bits);
-  out[kUnitSlot] = __int_as_float(slot);
-  out[2] = 0.f;
-  out[3] = 0.f;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) out[kUnitMap + k] = m[unit_entry_u(k)];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) out[kUnitCoef + k] = rec[LYNX_COEF_OFFSET + k];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) out[kUnitInv + k] = rec[LYNX_ENTRY_OFFSET + k];
-  float* ex = extras + i * kUnitExtraStride;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) ex[k] = m[unit_entry_d(k)];
+  const int slot = plan.slot[u];
+  pack_unit_record<float>(steps + (b * S + slot) * LYNX_STEP_STRIDE, slot, plan.cls[u], plan.pair[u], units + i * kUnitStride,
+                          extras + i * kUnitExtraStride);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -161,8 +89,8 @@ __device__ __forceinline__ bool pair_not_finite(const lynx_f32x2 (&z)[7]) {
 
 template <int MOM, bool FULL> constexpr int units_waves_per_simd() { return (!FULL && (MOM == 0 || MOM == 3)) ? 5 : 1; }
 
-// half a unit record (16 scalars) from the workgroup's copy in LDS: four wave-uniform 16-byte loads, every lane gets
-// the same values (they are used as the broadcast operand of the packed multiply-adds)
+// half a unit record (16 scalars), fetched with wave-uniform loads: they land in scalar registers and are the
+// broadcast operand of the packed multiply-adds
 struct UnitHalf {
   float v[16];
 };
@@ -174,7 +102,7 @@ __device__ __forceinline__ void unit_fetch(const float* __restrict__ half, UnitH
 // the linear map of a unit of class CLS on a pair of particles; `ex`: the class-D extras of this unit (fetched here:
 // that class pays a second round trip)
 template <int CLS>
-__device__ __forceinline__ void unit_linear(const UnitHalf& map, const float* ex, lynx_f32x2 (&z)[7]) {
+__device__ __forceinline__ void unit_linear(const UnitHalf& map, const float* __restrict__ ex, lynx_f32x2 (&z)[7]) {
   const float* m = map.v;
   if constexpr (CLS == kClassU) {
     {
@@ -201,12 +129,8 @@ __device__ __forceinline__ void unit_linear(const UnitHalf& map, const float* ex
   } else {
     static_assert(CLS == kClassD, "dense programs take units_dense_program");
     float md[8];
-    {
-      const lynx_f32x4* q = reinterpret_cast<const lynx_f32x4*>(ex);
-      const lynx_f32x4 a = q[0], c = q[1];
-      md[0] = a.x; md[1] = a.y; md[2] = a.z; md[3] = a.w;
-      md[4] = c.x; md[5] = c.y; md[6] = c.z; md[7] = c.w;
-    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) md[k] = uniform_value(ex[k]);
     const lynx_f32x2 vx[4] = {z[0], z[1], z[5], z[6]};
     const lynx_f32x2 vs[5] = {z[0], z[1], z[4], z[5], z[6]};
     const float r0[4] = {m[0], m[1], md[0], m[2]}, r1[4] = {m[3], m[4], md[1], m[5]};
@@ -263,9 +187,9 @@ __device__ __forceinline__ void unit_linear_dense(const float* __restrict__ tab,
   for (int i = 0; i < 7; ++i) z[i] = o[i];
 }
 
-// The program on a pair of particles.  `s_units` / `s_extras`: the sample's records in LDS; `all_dense`: every unit in
-// its dense form.
-__device__ __forceinline__ void units_program(int U, const float* __restrict__ s_units, const float* s_extras,
+// The program on a pair of particles.  `s_units` / `s_extras`: the sample's records; `all_dense`: every unit in its
+// dense form.
+__device__ __forceinline__ void units_program(int U, const float* __restrict__ s_units, const float* __restrict__ s_extras,
                                               const float* __restrict__ g_steps, bool all_dense, lynx_f32x2 (&z)[7]) {
 #pragma unroll 1
   for (int u = 0; u < U; ++u) {
@@ -309,15 +233,8 @@ __global__ __launch_bounds__(kTrackThreads, (units_waves_per_simd<MOM, FULL>()))
   const T* src = p_in + b * a.in_stride;
   T* dst = p_out + b * end * 7;
   const float* g_steps = steps_in + b * (int64_t)S * LYNX_STEP_STRIDE;
-  // this sample's unit records -> LDS (behind the moment slab), once per workgroup
-  float* s_units = reinterpret_cast<float*>(smem_raw + a.lds_scratch_bytes);
-  float* s_extras = s_units + U * kUnitStride;
-  {
-    const float* g_units = units_in + b * (int64_t)U * kUnitStride;
-    const float* g_extras = extras_in + b * (int64_t)U * kUnitExtraStride;
-    for (int i = tid; i < U * kUnitStride; i += kTrackThreads) s_units[i] = g_units[i];
-    for (int i = tid; i < U * kUnitExtraStride; i += kTrackThreads) s_extras[i] = g_extras[i];
-  }
+  const float* g_units = units_in + b * (int64_t)U * kUnitStride;
+  const float* g_extras = extras_in + b * (int64_t)U * kUnitExtraStride;
 
   // the first tile's loads go out before anything else
   T zn[UNROLL][7];
@@ -336,7 +253,6 @@ __global__ __launch_bounds__(kTrackThreads, (units_waves_per_simd<MOM, FULL>()))
   T shift[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) shift[i] = T(0);
-  __syncthreads();  // the records are in LDS
 
   for (int it = 0; it < a.tiles_per_wg; ++it) {
     const int64_t tile = (int64_t)chunk * a.tiles_per_wg + it;
@@ -363,7 +279,7 @@ __global__ __launch_bounds__(kTrackThreads, (units_waves_per_simd<MOM, FULL>()))
     // a non-finite particle anywhere in the wave: the dense chain, whose zero entries spread it like the reference's
     bool all_dense = __builtin_amdgcn_ballot_w64(pair_not_finite(z)) != 0;  // wave-uniform
     for (;;) {
-      units_program(U, units_in + b * (int64_t)U * kUnitStride, s_extras, g_steps, all_dense, z);
+      units_program(U, g_units, g_extras, g_steps, all_dense, z);
       // what came out: a value that overflowed on the way (or met a non-finite coefficient) would have spread through
       // the dense chain's zero entries -- then the tile is done again, densely
       if (all_dense || __builtin_amdgcn_ballot_w64(pair_not_finite(z)) == 0) break;
@@ -405,9 +321,7 @@ __global__ __launch_bounds__(kTrackThreads, (units_waves_per_simd<MOM, FULL>()))
   if (MOM) workgroup_moment_record<T, MOM, FULL>(sums, shift, smem_raw, partials + ((int64_t)b * a.chunks + chunk) * kPartialStride);
 }
 
-// LDS of k_track_units: the moment slab (TrackArgs.lds_scratch_bytes) + the sample's unit records and class-D extras
-inline size_t units_lds_bytes(size_t slab_bytes, int n_units) {
-  return slab_bytes + (size_t)n_units * (kUnitStride + kUnitExtraStride) * sizeof(float);
-}
+// LDS of k_track_units: the moment slab (TrackArgs.lds_scratch_bytes)
+inline size_t units_lds_bytes(size_t slab_bytes, int /*n_units*/) { return slab_bytes; }
 
 }  // namespace lynx

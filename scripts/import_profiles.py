@@ -3,7 +3,8 @@
 Copy the summaries of one profile series (scripts/gpu/prof_r2.sh, SERIES=<letter>, merged back by gpurun into
 gpurun_out/prof_r2_<letter>/) into profiles/ under the names profiles/README.md describes.
 
-    python scripts/import_profiles.py d            # -> profiles/r02_d_*
+    python scripts/import_profiles.py a            # gpurun_out/prof_r3_a -> profiles/r03_a_*
+    python scripts/import_profiles.py d r02        # gpurun_out/prof_r2_d -> profiles/r02_d_*
 """
 import glob
 import shutil
@@ -12,8 +13,8 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 series = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
-src = ROOT / "gpurun_out" / f"prof_r2_{series}"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
+src = ROOT / "gpurun_out" / f"prof_r{int(rnd[1:])}_{series}"
 dst = ROOT / "profiles"
 copied = []
 
@@ -37,4 +38,14 @@ for w in ("c3", "c2"):
     put(src / f"steady_{w}.json", f"{w}_bench_steady.json")
     put(src / f"latency_{w}.json", f"{w}_bench_waited_for.json")
 put(src / "latency_table.json", "latency_table.json")
+# round 3: the strong-scaling shards of config 4, config 5 A/B and default line, SQ counters of config 5's kernels
+put(src / "strong_scaling_shards.json", "c4_strong_scaling_shards.json")
+for b in (1024, 512, 256, 128):
+    put(src / f"shard_b{b}_1.json", f"c4_shard_b{b}_bench.json")
+put(src / "c5_units1.json", "c5_bench_units.json")
+put(src / "c5_units0.json", "c5_bench_dense_step_loop.json")
+put(src / "c5_default.json", "c5_bench_default.json")
+put(src / "c5grad.json", "c5grad_bench.json")
+put(src / "steady_c3big.json", "c3big_bench_steady.json")
+put(src / "pmc_c5" / "c5_pmc_sq.json", "c5_pmc_sq.json")
 print(f"{len(copied)} files -> profiles/{rnd}_{series}_*:", ", ".join(copied))
