@@ -647,6 +647,11 @@ __global__ __launch_bounds__(64, 4) void k_emit_steps(LatticeDev lat, const int3
     cavity_entry_inverse<T>(c4[0], c4[1], c5[0], c5[1], ci);
 #pragma unroll
     for (int q = 0; q < 4; ++q) row[LYNX_ENTRY_OFFSET + q] = ci[q];
+    // the run's (s, delta) block, for the unit record (the row buffer's padding: not part of the table)
+    row[64] = R[4 * 7 + 4];
+    row[65] = R[4 * 7 + 5];
+    row[66] = R[5 * 7 + 4];
+    row[67] = R[5 * 7 + 5];
   } else {
 #pragma unroll 1
     for (int i = 0; i < 7; ++i) {
@@ -691,7 +696,7 @@ __global__ __launch_bounds__(64, 4) void k_emit_steps(LatticeDev lat, const int3
         const int code = step_unit[s];
         if (code >= 0) {
           const int64_t i = b * n_units + (code & 0xff);
-          pack_unit_record<T>(row, s, (code >> 8) & 3, (code >> 10) & 1, units_out + i * kUnitStride,
+          pack_unit_record<T>(row, row + 64, s, (code >> 8) & 3, (code >> 10) & 1, units_out + i * kUnitStride,
                               extras_out + i * kUnitExtraStride);
         }
       }

@@ -236,10 +236,20 @@ template <typename T, typename Z>
 __global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
     LatticeDev lat, BwdArgs a, const T* __restrict__ p_in, const T* __restrict__ steps,
     const double* __restrict__ moments_fwd, const double* __restrict__ grad_moments,
-    T* __restrict__ partials /* [B][chunks][S][64] */, T* __restrict__ grad_p /* [B][N][7] or null */) {
+    T* __restrict__ partials /* [B][chunks][S][64] */, T* __restrict__ grad_p /* [B][N][7] or null */,
+    const float* __restrict__ units_skip = nullptr /* unit records: samples whose units are all of class U belong to
+                                                       k_track_bwd_units (lynx_grad_units.hpp) */,
+    int units_stride = 0, int units_class_shift = 0, int units_class_u = 0) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int K = kBwdGroup;
   constexpr int W = LaneOf<Z>::W;
+  if (units_skip) {  // uniform
+    const float* rec = units_skip + (blockIdx.x / a.chunks) * (int64_t)a.n_units * units_stride;
+    bool all = true;
+    for (int u = 0; u < a.n_units; ++u)
+      all = all && ((__float_as_int((float)rec[u * units_stride]) >> units_class_shift) & 3) == units_class_u;
+    if (all) return;
+  }
   using Geo = ExGeom<T, W>;
   using V = typename VecOf<T, true>::type;  // 16-byte LDS accesses
   constexpr int VW = Geo::kVW, P = Geo::kPitch;

@@ -20,6 +20,7 @@
 #include "lynx_device.hpp"
 #include "lynx_grad.hpp"
 #include "lynx_units.hpp"
+#include "lynx_grad_units.hpp"
 
 using namespace lynx;
 
@@ -70,6 +71,8 @@ struct lynx_ctx {
   static constexpr int kTableBwd = kTableSlots, kTablePb = kTableSlots + 1;
   void* scratch_steps[kTableSlots + 2] = {};  // the ring of step tables, the reverse pass's own, the ParameterBeam lanes path's
   size_t scratch_steps_bytes[kTableSlots + 2] = {};
+  void* scratch_units_bwd[2] = {nullptr, nullptr};  // ... and of the reverse pass's own table
+  size_t scratch_units_bwd_bytes[2] = {0, 0};
   void* scratch_units[2 * kTableSlots] = {};  // compact unit records of multi-step float32 programs (lynx_units.hpp) and their class-D extras, per table slot
   size_t scratch_units_bytes[2 * kTableSlots] = {};
   void* scratch_grad[3] = {nullptr, nullptr, nullptr};  // backward: partials, T_bar, build scratch
@@ -346,6 +349,8 @@ int lynx_ctx_destroy(lynx_ctx* ctx) {
     if (ctx->scratch_steps[i]) (void)hipFree(ctx->scratch_steps[i]);
   for (int i = 0; i < 2 * lynx_ctx::kTableSlots; ++i)
     if (ctx->scratch_units[i]) (void)hipFree(ctx->scratch_units[i]);
+  for (int i = 0; i < 2; ++i)
+    if (ctx->scratch_units_bwd[i]) (void)hipFree(ctx->scratch_units_bwd[i]);
   for (int i = 0; i < 3; ++i)
     if (ctx->scratch_grad[i]) (void)hipFree(ctx->scratch_grad[i]);
   for (int i = 0; i < lynx_ctx::kTableSlots; ++i) {
@@ -1421,7 +1426,27 @@ static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const v
   for (int u = a.n_units; u < kBwdGroup * kBwdMaxGroups; ++u) a.unit_slot[u] = 0;
   const size_t steps_bytes = (size_t)B * S * LYNX_STEP_STRIDE * sizeof(T);
   if ((rc = ensure_scratch(ctx, &ctx->scratch_steps[lynx_ctx::kTableBwd], &ctx->scratch_steps_bytes[lynx_ctx::kTableBwd], steps_bytes))) return rc;
-  if ((rc = launch_build<T>(ctx, lat, ctx->stream, d_energy_in, ctx->scratch_steps[lynx_ctx::kTableBwd], nullptr, merged))) return rc;
+  // float32 packed pairs: samples whose units all have class U take the structured reverse kernel (lynx_grad_units.hpp)
+  float* d_units = nullptr;
+  float* d_extras = nullptr;
+  if constexpr (W == 2) {
+    if (env_int("LYNX_BWD_UNITS", 1)) {
+      if ((rc = ensure_units_plan(ctx, lat, merged != 0))) return rc;
+      bool same = lat->units_ok && lat->units.n_units == a.n_units;
+      for (int u = 0; same && u < a.n_units; ++u) same = lat->units.slot[u] == a.unit_slot[u];
+      if (same) {
+        const int64_t n = B * a.n_units;
+        if ((rc = ensure_scratch(ctx, &ctx->scratch_units_bwd[0], &ctx->scratch_units_bwd_bytes[0], (size_t)n * kUnitStride * sizeof(float))) ||
+            (rc = ensure_scratch(ctx, &ctx->scratch_units_bwd[1], &ctx->scratch_units_bwd_bytes[1], (size_t)n * kUnitExtraStride * sizeof(float))))
+          return rc;
+        d_units = (float*)ctx->scratch_units_bwd[0];
+        d_extras = (float*)ctx->scratch_units_bwd[1];
+      }
+    }
+  }
+  if ((rc = launch_build<T>(ctx, lat, ctx->stream, d_energy_in, ctx->scratch_steps[lynx_ctx::kTableBwd], nullptr, merged, false,
+                            d_units, d_extras)))
+    return rc;
   ctx->main_dirty = true;
 
   // Z: what a lane carries -- one particle, or (float32) two as a packed pair
@@ -1447,9 +1472,19 @@ static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const v
                            (size_t)B * (2 * E + S + 1) * 49 * sizeof(T))))
     return rc;
   LatticeDev lv = dev_view(lat);
+  if constexpr (W == 2) {
+    if (d_units) {
+      const size_t lds_u = bwd_units_lds_bytes(S);
+      if ((rc = allow_lds(ctx, k_track_bwd_units, lds_u))) return rc;
+      hipLaunchKernelGGL(k_track_bwd_units, dim3((unsigned)(B * chunks)), dim3(kTrackThreads), lds_u, ctx->stream, a, S,
+                         (const float*)d_p_in, (const float*)d_units, (const float*)d_extras, d_moments_fwd, d_grad_moments,
+                         (float*)ctx->scratch_grad[0], (float*)d_grad_p_in);
+      HIP_TRY(ctx, hipGetLastError());
+    }
+  }
   hipLaunchKernelGGL((k_track_bwd<T, Z>), dim3((unsigned)(B * chunks)), dim3(kTrackThreads), lds, ctx->stream, lv, a,
                      (const T*)d_p_in, (const T*)ctx->scratch_steps[lynx_ctx::kTableBwd], d_moments_fwd, d_grad_moments,
-                     (T*)ctx->scratch_grad[0], (T*)d_grad_p_in);
+                     (T*)ctx->scratch_grad[0], (T*)d_grad_p_in, (const float*)d_units, kUnitStride, kUnitClassShift, (int)kClassU);
   HIP_TRY(ctx, hipGetLastError());
   hipLaunchKernelGGL(k_reduce_tbar<T>, dim3((unsigned)(B * S)), dim3(64), 0, ctx->stream, (const T*)ctx->scratch_grad[0],
                      (int)chunks, (int)S, (T*)ctx->scratch_grad[1]);

@@ -19,7 +19,11 @@ constexpr int kUnitSlot = 1;    // step-table slot of the unit's (dense) record
 constexpr int kUnitCoef = 4;    // 8 cavity coefficients (LYNX_C_*)
 constexpr int kUnitInv = 12;    // 4: inverse of the cavity's (s, delta) block (merged pairs)
 constexpr int kUnitMap = 16;    // 16 entries of class U, in the order of unit_entry_u()
-constexpr int kUnitExtraStride = 8;  // second array [B][U][8]: the 8 additional entries of class D, order of unit_entry_d()
+// second array [B][U][16]: [0..7] the 8 additional entries of class D (order of unit_entry_d()); [8..11] merged pairs:
+// the (s, delta) block of the RUN's map, rows 4 and 5 -- what gives the s and delta that enter the cavity (the reverse
+// pass drives the kick with them)
+constexpr int kUnitExtraStride = 16;
+constexpr int kUnitPre = 8;
 
 constexpr int kUnitKick = 1;      // active cavity: non-linear kick behind the linear map
 constexpr int kUnitInverse = 2;   // ... driven by the entry inverse (merged pair) instead of the unit's own s, delta
@@ -60,8 +64,8 @@ __host__ __device__ inline bool unit_pattern_has(int cls, int q) {
 // checks the proposed class `cls` against the numbers (every entry outside the pattern exactly zero, row 6 = e6, all
 // 49 finite -- otherwise dense) and writes the 32-float record and the 8 class-D extras.
 template <typename R>
-__device__ __forceinline__ void pack_unit_record(const R* rec, int slot, int cls, int pair, float* __restrict__ out,
-                                                 float* __restrict__ ex) {
+__device__ __forceinline__ void pack_unit_record(const R* rec, const R* pre /* merged pair: r44 r45 r54 r55 of the run */,
+                                                 int slot, int cls, int pair, float* __restrict__ out, float* __restrict__ ex) {
   const int desc = (int)rec[LYNX_FLAGS_OFFSET];
   const bool kick = ((desc >> LYNX_DESC_KIND_SHIFT) & 3) == LYNX_STEP_CAVITY && (desc & LYNX_FLAG_CAV_GAIN);
   bool ok = cls != kClassDense;
@@ -88,6 +92,10 @@ __device__ __forceinline__ void pack_unit_record(const R* rec, int slot, int cls
   for (int k = 0; k < 16; ++k) out[kUnitMap + k] = (float)rec[unit_entry_u(k)];
 #pragma unroll
   for (int k = 0; k < 8; ++k) ex[k] = (float)rec[unit_entry_d(k)];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) ex[kUnitPre + k] = pair ? (float)pre[k] : ((k == 0 || k == 3) ? 1.0f : 0.0f);
+#pragma unroll
+  for (int k = kUnitPre + 4; k < kUnitExtraStride; ++k) ex[k] = 0.f;
 }
 
 // what k_emit_steps is told about a step: -1 = no unit applies this step's record (the run half of a merged pair),

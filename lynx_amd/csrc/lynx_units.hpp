@@ -51,8 +51,13 @@ __global__ __launch_bounds__(256) void k_pack_units(UnitPlan plan, int64_t B, in
   const int64_t b = i / U;
   const int u = (int)(i - b * U);
   const int slot = plan.slot[u];
-  pack_unit_record<float>(steps + (b * S + slot) * LYNX_STEP_STRIDE, slot, plan.cls[u], plan.pair[u], units + i * kUnitStride,
-                          extras + i * kUnitExtraStride);
+  float pre[4] = {1.f, 0.f, 0.f, 1.f};
+  if (plan.pair[u]) {  // the run's slot holds its rows 4 and 5 in front (k_build)
+    const float* run = steps + (b * S + slot - 1) * LYNX_STEP_STRIDE;
+    pre[0] = run[4]; pre[1] = run[5]; pre[2] = run[7 + 4]; pre[3] = run[7 + 5];
+  }
+  pack_unit_record<float>(steps + (b * S + slot) * LYNX_STEP_STRIDE, pre, slot, plan.cls[u], plan.pair[u],
+                          units + i * kUnitStride, extras + i * kUnitExtraStride);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -60,4 +60,15 @@ for w in ('c4','c3big'):
     json.dump(rec, open(out+'/%s_pmc_traffic.json'%w,'w'), indent=1)
     for k,v in rec.items():
         if 'k_track_direct' in k or 'diag_copy' in k: print(w,k,v)
+t={}
+for f in sorted(glob.glob(out+'/shard_b*_*.json')):
+    try:
+        d=json.loads(open(f).read().strip().splitlines()[-1]); b=int(os.path.basename(f).split('_')[1][1:]); t.setdefault(b,[]).append(d['ms_per_step'])
+    except Exception as e: print(f,'ERR',e)
+if 1024 in t:
+    best={b:min(v) for b,v in t.items()}; med={b:sorted(v)[len(v)//2] for b,v in t.items()}
+    summary={'what':'BASELINE config 4 strong-scaled over N GPUs: one rank\'s shard of 1024/N samples on ONE GPU, RCCL gather in the step (world size 1); speedup = t(1024)/t(1024/N)',
+             'ms_per_step':{str(b):v for b,v in sorted(t.items())},'speedup_median':{str(1024//b): med[1024]/med[b] for b in sorted(med)},'speedup_best':{str(1024//b): best[1024]/best[b] for b in sorted(best)}}
+    json.dump(summary, open(out+'/strong_scaling_shards.json','w'), indent=1)
+    print('strong-scaling projection (t(1024)/t(1024/N), median):', summary['speedup_median'])
 PY
