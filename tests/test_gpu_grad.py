@@ -149,32 +149,33 @@ def test_structured_reverse_pass_fp32(lx, monkeypatch, B, N):
     """
     Samples whose units all have class U (runs of drifts, correctors, misaligned quadrupoles; cavities) take the
     structured reverse kernel (k_track_bwd_units: 16 particle products per unit instead of 49, unit records instead of
-    step-table rows), the others the dense one, in the same call: here every sample but one -- whose second
-    quadrupole is tilted (coupled map: the numeric check sends it to k_track_bwd).  Every parameter gradient and the
-    gradient w.r.t. the incoming particles against (a) the dense float32 pass (LYNX_BWD_UNITS=0) and (b) the float64
-    pass, which test_gradients_match_finite_differences_fp64 pins to finite differences of the oracle.
+    step-table rows), the others the dense one.  Every parameter gradient and the gradient w.r.t. the incoming
+    particles against (a) the dense float32 pass (LYNX_BWD_UNITS=0) and (b) the float64 pass, which
+    test_gradients_match_finite_differences_fp64 pins to finite differences of the oracle.  With a tilted quadrupole in
+    the lattice (coupled map: no unit of that run has the structure) both settings run the dense kernel: identical.
     """
     rng = np.random.default_rng(43)
     f = lambda v: np.full(B, v)  # noqa: E731
-    tilt = np.zeros(B)
-    tilt[1] = 0.3
-    desc = []
-    for cell in range(3):
-        desc += [("drift", dict(length=f(0.3))),
-                 ("quadrupole", dict(length=f(0.1), k1=rng.uniform(-5, 5, B), misalignment=rng.normal(0, 1e-3, (B, 2)),
-                                     **({"tilt": tilt} if cell == 1 else {}))),
-                 ("hcor", dict(length=f(0.1), angle=rng.normal(0, 1e-3, B))),
-                 ("drift", dict(length=f(0.3))),
-                 ("cavity", dict(length=f(1.0377), voltage=rng.uniform(5e6, 2e7, B), phase=rng.uniform(-10, 10, B),
-                                 frequency=f(1.3e9)))]
-    desc += [("quadrupole", dict(length=f(0.2), k1=rng.uniform(-5, 5, B))), ("drift", dict(length=f(0.4)))]
+
+    def lattice(tilted):
+        desc = []
+        for cell in range(3):
+            desc += [("drift", dict(length=f(0.3))),
+                     ("quadrupole", dict(length=f(0.1), k1=rng.uniform(-5, 5, B), misalignment=rng.normal(0, 1e-3, (B, 2)),
+                                         **({"tilt": rng.uniform(-0.3, 0.3, B)} if tilted and cell == 1 else {}))),
+                     ("hcor", dict(length=f(0.1), angle=rng.normal(0, 1e-3, B))),
+                     ("drift", dict(length=f(0.3))),
+                     ("cavity", dict(length=f(1.0377), voltage=rng.uniform(5e6, 2e7, B), phase=rng.uniform(-10, 10, B),
+                                     frequency=f(1.3e9)))]
+        return desc + [("quadrupole", dict(length=f(0.2), k1=rng.uniform(-5, 5, B))), ("drift", dict(length=f(0.4)))]
+
     P = o.gaussian_particles((B,), N, seed=9, dtype=np.float64, sigma=[1e-3, 1e-4, 1e-3, 1e-4, 1e-3, 1e-3],
                              mu=[1e-3, -1e-4, 5e-4, 2e-4, 1e-4, 1e-3])
     energy = rng.uniform(6e6, 8e6, B)
     w_mu = rng.normal(size=(B, 6))
     w_cov = rng.normal(size=(B, 6, 6)) * 1e3
 
-    def gradients(dtype):
+    def gradients(desc, dtype):
         elements, _ = make_lattice(desc, dtype, lx)
         g = lx.grad.track_vjp(lx.Segment(elements), lx.ParticleBeam(P.astype(dtype), energy.astype(dtype), dtype=dtype))(
             mu_bar=w_mu, cov_bar=w_cov, wrt_particles=True)
@@ -185,20 +186,23 @@ def test_structured_reverse_pass_fp32(lx, monkeypatch, B, N):
         out["particles"] = np.asarray(g.particles, dtype=np.float64)[..., :6]
         return out
 
-    g64 = gradients(np.float64)
-    structured = gradients(np.float32)
-    monkeypatch.setenv("LYNX_BWD_UNITS", "0")
-    dense = gradients(np.float32)
-    monkeypatch.delenv("LYNX_BWD_UNITS")
-    for key, ref in g64.items():
-        floor = 1e-4 * max(np.max(np.abs(ref)), 1e-9 * np.max(np.abs(w_cov)))
-        for name, got in (("structured", structured[key]), ("dense", dense[key])):
-            assert got.shape == ref.shape
-            assert np.all(np.abs(got - ref) <= 3e-3 * np.abs(ref) + floor), (name, key, got, ref)
-        assert np.all(np.abs(structured[key] - dense[key]) <= 1e-3 * np.abs(ref) + floor), (key, structured[key], dense[key])
-    # the tilted sample went through the dense kernel both times: identical there; elsewhere the sums are associated differently
-    assert np.array_equal(structured["particles"][1], dense["particles"][1])
-    assert any(np.any(structured[key] != dense[key]) for key in g64)
+    for tilted in (False, True):
+        desc = lattice(tilted)
+        g64 = gradients(desc, np.float64)
+        structured = gradients(desc, np.float32)
+        monkeypatch.setenv("LYNX_BWD_UNITS", "0")
+        dense = gradients(desc, np.float32)
+        monkeypatch.delenv("LYNX_BWD_UNITS")
+        for key, ref in g64.items():
+            floor = 1e-4 * max(np.max(np.abs(ref)), 1e-9 * np.max(np.abs(w_cov)))
+            for name, got in (("structured", structured[key]), ("dense", dense[key])):
+                assert got.shape == ref.shape
+                assert np.all(np.abs(got - ref) <= 3e-3 * np.abs(ref) + floor), (tilted, name, key, got, ref)
+            assert np.all(np.abs(structured[key] - dense[key]) <= 1e-3 * np.abs(ref) + floor), (tilted, key)
+        if tilted:  # the middle run is coupled: ... for every sample (the tilt flag is a whole-batch predicate)
+            assert all(np.array_equal(structured[key], dense[key]) for key in g64)
+        else:       # different kernels: the sums over particles are associated differently
+            assert any(np.any(structured[key] != dense[key]) for key in g64)
 
 
 def test_gradient_of_linear_lattice_and_broadcast_parameters(lx):
