@@ -774,6 +774,18 @@ __device__ __forceinline__ void phase_sincos(double x, double& s, double& c) {
 __device__ __forceinline__ void phase_sincos(lynx_f32x2 x, lynx_f32x2& s, lynx_f32x2& c) {
   float s0, c0, s1, c1;
   const float big = __builtin_fmaxf(__builtin_fabsf(x.x), __builtin_fabsf(x.y));
+  // whole wave inside the first quadrant's half width: quadrant 0 for everybody -- no reduction, no selection (the
+  // general path's result for q = 0, bit for bit)
+  if (__builtin_amdgcn_ballot_w64(!(big <= 0.75f)) == 0) {
+    const lynx_f32x2 z = x * x;
+    lynx_f32x2 ps = vfma(z, lynx_f32x2(-1.9515295891e-4f), lynx_f32x2(8.3321608736e-3f));
+    ps = vfma(ps, z, lynx_f32x2(-1.6666654611e-1f));
+    s = vfma(ps * z, x, x);
+    lynx_f32x2 pc = vfma(z, lynx_f32x2(2.443315711809948e-5f), lynx_f32x2(-1.388731625493765e-3f));
+    pc = vfma(pc, z, lynx_f32x2(4.166664568298827e-2f));
+    c = vfma(pc * z, z, vfma(z, lynx_f32x2(-0.5f), lynx_f32x2(1.0f)));
+    return;
+  }
   if (__builtin_expect(!(big <= kFastTrigLimit), 0)) {
     phase_sincos(x.x, s0, c0);
     phase_sincos(x.y, s1, c1);
@@ -815,6 +827,17 @@ __device__ __forceinline__ float phase_cos(float x) {
 __device__ __forceinline__ double phase_cos(double x) { return t_cos(x); }
 __device__ __forceinline__ lynx_f32x2 phase_cos(lynx_f32x2 x) {
   const float big = __builtin_fmaxf(__builtin_fabsf(x.x), __builtin_fabsf(x.y));
+  // Cavity phases are a few degrees and s beta0 k a few milliradians: when the WHOLE WAVE sits inside |x| <= 1.5 the
+  // half-period index is 0 for everybody, so the reduction (x - n pi in three steps) and the sign (n's parity) drop
+  // out -- bit for bit what the general path returns for n = 0, at 9 instead of 21 instructions per pair
+  // (BASELINE config 5 forward: 0.765 -> 0.72 ms/step).
+  if (__builtin_amdgcn_ballot_w64(!(big <= 1.5f)) == 0) {
+    const lynx_f32x2 z = x * x;
+    lynx_f32x2 q = vfma(z, lynx_f32x2(-2.654408035596134e-07f), lynx_f32x2(2.478602073097136e-05f));
+    q = vfma(q, z, lynx_f32x2(-0.0013888812391087413f));
+    q = vfma(q, z, lynx_f32x2(0.0416666679084301f));
+    return vfma(q * z, z, vfma(z, lynx_f32x2(-0.5f), lynx_f32x2(1.0f)));
+  }
   lynx_f32x2 out;
   if (__builtin_expect(!(big <= kFastTrigLimit), 0)) {
     out.x = phase_cos(x.x);
