@@ -1255,7 +1255,10 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
       // cavities: their build (k_cavity_flags + the lanes kernels) takes most of a streaming kernel's time next to a
       // VALU-bound kernel, and the host's wake-up would sit on the critical path (BASELINE config 5: 0.932 -> 0.947
       // ms/step with it).  LYNX_BUILD_HOST_WAIT=0 / 1 forces the main-stream / host wait.
-      if (env_int("LYNX_BUILD_HOST_WAIT", lat->has_cavity ? 0 : 1)) HIP_TRY(ctx, hipEventSynchronize(ctx->ev_built[slot]));
+      // Nor for short streaming kernels (BASELINE config 3, 1 M particles: 29 us of kernel, 22 us of build -- the
+      // host would be the pacemaker: 48 -> 75 us/step): from 128 MB of particles per call.
+      const bool long_kernel = (size_t)B * N * 7 * sizeof(T) >= ((size_t)128 << 20);
+      if (env_int("LYNX_BUILD_HOST_WAIT", (lat->has_cavity || !long_kernel) ? 0 : 1)) HIP_TRY(ctx, hipEventSynchronize(ctx->ev_built[slot]));
       else HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_built[slot], 0));
     }
     d_steps = ctx->scratch_steps[slot];
