@@ -1132,19 +1132,19 @@ static int ensure_units_plan(lynx_ctx* ctx, lynx_lattice* lat, bool merged) {
   return LYNX_OK;
 }
 
-template <int MOM, bool FULL>
+template <int MOM, bool FULL, int PAIRS>
 static int launch_units_inst(lynx_ctx* ctx, const TrackPlan& p, int32_t U, int32_t S, const void* d_p_in, void* d_p_out,
                              void* d_energy_out, const void* d_steps, const void* d_units, const void* d_extras,
                              double* d_partials) {
   const size_t lds = units_lds_bytes((size_t)p.a.lds_scratch_bytes, U);
-  int rc = allow_lds(ctx, k_track_units<MOM, FULL>, lds);
+  int rc = allow_lds(ctx, k_track_units<MOM, FULL, PAIRS>, lds);
   if (rc) return rc;
   hipEvent_t e0 = nullptr, e1 = p.done;
   if (ctx->profiling) {  // every profiled launch needs time stamps of its own
     HIP_TRY(ctx, hipEventCreate(&e0));
     HIP_TRY(ctx, hipEventCreate(&e1));
   }
-  hipExtLaunchKernelGGL((k_track_units<MOM, FULL>), dim3(p.grid), dim3(kTrackThreads), (std::uint32_t)lds, ctx->stream, e0, e1,
+  hipExtLaunchKernelGGL((k_track_units<MOM, FULL, PAIRS>), dim3(p.grid), dim3(kTrackThreads), (std::uint32_t)lds, ctx->stream, e0, e1,
                         0u, p.a, U, S, (const float*)d_p_in, (float*)d_p_out, (float*)d_energy_out, (const float*)d_steps,
                         (const float*)d_units, (const float*)d_extras, d_partials);
   HIP_TRY(ctx, hipGetLastError());
@@ -1157,9 +1157,14 @@ static int launch_units(lynx_ctx* ctx, const TrackPlan& p, int32_t U, int32_t S,
                         void* d_energy_out, const void* d_steps, const void* d_units, const void* d_extras,
                         double* d_partials, bool moments) {
 #define LYNX_UNITS_ARGS ctx, p, U, S, d_p_in, d_p_out, d_energy_out, d_steps, d_units, d_extras, d_partials
-  if (!moments) return launch_units_inst<0, false>(LYNX_UNITS_ARGS);
-  if (p.mom_mode == 3) return p.full_cov ? launch_units_inst<3, true>(LYNX_UNITS_ARGS) : launch_units_inst<3, false>(LYNX_UNITS_ARGS);
-  return p.full_cov ? launch_units_inst<2, true>(LYNX_UNITS_ARGS) : launch_units_inst<2, false>(LYNX_UNITS_ARGS);
+  if (p.unroll == 4) {  // two pairs per lane
+    if (!moments) return launch_units_inst<0, false, 2>(LYNX_UNITS_ARGS);
+    if (p.mom_mode == 3) return p.full_cov ? launch_units_inst<3, true, 2>(LYNX_UNITS_ARGS) : launch_units_inst<3, false, 2>(LYNX_UNITS_ARGS);
+    return p.full_cov ? launch_units_inst<2, true, 2>(LYNX_UNITS_ARGS) : launch_units_inst<2, false, 2>(LYNX_UNITS_ARGS);
+  }
+  if (!moments) return launch_units_inst<0, false, 1>(LYNX_UNITS_ARGS);
+  if (p.mom_mode == 3) return p.full_cov ? launch_units_inst<3, true, 1>(LYNX_UNITS_ARGS) : launch_units_inst<3, false, 1>(LYNX_UNITS_ARGS);
+  return p.full_cov ? launch_units_inst<2, true, 1>(LYNX_UNITS_ARGS) : launch_units_inst<2, false, 1>(LYNX_UNITS_ARGS);
 #undef LYNX_UNITS_ARGS
 }
 
@@ -1227,7 +1232,7 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
       // dense step loop of k_track_direct
       // (LYNX_TRACK_UNITS=2: insist -- an error if this call cannot take the structured loop; for tests)
       const int want_units = env_int("LYNX_TRACK_UNITS", 1);
-      if (S > 1 && p.unroll == 2 && !p.xpose && p.a.n_observers == 0 && !p.a.interleave && want_units) {
+      if (S > 1 && (p.unroll == 2 || p.unroll == 4) && !p.xpose && p.a.n_observers == 0 && !p.a.interleave && want_units) {
         if ((rc = ensure_units_plan(ctx, lat, p.a.merged_pairs != 0))) return rc;
         use_units = lat->units_ok;
       }

@@ -92,7 +92,9 @@ __device__ __forceinline__ bool pair_not_finite(const lynx_f32x2 (&z)[7]) {
   return (acc.x != acc.x) || (acc.y != acc.y);
 }
 
-template <int MOM, bool FULL> constexpr int units_waves_per_simd() { return (!FULL && (MOM == 0 || MOM == 3)) ? 5 : 1; }
+template <int MOM, bool FULL, int PAIRS> constexpr int units_waves_per_simd() {
+  return PAIRS == 1 ? ((!FULL && (MOM == 0 || MOM == 3)) ? 5 : 1) : ((!FULL && (MOM == 0 || MOM == 3)) ? 4 : 1);
+}
 
 // half a unit record (16 scalars), fetched with wave-uniform loads: they land in scalar registers and are the
 // broadcast operand of the packed multiply-adds
@@ -192,41 +194,51 @@ __device__ __forceinline__ void unit_linear_dense(const float* __restrict__ tab,
   for (int i = 0; i < 7; ++i) z[i] = o[i];
 }
 
-// The program on a pair of particles.  `s_units` / `s_extras`: the sample's records; `all_dense`: every unit in its
-// dense form.
+// The program on the PAIRS pairs of particles a lane holds.  `s_units` / `s_extras`: the sample's records;
+// `all_dense`: every unit in its dense form.  One record fetch per unit serves all pairs.
+template <int PAIRS>
 __device__ __forceinline__ void units_program(int U, const float* __restrict__ s_units, const float* __restrict__ s_extras,
-                                              const float* __restrict__ g_steps, bool all_dense, lynx_f32x2 (&z)[7]) {
+                                              const float* __restrict__ g_steps, bool all_dense, lynx_f32x2 (&z)[PAIRS][7]) {
 #pragma unroll 1
   for (int u = 0; u < U; ++u) {
     const float* rec = s_units + u * kUnitStride;
     UnitHalf kick, map;
     unit_fetch(rec + kUnitMap, map);
     unit_fetch(rec, kick);
-    const lynx_f32x2 s_own = z[4], d_own = z[5];
     const int bits = __builtin_amdgcn_readfirstlane(__float_as_int(kick.v[kUnitDesc]));  // wave-uniform: scalar branches
     const int cls = all_dense ? (int)kClassDense : ((bits >> kUnitClassShift) & 3);
+    lynx_f32x2 s_own[PAIRS], d_own[PAIRS];
+#pragma unroll
+    for (int p = 0; p < PAIRS; ++p) {
+      s_own[p] = z[p][4];
+      d_own[p] = z[p][5];
+    }
     if (cls == kClassU) {
-      unit_linear<kClassU>(map, nullptr, z);
+#pragma unroll
+      for (int p = 0; p < PAIRS; ++p) unit_linear<kClassU>(map, nullptr, z[p]);
     } else if (cls == kClassD) {
-      unit_linear<kClassD>(map, s_extras + u * kUnitExtraStride, z);
+#pragma unroll
+      for (int p = 0; p < PAIRS; ++p) unit_linear<kClassD>(map, s_extras + u * kUnitExtraStride, z[p]);
     } else {
       const int slot = __builtin_amdgcn_readfirstlane(__float_as_int(kick.v[kUnitSlot]));
-      unit_linear_dense(g_steps + slot * LYNX_STEP_STRIDE, z);
+#pragma unroll
+      for (int p = 0; p < PAIRS; ++p) unit_linear_dense(g_steps + slot * LYNX_STEP_STRIDE, z[p]);
     }
-    unit_nonlinear(kick, bits, s_own, d_own, z);
+#pragma unroll
+    for (int p = 0; p < PAIRS; ++p) unit_nonlinear(kick, bits, s_own[p], d_own[p], z[p]);
   }
 }
 
 // ---------------------------------------------------------------------------------------
-// k_track_units: grid.x = B * chunks, 256 threads, two particles per lane (tid and tid + 256 of a 512-particle tile).
+// k_track_units: grid.x = B * chunks, 256 threads, 2 PAIRS particles per lane (tid + 256 k of a tile of 512 PAIRS).
 // ---------------------------------------------------------------------------------------
-template <int MOM, bool FULL>
-__global__ __launch_bounds__(kTrackThreads, (units_waves_per_simd<MOM, FULL>())) void k_track_units(
+template <int MOM, bool FULL, int PAIRS>
+__global__ __launch_bounds__(kTrackThreads, (units_waves_per_simd<MOM, FULL, PAIRS>())) void k_track_units(
     TrackArgs a, int32_t U, int32_t S, const float* p_in, float* p_out, float* __restrict__ energy_out,
     const float* __restrict__ steps_in, const float* __restrict__ units_in, const float* __restrict__ extras_in,
     double* __restrict__ partials) {
   using T = float;
-  constexpr int UNROLL = 2;
+  constexpr int UNROLL = 2 * PAIRS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x;
   // sample and chunk of this workgroup, in scalar registers (the division runs on the vector unit): everything that
@@ -267,12 +279,14 @@ __global__ __launch_bounds__(kTrackThreads, (units_waves_per_simd<MOM, FULL>()))
     // registers; lanes beyond the end of the sample ride along on a clamped address and are masked where it counts)
     if (tile * kTile >= end) break;
     sums.begin_iteration();
-    lynx_f32x2 z[7];
+    lynx_f32x2 z[PAIRS][7];
 #pragma unroll
-    for (int c = 0; c < 7; ++c) {
-      z[c].x = zn[0][c];
-      z[c].y = zn[1][c];
-    }
+    for (int p = 0; p < PAIRS; ++p)
+#pragma unroll
+      for (int c = 0; c < 7; ++c) {
+        z[p][c].x = zn[2 * p][c];
+        z[p][c].y = zn[2 * p + 1][c];
+      }
     if (it + 1 < a.tiles_per_wg) {  // prefetch the next tile of this workgroup
       const int64_t j0 = (tile + 1) * kTile + tid;
 #pragma unroll
@@ -282,12 +296,18 @@ __global__ __launch_bounds__(kTrackThreads, (units_waves_per_simd<MOM, FULL>()))
       }
     }
     // a non-finite particle anywhere in the wave: the dense chain, whose zero entries spread it like the reference's
-    bool all_dense = __builtin_amdgcn_ballot_w64(pair_not_finite(z)) != 0;  // wave-uniform
+    auto any_not_finite = [&]() {
+      bool bad = false;
+#pragma unroll
+      for (int p = 0; p < PAIRS; ++p) bad = bad || pair_not_finite(z[p]);
+      return __builtin_amdgcn_ballot_w64(bad) != 0;  // wave-uniform
+    };
+    bool all_dense = any_not_finite();
     for (;;) {
-      units_program(U, g_units, g_extras, g_steps, all_dense, z);
+      units_program<PAIRS>(U, g_units, g_extras, g_steps, all_dense, z);
       // what came out: a value that overflowed on the way (or met a non-finite coefficient) would have spread through
       // the dense chain's zero entries -- then the tile is done again, densely
-      if (all_dense || __builtin_amdgcn_ballot_w64(pair_not_finite(z)) == 0) break;
+      if (all_dense || !any_not_finite()) break;
       all_dense = true;
       // reload the tile; the outgoing beam has not been written yet, so in-place tracking is safe
 #pragma unroll
@@ -297,18 +317,20 @@ __global__ __launch_bounds__(kTrackThreads, (units_waves_per_simd<MOM, FULL>()))
         load_particle(src + (i < end ? i : 0) * 7, t);
 #pragma unroll
         for (int c = 0; c < 7; ++c) {
-          if (u == 0) z[c].x = t[c];
-          else z[c].y = t[c];
+          if (u % 2 == 0) z[u / 2][c].x = t[c];
+          else z[u / 2][c].y = t[c];
         }
       }
     }
 
     T zo[UNROLL][7];
 #pragma unroll
-    for (int c = 0; c < 7; ++c) {
-      zo[0][c] = z[c].x;
-      zo[1][c] = z[c].y;
-    }
+    for (int p = 0; p < PAIRS; ++p)
+#pragma unroll
+      for (int c = 0; c < 7; ++c) {
+        zo[2 * p][c] = z[p][c].x;
+        zo[2 * p + 1][c] = z[p][c].y;
+      }
     if (MOM && it == 0) {
 #pragma unroll
       for (int k = 0; k < 6; ++k) shift[k] = wave_first(zo[0][k]);
