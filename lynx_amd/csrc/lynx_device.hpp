@@ -1026,7 +1026,19 @@ struct TrackArgs {
   int64_t in_stride;     // scalars between the samples of p_in: N*7, or 0 for one shared incoming beam
   int32_t merged_pairs;  // the step table holds [run, cavity] pairs in merged form (the builder marks them: LYNX_DESC_PAIR)
   int32_t n_observers;   // LYNX_STEP_FLAG_OBSERVE steps of the program (their sums live behind the step table in LDS)
+  // "this kernel has reached its tail": workgroup `tail_wg` (one of the last to be dispatched) writes `tail_seq` to
+  // `tail_flag` when it starts.  The build stream waits for the flag of the kernel BEFORE the one in front of it
+  // (hipStreamWaitValue32), so that the next call's build starts where the GPU is running empty instead of at the
+  // head of a streaming kernel, where its waves take slots from it for hundreds of microseconds.
+  uint32_t tail_seq;
+  int32_t tail_wg;
+  unsigned int* tail_flag;
 };
+
+__device__ __forceinline__ void announce_tail(const TrackArgs& a) {
+  if (a.tail_flag && blockIdx.x == (unsigned)a.tail_wg && threadIdx.x == 0)
+    __hip_atomic_store(a.tail_flag, a.tail_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 __device__ __forceinline__ float uniform_value(float v) {
   return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
@@ -1513,6 +1525,7 @@ __global__ __launch_bounds__(kTrackThreads, (track_waves_per_simd<T, MOM, FULL, 
     double* __restrict__ obs_partials) {
   static_assert(!XPOSE || (UNROLL * 7 * sizeof(T) == 112 && !FUSED), "XPOSE: a lane owns 112 bytes");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  announce_tail(a);
   unsigned char* s_scratch = smem_raw;                                 // build scratch / wave tiles / reduction
   T* s_steps = reinterpret_cast<T*>(smem_raw + a.lds_scratch_bytes);    // [S][64]
   T* s_energy = s_steps + (size_t)lat.n_steps * LYNX_STEP_STRIDE;       // [S+1]

@@ -52,6 +52,11 @@ struct lynx_ctx {
   // looks at them whenever it has waited for the GPU anyway
   int32_t* h_status = nullptr;
   int32_t* d_status = nullptr;
+  // "streaming kernel k has reached its tail" (TrackArgs.tail_*): the word the kernels write, and how many have been
+  // launched with it
+  unsigned int* d_tail_flag = nullptr;
+  uint32_t tail_seq = 0;
+  int can_wait_value = 0;
   std::string err;
   hipDeviceProp_t prop;
   // caching allocator: size class -> free blocks; live pointer -> size class
@@ -314,6 +319,9 @@ int lynx_ctx_create(int device, lynx_ctx** out) {
   HIP_TRY(nullptr, hipHostMalloc((void**)&ctx->h_status, 2 * sizeof(int32_t), hipHostMallocMapped));
   ctx->h_status[0] = ctx->h_status[1] = 0;
   HIP_TRY(nullptr, hipHostGetDevicePointer((void**)&ctx->d_status, ctx->h_status, 0));
+  HIP_TRY(nullptr, hipMalloc((void**)&ctx->d_tail_flag, sizeof(unsigned int)));
+  HIP_TRY(nullptr, hipMemset(ctx->d_tail_flag, 0, sizeof(unsigned int)));
+  if (hipDeviceGetAttribute(&ctx->can_wait_value, hipDeviceAttributeCanUseStreamWaitValue, device) != hipSuccess) ctx->can_wait_value = 0;
   *out = ctx;
   return LYNX_OK;
 }
@@ -358,6 +366,7 @@ int lynx_ctx_destroy(lynx_ctx* ctx) {
     (void)hipEventDestroy(ctx->ev_streamed_own[i]);
   }
   if (ctx->h_status) (void)hipHostFree(ctx->h_status);
+  if (ctx->d_tail_flag) (void)hipFree(ctx->d_tail_flag);
   (void)hipEventDestroy(ctx->ev_mark);
   (void)hipEventDestroy(ctx->ev_start);
   (void)hipEventDestroy(ctx->ev_stop);
@@ -953,6 +962,9 @@ static TrackPlan plan_track(lynx_ctx* ctx, const lynx_lattice* lat, int64_t B, i
   p.a.store = 0;
   p.a.interleave = env_int("LYNX_INTERLEAVE", 0);
   p.a.build_chunk = 1;
+  p.a.tail_flag = nullptr;
+  p.a.tail_seq = 0;
+  p.a.tail_wg = 0;
   // wave tiles: with non-temporal full-width stores +7 % on single-map float32 programs (BASELINE config 4:
   // 5.4 -> 5.8 TB/s) and +10 % (+7 % of that from the stores) on float64 (config 3 at 8 M particles); slower on
   // multi-step float32 programs, which want two particles per lane, not four
@@ -1193,6 +1205,7 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
   const void* d_extras = nullptr;
   int n_units = 0;
   bool use_units = false;
+  bool tail = false;
   int rc;
   int slot = -1;
   bool async_build = false;
@@ -1217,6 +1230,11 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
     if (async) {
       // the table slot was last read by the streaming kernel kTableSlots calls ago
       if (ctx->streamed_valid[slot]) HIP_TRY(ctx, hipStreamWaitEvent(bs, ctx->ev_streamed[slot], 0));
+      // ... and the build starts in the TAIL of the streaming kernel before the one enqueued last (which has the GPU
+      // to itself when it gets there), not at that kernel's head
+      tail = ctx->can_wait_value && env_int("LYNX_BUILD_IN_TAIL", 1);
+      if (tail && ctx->tail_seq >= 2)
+        HIP_TRY(ctx, hipStreamWaitValue32(bs, ctx->d_tail_flag, ctx->tail_seq - 1, hipStreamWaitValueGte, 0xffffffffu));
       // what the build reads (energy, lattice pool) may have been written on the main stream
       if (ctx->main_dirty || (ctx->main_wrote && ctx->main_wrote == d_energy_in)) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev_mark, ctx->stream));
@@ -1301,6 +1319,12 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
   // table slot; a call whose build ran on the main stream leaves it out (it costs host time: BASELINE config 2 is
   // bound by the host's enqueue rate) and marks the main stream dirty instead, which makes the next asynchronous
   // build wait for everything enqueued here
+  if (tail) {  // this kernel announces its tail: one of the workgroups of its last round of dispatches
+    const int64_t cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+    p.a.tail_flag = ctx->d_tail_flag;
+    p.a.tail_seq = ++ctx->tail_seq;
+    p.a.tail_wg = (int32_t)std::max<int64_t>(0, (int64_t)p.grid - 4 * cus);
+  }
   p.done = (slot >= 0 && async_build) ? ctx->ev_streamed_own[slot] : nullptr;
   if (side && !p.done) p.done = ring->track_done;  // the side stream's reduction starts behind it
   if (use_units) rc = launch_units(ctx, p, n_units, S, d_p_in, d_p_out, d_energy_out, d_steps, d_units, d_extras, d_partials, moments);

@@ -240,6 +240,7 @@ __global__ __launch_bounds__(kTrackThreads, (units_waves_per_simd<MOM, FULL, PAI
   using T = float;
   constexpr int UNROLL = 2 * PAIRS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  announce_tail(a);
   const int tid = threadIdx.x;
   // sample and chunk of this workgroup, in scalar registers (the division runs on the vector unit): everything that
   // is derived from them -- the record addresses of the step loop above all -- then stays scalar
