@@ -254,10 +254,16 @@ __global__ __launch_bounds__(kTrackThreads, (units_waves_per_simd<MOM, FULL, PAI
   const float* g_units = units_in + b * (int64_t)U * kUnitStride;
   const float* g_extras = extras_in + b * (int64_t)U * kUnitExtraStride;
 
+  int64_t tile0 = (int64_t)chunk * a.tiles_per_wg;
+  int my_tiles = a.tiles_per_wg;
+  if (a.n_tiles > 0) {  // balanced partition (TrackArgs)
+    tile0 = (int64_t)chunk * a.n_tiles / a.chunks;
+    my_tiles = (int)(((int64_t)(chunk + 1) * a.n_tiles) / a.chunks - tile0);
+  }
   // the first tile's loads go out before anything else
   T zn[UNROLL][7];
   {
-    const int64_t i0 = (int64_t)chunk * a.tiles_per_wg * kTile + tid;
+    const int64_t i0 = tile0 * kTile + tid;
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       const int64_t i = i0 + (int64_t)u * kTrackThreads;
@@ -272,8 +278,8 @@ __global__ __launch_bounds__(kTrackThreads, (units_waves_per_simd<MOM, FULL, PAI
 #pragma unroll
   for (int i = 0; i < 6; ++i) shift[i] = T(0);
 
-  for (int it = 0; it < a.tiles_per_wg; ++it) {
-    const int64_t tile = (int64_t)chunk * a.tiles_per_wg + it;
+  for (int it = 0; it < my_tiles; ++it) {
+    const int64_t tile = tile0 + it;
     const int64_t i0 = tile * kTile + tid;
     // (uniform: the whole workgroup leaves together.  A per-lane `i0 >= end` here makes the loop's control flow
     // divergent, and the compiler then keeps every loop-carried scalar -- record registers, addresses -- in VECTOR
@@ -288,7 +294,7 @@ __global__ __launch_bounds__(kTrackThreads, (units_waves_per_simd<MOM, FULL, PAI
         z[p][c].x = zn[2 * p][c];
         z[p][c].y = zn[2 * p + 1][c];
       }
-    if (it + 1 < a.tiles_per_wg) {  // prefetch the next tile of this workgroup
+    if (it + 1 < my_tiles) {  // prefetch the next tile of this workgroup
       const int64_t j0 = (tile + 1) * kTile + tid;
 #pragma unroll
       for (int u = 0; u < UNROLL; ++u) {
