@@ -579,7 +579,9 @@ def main():
             "dtype": "f32" if itemsize == 4 else "f64",
             "data": "synthetic",
             "config": config,
-            "roofline": {"bound": "hbm", "kernel": "k_track_direct", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            # config 5's step loop is the structured one (lynx_units.hpp) unless LYNX_TRACK_UNITS=0 asks for the dense loop
+            "roofline": {"bound": "hbm", "kernel": "k_track_units" if (args.workload == "c5" and os.environ.get("LYNX_TRACK_UNITS", "1") != "0")
+                         else "k_track_direct", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes,

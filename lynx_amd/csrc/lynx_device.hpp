@@ -58,14 +58,22 @@ __device__ __forceinline__ int step_descriptor(const LatticeDev& lat, int s, int
   return d;
 }
 
-// LYNX_ENTRY_OFFSET: inverse of the (s, delta) block of a cavity's rounded map, formed in float64
+// LYNX_ENTRY_OFFSET: inverse of the (s, delta) block of a cavity's rounded map, formed in float64.  Returns whether the
+// block is too ill-conditioned to be used that way (LYNX_DESC_ILL): the forward kernels recover s_in, delta_in from
+// components 4 and 5 of M z, whose float32 rounding the inverse amplifies by about
+// (|c44 c55| + |c45 c54|) / |det| -- 1.0 to 1.04 on ultra-relativistic beams (BASELINE config 5), unbounded at low
+// energy off crest (the block is singular at E = 1 MeV, phi = -30 deg, V = 0.5247 MV).  Above kEntryConditionLimit, or with a det that is
+// not finite or zero, the pair is applied in the rows form instead, which has no such factor.
+constexpr double kEntryConditionLimit = 4.0;
 template <typename T>
-__device__ __forceinline__ void cavity_entry_inverse(T c44, T c45, T c54, T c55, T (&ci)[4]) {
-  const double det = (double)c44 * (double)c55 - (double)c45 * (double)c54;
+__device__ __forceinline__ bool cavity_entry_inverse(T c44, T c45, T c54, T c55, T (&ci)[4]) {
+  const double a = (double)c44 * (double)c55, b = (double)c45 * (double)c54;
+  const double det = a - b;
   ci[0] = (T)((double)c55 / det);
   ci[1] = (T)(-(double)c45 / det);
   ci[2] = (T)(-(double)c54 / det);
   ci[3] = (T)((double)c44 / det);
+  return !(fabs(det) * kEntryConditionLimit >= fabs(a) + fabs(b)) || det == 0.0;  // NaN compares false: ill
 }
 
 constexpr int kBuildChunk = 64;   // elements built in parallel per compose round (k_build may use up to 128)
@@ -605,6 +613,7 @@ __global__ __launch_bounds__(64, 4) void k_emit_steps(LatticeDev lat, const int3
   const double* src = products + (int64_t)step_slot[s] * 49 * Bp + b;
   const bool pair_cavity = merge_pairs && s > 0 && steps_pair_up(lat.steps[s - 1], st);
   const bool pair_run = merge_pairs && s + 1 < S && steps_pair_up(st, lat.steps[s + 1]);
+  bool entry_ill = false;
 #pragma unroll
   for (int q = 49; q < LYNX_STEP_STRIDE; ++q) row[q] = T(0);
   if (pair_cavity) {
@@ -644,7 +653,7 @@ __global__ __launch_bounds__(64, 4) void k_emit_steps(LatticeDev lat, const int3
       }
     }
     T ci[4];
-    cavity_entry_inverse<T>(c4[0], c4[1], c5[0], c5[1], ci);
+    entry_ill = cavity_entry_inverse<T>(c4[0], c4[1], c5[0], c5[1], ci);
 #pragma unroll
     for (int q = 0; q < 4; ++q) row[LYNX_ENTRY_OFFSET + q] = ci[q];
     // the run's (s, delta) block, for the unit record (the row buffer's padding: not part of the table)
@@ -674,7 +683,7 @@ __global__ __launch_bounds__(64, 4) void k_emit_steps(LatticeDev lat, const int3
 #pragma unroll
     for (int q = 0; q < 8; ++q) row[LYNX_COEF_OFFSET + q] = cs[q * Bp];
   }
-  row[LYNX_FLAGS_OFFSET] = (T)step_descriptor(lat, s, merge_pairs);
+  row[LYNX_FLAGS_OFFSET] = (T)(step_descriptor(lat, s, merge_pairs) | (entry_ill ? LYNX_DESC_ILL : 0));
   if (s == S - 1) {
     const T e_out = energy_before_step<T>(lat, b, energy_in[b], S);
     row[LYNX_ENERGY_OFFSET] = e_out;
@@ -992,19 +1001,23 @@ __global__ __launch_bounds__(1024) void k_build(LatticeDev lat, const T* __restr
         v = (T)acc;
       }
       T ci[4] = {T(0), T(0), T(0), T(0)};
-      if (threadIdx.x == 49) cavity_entry_inverse<T>(cav[4 * 7 + 4], cav[4 * 7 + 5], cav[5 * 7 + 4], cav[5 * 7 + 5], ci);
+      bool ill = false;
+      if (threadIdx.x == 49) ill = cavity_entry_inverse<T>(cav[4 * 7 + 4], cav[4 * 7 + 5], cav[5 * 7 + 4], cav[5 * 7 + 5], ci);
       __syncthreads();
       if (threadIdx.x < 49) cav[threadIdx.x] = v;
       if (threadIdx.x == 49) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) cav[LYNX_ENTRY_OFFSET + q] = ci[q];
+        cav[LYNX_FLAGS_OFFSET] = ill ? T(1) : T(0);  // until the descriptors are written below
       }
       if (threadIdx.x >= 64 && threadIdx.x < 78) run[threadIdx.x - 64] = run[28 + (threadIdx.x - 64)];
       __syncthreads();
     }
   }
-  for (int s = threadIdx.x; s < lat.n_steps; s += blockDim.x)
-    s_steps[s * LYNX_STEP_STRIDE + LYNX_FLAGS_OFFSET] = (T)step_descriptor(lat, s, merge_pairs);
+  for (int s = threadIdx.x; s < lat.n_steps; s += blockDim.x) {
+    const bool ill = s_steps[s * LYNX_STEP_STRIDE + LYNX_FLAGS_OFFSET] != T(0);  // zero unless set in the loop above
+    s_steps[s * LYNX_STEP_STRIDE + LYNX_FLAGS_OFFSET] = (T)(step_descriptor(lat, s, merge_pairs) | (ill ? LYNX_DESC_ILL : 0));
+  }
   if (lat.n_steps > 0 && threadIdx.x == 0)
     s_steps[(lat.n_steps - 1) * LYNX_STEP_STRIDE + LYNX_ENERGY_OFFSET] = s_energy[lat.n_steps];
   __syncthreads();
@@ -1489,9 +1502,21 @@ __device__ __forceinline__ void apply_program_lane(const LatticeDev& lat, int S,
         for (int q = 0; q < 61; ++q) m[q] = uniform_value(tab[q]);
       }
       if constexpr (kPairs) {
+        if (merged && (desc & LYNX_DESC_ILL)) {  // uniform and rare: the rows form (cavity_entry_inverse)
+          float pre[14];
 #pragma unroll
-        for (int h = 0; h < UNROLL / 2; ++h)
-          apply_step_pair(m, skind, sflags, zp[h], merged ? kEntryInverse : kEntryOwn);
+          for (int q = 0; q < 14; ++q) pre[q] = uniform_value(g_steps[(sidx - 1) * LYNX_STEP_STRIDE + q]);
+#pragma unroll
+          for (int h = 0; h < UNROLL / 2; ++h) {
+            lynx_f32x2 s_in, d_in;
+            merged_pair_entry(pre, zp[h], s_in, d_in);
+            apply_step_pair(m, skind, sflags, zp[h], kEntryGiven, s_in, d_in);
+          }
+        } else {
+#pragma unroll
+          for (int h = 0; h < UNROLL / 2; ++h)
+            apply_step_pair(m, skind, sflags, zp[h], merged ? kEntryInverse : kEntryOwn);
+        }
       } else {
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) apply_step<T>(m, skind, sflags, z[u]);

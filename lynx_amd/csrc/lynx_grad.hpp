@@ -213,7 +213,17 @@ __device__ __forceinline__ void apply_unit(const T* g_steps, int slot, Z (&z)[7]
       T m[61];
 #pragma unroll
       for (int q = 0; q < 61; ++q) m[q] = g_steps[slot * LYNX_STEP_STRIDE + q];
-      apply_step_pair(m, st.kind, st.flags, z, kEntryInverse);
+      const int desc = (int)uniform_value(g_steps[slot * LYNX_STEP_STRIDE + LYNX_FLAGS_OFFSET]);
+      if (desc & LYNX_DESC_ILL) {  // uniform: the rows form, like the forward kernel
+        T pre[14];
+#pragma unroll
+        for (int q = 0; q < 14; ++q) pre[q] = uniform_value(g_steps[(slot - 1) * LYNX_STEP_STRIDE + q]);
+        lynx_f32x2 s_in, d_in;
+        merged_pair_entry(pre, z, s_in, d_in);
+        apply_step_pair(m, st.kind, st.flags, z, kEntryGiven, s_in, d_in);
+      } else {
+        apply_step_pair(m, st.kind, st.flags, z, kEntryInverse);
+      }
       return;
     }
   }

@@ -63,6 +63,10 @@ namespace lynx {
 // and cannot be declared __restrict__)
 #define LYNX_DESC_KIND_SHIFT 16
 #define LYNX_DESC_PAIR (1 << 20)
+// on the CAVITY's descriptor of a merged pair, per sample: the (s, delta) block of this sample's cavity map is too
+// close to singular for its inverse to recover what entered the cavity (cavity_entry_inverse); the kernels then take
+// the two from rows 4 and 5 of the run's map, parked in the run's slot, applied to the state that enters the pair
+#define LYNX_DESC_ILL (1 << 21)
 // last step, slot 63: the beam energy behind the last step (published by the streaming kernel)
 #define LYNX_ENERGY_OFFSET 63
 // cavity coefficient slots (lynx/accelerator/cavity.py:141-226)

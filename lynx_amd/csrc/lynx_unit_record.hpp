@@ -28,6 +28,7 @@ constexpr int kUnitPre = 8;
 constexpr int kUnitKick = 1;      // active cavity: non-linear kick behind the linear map
 constexpr int kUnitInverse = 2;   // ... driven by the entry inverse (merged pair) instead of the unit's own s, delta
 constexpr int kUnitPair = 4;      // merged [run, cavity] pair
+constexpr int kUnitRows = 8;      // ... whose kick is driven by rows 4, 5 of the run's map instead (LYNX_DESC_ILL)
 constexpr int kUnitClassShift = 4;  // bits 4-5: the class this sample's map was found to have (dense if the check failed)
 
 enum { kClassDense = 0, kClassU = 1, kClassD = 2 };
@@ -78,7 +79,9 @@ __device__ __forceinline__ void pack_unit_record(const R* rec, const R* pre /* m
       ok = false;
     }
   }
-  const int bits = (kick ? kUnitKick : 0) | ((kick && pair) ? kUnitInverse : 0) | (pair ? kUnitPair : 0) |
+  const bool rows = kick && pair && (desc & LYNX_DESC_ILL);
+  const int bits = (kick ? kUnitKick : 0) | ((kick && pair && !rows) ? kUnitInverse : 0) | (pair ? kUnitPair : 0) |
+                   (rows ? kUnitRows : 0) |
                    ((ok ? cls : (int)kClassDense) << kUnitClassShift);
   out[kUnitDesc] = __int_as_float(bits);
   out[kUnitSlot] = __int_as_float(slot);

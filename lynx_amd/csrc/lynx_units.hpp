@@ -213,6 +213,14 @@ __device__ __forceinline__ void units_program(int U, const float* __restrict__ s
       s_own[p] = z[p][4];
       d_own[p] = z[p][5];
     }
+    if (bits & kUnitRows) {  // uniform and rare: what enters the cavity from the run's rows 4 and 5 (LYNX_DESC_ILL)
+      const int slot = __builtin_amdgcn_readfirstlane(__float_as_int(kick.v[kUnitSlot]));
+      float pre[14];
+#pragma unroll
+      for (int q = 0; q < 14; ++q) pre[q] = uniform_value(g_steps[(slot - 1) * LYNX_STEP_STRIDE + q]);
+#pragma unroll
+      for (int p = 0; p < PAIRS; ++p) merged_pair_entry(pre, z[p], s_own[p], d_own[p]);
+    }
     if (cls == kClassU) {
 #pragma unroll
       for (int p = 0; p < PAIRS; ++p) unit_linear<kClassU>(map, nullptr, z[p]);

@@ -97,3 +97,16 @@ def assert_parameter_beam(out, ref, tol, what=""):
     scale = np.maximum(sig[..., :, None] * sig[..., None, :], np.abs(rcov[..., :6, :6])) + 1e-300
     dcov = np.abs(cov[..., :6, :6] - rcov[..., :6, :6]) / scale
     assert np.nanmax(dcov) <= tol, (what, "cov", float(np.nanmax(dcov)), np.unravel_index(np.nanargmax(dcov), dcov.shape))
+
+
+def singular_entry_voltage(energy, phase, length, frequency, lo, hi):
+    """The voltage in [lo, hi] at which the (s, delta) block of the reference's cavity map (cavity.py:311-323) is singular."""
+    def det(v):
+        a = lambda x: np.array([x], dtype=np.float64)  # noqa: E731
+        m = o.element_transfer_map(o.Cavity(a(length), voltage=a(v), phase=a(phase), frequency=a(frequency)), a(energy), np.float64)[0]
+        return m[4, 4] * m[5, 5] - m[4, 5] * m[5, 4]
+    assert det(lo) * det(hi) < 0
+    for _ in range(80):
+        mid = 0.5 * (lo + hi)
+        lo, hi = (mid, hi) if det(mid) * det(lo) > 0 else (lo, mid)
+    return 0.5 * (lo + hi)

@@ -9,7 +9,7 @@ import pytest
 
 from oracle import lynx_oracle as o
 
-from .helpers import make_lattice
+from .helpers import make_lattice, singular_entry_voltage
 
 pytestmark = pytest.mark.gpu
 
@@ -102,19 +102,28 @@ def test_gradients_match_finite_differences_fp64(lx):
     assert checked > 50
 
 
-@pytest.mark.parametrize("B,N", [(2, 3000), (300, 256)], ids=["workgroup-build", "lanes-build"])
-def test_merged_pairs_reverse_pass_fp32(lx, monkeypatch, B, N):
+@pytest.mark.parametrize("B,N,ill", [(2, 3000, False), (300, 256, False), (2, 3000, True), (300, 256, True)],
+                         ids=["workgroup-build", "lanes-build", "workgroup-build-ill", "lanes-build-ill"])
+def test_merged_pairs_reverse_pass_fp32(lx, monkeypatch, B, N, ill):
     """
     float32 reverse pass over [run, cavity] pairs in the merged form of the forward kernel (one 7x7 application
     per pair, kick driven by two entry rows; k_build_bwd takes M_bar apart into T_run_bar and T_cav_bar):
     every parameter gradient against (a) the step-by-step float32 reverse pass (LYNX_BWD_MERGE=0) and (b) the
-    float64 reverse pass, which the test above pins to finite differences of the oracle.
+    float64 reverse pass, which the test above pins to finite differences of the oracle.  `ill`: a 1 MeV beam whose
+    first cavity (30 degrees off crest) sits next to the singular point of its map's (s, delta) block (LYNX_DESC_ILL: the forward sweep of
+    the reverse pass then drives the kick from the run's rows, like the forward kernels).
     """
     rng = np.random.default_rng(42)
     desc = _desc(B, rng)
     P = o.gaussian_particles((B,), N, seed=9, dtype=np.float64, sigma=[1e-3, 1e-4, 1e-3, 1e-4, 1e-3, 1e-3],
                              mu=[1e-3, -1e-4, 5e-4, 2e-4, 1e-4, 1e-3])
     energy = rng.uniform(6e6, 8e6, B)
+    if ill:
+        energy = np.full(B, 1e6)
+        kind, params = desc[3]
+        desc[3] = (kind, dict(params, length=np.full(B, 1.0), phase=np.full(B, -30.0),
+                              voltage=singular_entry_voltage(1e6, -30.0, 1.0, 1.3e9, 4e5, 6.5e5) * (1 + rng.uniform(1e-4, 1e-2, B))))
+        desc[6] = (desc[6][0], dict(desc[6][1], voltage=rng.uniform(2e5, 5e5, B)))
     w_mu = rng.normal(size=(B, 6))
     w_cov = rng.normal(size=(B, 6, 6)) * 1e3
 

@@ -12,7 +12,7 @@ import pytest
 
 from oracle import lynx_oracle as o
 
-from .helpers import assert_parameter_beam, make_lattice, map_err, rel_err
+from .helpers import assert_parameter_beam, make_lattice, map_err, rel_err, singular_entry_voltage
 
 pytestmark = pytest.mark.gpu
 
@@ -917,6 +917,42 @@ def test_two_kernel_path_is_bit_identical_to_fused(lx):
         # by one ulp (6e-8 at cos ~ 1), times the kick's amplitude V beta0 / (E_out beta1) < 1
         assert np.max(np.abs(got[..., k] - seq[..., k])) < 5e-6 * scale + (1.2e-7 if k == 5 else 0.0), k
         assert np.max(np.abs(got[..., k] - ref["particles"][..., k])) < 1e-4 * scale, k  # the oracle's cos is NumPy's
+
+
+@pytest.mark.parametrize("units", ["2", "0"])
+def test_merged_pairs_with_an_ill_conditioned_cavity_block_take_the_rows_form(lx, monkeypatch, units):
+    """
+    The merged [run, cavity] form recovers the s and delta that enter the cavity from components 4, 5 of the product
+    map's output with the inverse of the cavity's (s, delta) block.  At 1 MeV and 30 degrees off crest that block of the
+    reference's map (cavity.py:311-323) is singular at V = 0.5247 MV, and next to that voltage the inverse amplifies
+    the float32 rounding of M z by (|c44 c55| + |c45 c54|) / |det|: 5e4, 5e3, 5e2, 25 for samples 0-3 here (with the
+    guard switched off sample 0 is 4e-4 of the delta scale away from the step-by-step form).  The build marks such
+    samples (LYNX_DESC_ILL, per sample) and the kernels take the two from the run's rows instead -- the results must stay
+    as close to the step-by-step form and to the oracle as everywhere else, in both step loops (units / dense).
+    Sample 4 is well-conditioned and keeps the inverse form.
+    """
+    B, N, E = 5, 200_000, 1e6
+    v0 = singular_entry_voltage(E, -30.0, 1.0, 1.3e9, 4e5, 6.5e5)
+    volts = np.array([v0 * (1 + 1e-4), v0 * (1 - 1e-3), v0 * (1 + 1e-2), v0 * 1.2, 4e5])
+    phases = np.array([-30.0, -30.0, -30.0, -30.0, 0.0])
+    f = lambda v: np.full(B, v)  # noqa: E731
+    desc = [("drift", dict(length=f(0.5))), ("quadrupole", dict(length=f(0.2), k1=f(1.5))),
+            ("cavity", dict(length=f(1.0), voltage=volts, phase=phases, frequency=f(1.3e9))),
+            ("drift", dict(length=f(0.4))),
+            ("cavity", dict(length=f(1.0), voltage=f(3e5), phase=f(0.0), frequency=f(1.3e9))), ("drift", dict(length=f(0.1)))]
+    monkeypatch.setenv("LYNX_TRACK_UNITS", units)
+    merged, ref = _particle_case(lx, desc, np.float32, (B,), N, seed=12, energy=E)
+    monkeypatch.setattr(lx.config, "merge_steps", False)
+    stepwise, _ = _particle_case(lx, desc, np.float32, (B,), N, seed=12, energy=E)
+    got, seq = np.asarray(merged.particles), np.asarray(stepwise.particles)
+    assert np.all(np.isfinite(got))
+    assert not np.array_equal(got, seq)  # the merged form did run
+    for b in range(B):
+        for k in range(6):
+            scale = np.max(np.abs(ref["particles"][b, :, k]))
+            assert np.max(np.abs(got[b, :, k] - seq[b, :, k])) < 2e-5 * scale, (b, k)
+            assert np.max(np.abs(got[b, :, k] - ref["particles"][b, :, k])) < 1e-4 * scale, (b, k)
+    assert np.array_equal(merged.energy, stepwise.energy)
 
 
 def test_relational_invariants_from_the_reference_suite(lx):
