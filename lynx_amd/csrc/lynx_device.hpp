@@ -542,11 +542,37 @@ __global__ __launch_bounds__(64, 4) void k_build_pieces(LatticeDev lat, const Bu
   }
 }
 
+// dst = X[b] . X[a] for one sample (the lane's)
+__device__ __forceinline__ void pair_product(const PairTask t, int64_t b, int64_t Bp, double* products);
+
 __global__ __launch_bounds__(64) void k_pair_products(const PairTask* __restrict__ tasks, int64_t B, int64_t Bp,
                                                       double* products) {
   const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (b >= B) return;
-  const PairTask t = tasks[blockIdx.y];
+  pair_product(tasks[blockIdx.y], b, Bp, products);
+}
+
+// Every level of the tree in ONE launch: a workgroup of 4 waves per 64 samples, wave w takes tasks w, w + 4, ... of a
+// level, a barrier between levels (the products of a level are read by this workgroup only).  For lattices whose
+// levels are narrow (<= kPairLevelsMaxTasks tasks: BASELINE config 4 has 8, 4, 2, 1) the chain of launches was what
+// a build took: ~20 us per level underneath a streaming kernel, against 2-3 us for the product itself.
+constexpr int kPairLevelsMax = 8, kPairLevelsMaxTasks = 16;
+struct PairLevels {
+  int32_t n;
+  int32_t first[kPairLevelsMax], count[kPairLevelsMax];
+};
+__global__ __launch_bounds__(256) void k_pair_levels(PairLevels lv, const PairTask* __restrict__ tasks, int64_t B, int64_t Bp,
+                                                     double* products) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t b = (int64_t)blockIdx.x * 64 + lane;
+  for (int l = 0; l < lv.n; ++l) {
+    if (b < B)
+      for (int t = wave; t < lv.count[l]; t += 4) pair_product(tasks[lv.first[l] + t], b, Bp, products);
+    __syncthreads();  // workgroup scope: this level's products are in memory before the next level reads them
+  }
+}
+
+__device__ __forceinline__ void pair_product(const PairTask t, int64_t b, int64_t Bp, double* products) {
   const double* xa = products + (int64_t)t.a * 49 * Bp + b;
   const double* xb = products + (int64_t)t.b * 49 * Bp + b;
   double* xd = products + (int64_t)t.dst * 49 * Bp + b;

@@ -874,10 +874,26 @@ static int launch_build_lanes(lynx_ctx* ctx, lynx_lattice* lat, hipStream_t stre
   hipLaunchKernelGGL(k_build_pieces<T>, dim3((unsigned)groups, (unsigned)lat->n_pieces), dim3(64), build_pieces_lds<T>(), stream, lv,
                      lat->d_pieces, (const T*)d_energy_in, Bp, (double*)ctx->scratch_products, (T*)ctx->scratch_coefs);
   HIP_TRY(ctx, hipGetLastError());
-  for (const auto& level : lat->levels) {
-    hipLaunchKernelGGL(k_pair_products, dim3((unsigned)groups, (unsigned)level.second), dim3(64), 0, stream,
-                       lat->d_tasks + level.first, lat->batch, Bp, (double*)ctx->scratch_products);
+  // narrow trees (BASELINE config 4: 8, 4, 2, 1 tasks per level) in one launch: underneath a streaming kernel every
+  // launch of the chain costs ~20 us, the product itself 3-6 (config 4: 0.995 -> 0.985 ms/step, same box)
+  bool narrow = !lat->levels.empty() && (int)lat->levels.size() <= kPairLevelsMax && env_int("LYNX_PAIR_LEVELS_FUSED", 1) != 0;
+  for (const auto& level : lat->levels) narrow = narrow && level.second <= kPairLevelsMaxTasks;
+  if (narrow) {
+    PairLevels lv{};
+    lv.n = (int32_t)lat->levels.size();
+    for (int l = 0; l < lv.n; ++l) {
+      lv.first[l] = lat->levels[l].first;
+      lv.count[l] = lat->levels[l].second;
+    }
+    hipLaunchKernelGGL(k_pair_levels, dim3((unsigned)groups), dim3(256), 0, stream, lv, lat->d_tasks, lat->batch, Bp,
+                       (double*)ctx->scratch_products);
     HIP_TRY(ctx, hipGetLastError());
+  } else {
+    for (const auto& level : lat->levels) {
+      hipLaunchKernelGGL(k_pair_products, dim3((unsigned)groups, (unsigned)level.second), dim3(64), 0, stream,
+                         lat->d_tasks + level.first, lat->batch, Bp, (double*)ctx->scratch_products);
+      HIP_TRY(ctx, hipGetLastError());
+    }
   }
   hipLaunchKernelGGL(k_emit_steps<T>, dim3((unsigned)groups, (unsigned)lat->n_steps), dim3(64), emit_steps_lds<T>(), stream, lv,
                      lat->d_step_slot, (const T*)d_energy_in, Bp, (const double*)ctx->scratch_products,
