@@ -775,7 +775,9 @@ static void build_shape(lynx_ctx* ctx, const lynx_lattice* lat, bool underneath,
   const int64_t cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
   const bool wide = lat->batch * 2 <= cus && !(underneath && env_int("LYNX_BUILD_NARROW_UNDERNEATH", 1));
   *threads = wide ? 1024 : 256;
-  int limit = wide ? 128 : (sizeof(T) == 4 ? 32 : 64);
+  // (float32, at most one workgroup per CU: 64 again -- half the rounds; the 128-sample shard of BASELINE config 4
+  // underneath its streaming kernel: 0.1573 -> 0.1543 ms/step, medians of four, same box)
+  int limit = wide ? 128 : ((sizeof(T) == 4 && lat->batch > cus) ? 32 : 64);
   limit = env_int("LYNX_BUILD_CHUNK", limit);
   if (limit > *threads) limit = *threads;
   if (limit < 2) limit = 2;
