@@ -937,12 +937,16 @@ __device__ __forceinline__ lynx_f32x2 pk_fma(lynx_f32x2 a, float b, lynx_f32x2 c
 //   kEntryGiven   s_entry, d_entry (merged [run, cavity] pair, reverse pass: rows 4, 5 of T_run applied to z),
 //   kEntryInverse merged pair, forward pass: the inverse of T_cav's (s, delta) block (LYNX_ENTRY_OFFSET) applied
 //                 to components 4, 5 of M z, M = T_cav . T_run
-enum { kEntryOwn = 0, kEntryGiven = 1, kEntryInverse = 2 };
+//   kEntryStash   merged pair whose block is ill-conditioned (LYNX_DESC_ILL), forward pass: s_entry, d_entry as in
+//                 kEntryGiven, parked in this lane's four floats of LDS while the 7x7 is applied (carrying them in
+//                 registers cost the step loop 10 of them and the multi-step kernels spills)
+enum { kEntryOwn = 0, kEntryGiven = 1, kEntryInverse = 2, kEntryStash = 3 };
 
 __device__ __forceinline__ void apply_step_pair(const float* M /*49 + coef (+ 4)*/, int step_kind, int step_flags,
                                                 lynx_f32x2 (&z)[7], int entry = kEntryOwn,
                                                 lynx_f32x2 s_entry = lynx_f32x2{0.f, 0.f},
-                                                lynx_f32x2 d_entry = lynx_f32x2{0.f, 0.f}) {
+                                                lynx_f32x2 d_entry = lynx_f32x2{0.f, 0.f},
+                                                const float* stash = nullptr) {
   lynx_f32x2 o[7];
 #pragma unroll
   for (int i = 0; i < 7; ++i) {
@@ -961,6 +965,10 @@ __device__ __forceinline__ void apply_step_pair(const float* M /*49 + coef (+ 4)
       const float* ci = M + LYNX_ENTRY_OFFSET;
       s_in = pk_fma(o[5], ci[1], o[4] * ci[0]);
       d_in = pk_fma(o[5], ci[3], o[4] * ci[2]);
+    } else if (entry == kEntryStash) {
+      const lynx_f32x4 v = *reinterpret_cast<const lynx_f32x4*>(stash);
+      s_in = lynx_f32x2{v.x, v.y};
+      d_in = lynx_f32x2{v.z, v.w};
     }
     const lynx_f32x2 arg = -1.0f * s_in * coef[LYNX_C_BK] + coef[LYNX_C_PHI];
     const lynx_f32x2 ca = phase_cos(arg);
@@ -1077,6 +1085,7 @@ struct TrackArgs {
   // rounds of resident workgroups was measured and lost (C4 0.995 -> 1.07 ms, the 128-sample shard 0.155 -> 0.162):
   // DESIGN.md section 5, dead ends.
   int32_t n_tiles;
+  int32_t stash_offset;  // merged tables: byte offset in LDS of the lanes' four-float stashes (kEntryStash), 16-byte aligned
 };
 
 __device__ __forceinline__ void announce_tail(const TrackArgs& a) {
@@ -1466,7 +1475,8 @@ template <typename T, int UNROLL, bool SCALAR_TABLE>
 __device__ __forceinline__ void apply_program_lane(const LatticeDev& lat, int S, const T* g_steps, const T* s_steps,
                                                    T (&z)[UNROLL][7],
                                                    double* s_obs = nullptr /* this lane's [observer][x, y] sums, pitch 256 */,
-                                                   const bool (*live)[UNROLL] = nullptr) {
+                                                   const bool (*live)[UNROLL] = nullptr,
+                                                   float* stash = nullptr /* this lane's 4 floats of LDS (kEntryStash) */) {
   constexpr bool kMapInRegs = sizeof(T) == 4;
   constexpr bool kPairs = kMapInRegs && UNROLL % 2 == 0;
   lynx_f32x2 zp[kPairs ? UNROLL / 2 : 1][7];
@@ -1508,7 +1518,9 @@ __device__ __forceinline__ void apply_program_lane(const LatticeDev& lat, int S,
       }
       ++n_obs;
     }
-    if constexpr (kPairs && SCALAR_TABLE) {
+    // (two particles per lane only: the plan's choice for multi-step programs, and the only form the host asks merged
+    // tables for -- the four-per-lane kernels of single-map programs, BASELINE config 4's among them, stay free of it)
+    if constexpr (kPairs && SCALAR_TABLE && UNROLL == 2) {
       if (desc & LYNX_DESC_PAIR) {  // uniform: this run is applied together with the cavity behind it
         merged = true;
         ++sidx;
@@ -1528,20 +1540,23 @@ __device__ __forceinline__ void apply_program_lane(const LatticeDev& lat, int S,
         for (int q = 0; q < 61; ++q) m[q] = uniform_value(tab[q]);
       }
       if constexpr (kPairs) {
-        if (merged && (desc & LYNX_DESC_ILL)) {  // uniform and rare: the rows form (cavity_entry_inverse)
-          float pre[14];
+        // an ill-conditioned pair (uniform and rare: cavity_entry_inverse): what enters the cavity comes from the run's
+        // rows 4 and 5, worked out here and parked in LDS while the 7x7 is applied
+        const bool rows_form = __builtin_expect(merged && (desc & LYNX_DESC_ILL), 0);
+        const int entry = !merged ? kEntryOwn : (rows_form ? kEntryStash : kEntryInverse);
 #pragma unroll
-          for (int q = 0; q < 14; ++q) pre[q] = uniform_value(g_steps[(sidx - 1) * LYNX_STEP_STRIDE + q]);
+        for (int h = 0; h < UNROLL / 2; ++h) {
+          if (rows_form) {
+            lynx_f32x2 s_in = zp[h][0] * uniform_value(g_steps[(sidx - 1) * LYNX_STEP_STRIDE]);
+            lynx_f32x2 d_in = zp[h][0] * uniform_value(g_steps[(sidx - 1) * LYNX_STEP_STRIDE + 7]);
 #pragma unroll
-          for (int h = 0; h < UNROLL / 2; ++h) {
-            lynx_f32x2 s_in, d_in;
-            merged_pair_entry(pre, zp[h], s_in, d_in);
-            apply_step_pair(m, skind, sflags, zp[h], kEntryGiven, s_in, d_in);
+            for (int j = 1; j < 7; ++j) {
+              s_in = pk_fma(zp[h][j], uniform_value(g_steps[(sidx - 1) * LYNX_STEP_STRIDE + j]), s_in);
+              d_in = pk_fma(zp[h][j], uniform_value(g_steps[(sidx - 1) * LYNX_STEP_STRIDE + 7 + j]), d_in);
+            }
+            *reinterpret_cast<lynx_f32x4*>(stash) = lynx_f32x4{s_in.x, s_in.y, d_in.x, d_in.y};
           }
-        } else {
-#pragma unroll
-          for (int h = 0; h < UNROLL / 2; ++h)
-            apply_step_pair(m, skind, sflags, zp[h], merged ? kEntryInverse : kEntryOwn);
+          apply_step_pair(m, skind, sflags, zp[h], entry, lynx_f32x2{0.f, 0.f}, lynx_f32x2{0.f, 0.f}, stash);
         }
       } else {
 #pragma unroll
@@ -1584,6 +1599,7 @@ __global__ __launch_bounds__(kTrackThreads, (track_waves_per_simd<T, MOM, FULL, 
   announce_tail(a);
   unsigned char* s_scratch = smem_raw;                                 // build scratch / wave tiles / reduction
   T* s_steps = reinterpret_cast<T*>(smem_raw + a.lds_scratch_bytes);    // [S][64]
+  float* stash = reinterpret_cast<float*>(smem_raw + a.stash_offset) + threadIdx.x * 4;  // used with merged tables only
   T* s_energy = s_steps + (size_t)lat.n_steps * LYNX_STEP_STRIDE;       // [S+1]
   // observers (active BPMs): every lane's float64 sums of x and y at each of them, [2 * n_observers][256]
   double* s_obs = reinterpret_cast<double*>(smem_raw + ((a.lds_scratch_bytes + ((size_t)lat.n_steps * (LYNX_STEP_STRIDE + 1) + 1) * sizeof(T) + 7) / 8 * 8)) + threadIdx.x;
@@ -1761,7 +1777,7 @@ __global__ __launch_bounds__(kTrackThreads, (track_waves_per_simd<T, MOM, FULL, 
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) alive[u] = i0 + (int64_t)u * kLaneStep < end;
         apply_program_lane<T, UNROLL, kScalarTable>(lat, S, g_steps, s_steps, z,
-                                                    a.n_observers ? s_obs : nullptr, &alive);
+                                                    a.n_observers ? s_obs : nullptr, &alive, stash);
       }
 #pragma unroll
       for (int u = 0; u < UNROLL; ++u) {

@@ -984,6 +984,7 @@ static TrackPlan plan_track(lynx_ctx* ctx, const lynx_lattice* lat, int64_t B, i
   p.a.tail_seq = 0;
   p.a.tail_wg = 0;
   p.a.n_tiles = 0;
+  p.a.stash_offset = 0;
   // wave tiles: with non-temporal full-width stores +7 % on single-map float32 programs (BASELINE config 4:
   // 5.4 -> 5.8 TB/s) and +10 % (+7 % of that from the stores) on float64 (config 3 at 8 M particles); slower on
   // multi-step float32 programs, which want two particles per lane, not four
@@ -1238,8 +1239,13 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
     for (int32_t s = 1; s < S; ++s)
       has_pair |= lat->h_steps[s].kind == LYNX_STEP_CAVITY && lat->h_steps[s - 1].kind == LYNX_STEP_RUN &&
                   !(lat->h_steps[s - 1].flags & LYNX_STEP_FLAG_OBSERVE);
-    p.a.merged_pairs = has_pair && sizeof(T) == 4 && p.unroll % 2 == 0 &&
+    p.a.merged_pairs = has_pair && sizeof(T) == 4 && p.unroll == 2 &&
                        !(flags & LYNX_TRACK_SEQUENTIAL_STEPS) && env_int("LYNX_MERGE_STEPS", 1);
+    if (p.a.merged_pairs) {  // four floats of LDS per lane for pairs that take the rows form (kEntryStash)
+      p.lds = (p.lds + 15) / 16 * 16;
+      p.a.stash_offset = (int32_t)p.lds;
+      p.lds += (size_t)kTrackThreads * 4 * sizeof(float);
+    }
     // The second stream pays once the streaming kernel is long enough to hide a build under; below half a
     // million particles per call the extra event traffic costs more host time than the overlap returns
     // (BASELINE config 2: 31 -> 46 us per call with it).

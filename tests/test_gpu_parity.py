@@ -834,6 +834,8 @@ def test_fused_covariance_switch(lx):
 VARIANTS = [
     {"LYNX_XPOSE": "1"}, {"LYNX_XPOSE": "0"}, {"LYNX_ASYNC_BUILD": "1"}, {"LYNX_ASYNC_BUILD": "0"},
     {"LYNX_LANES_BUILD_MIN_BATCH": "1"}, {"LYNX_LANES_BUILD_MIN_BATCH": "1", "LYNX_PIECE": "3"},
+    {"LYNX_LANES_BUILD_MIN_BATCH": "1", "LYNX_PIECE": "1"},  # two levels of pair products, in one launch (k_pair_levels)
+    {"LYNX_LANES_BUILD_MIN_BATCH": "1", "LYNX_PIECE": "1", "LYNX_PAIR_LEVELS_FUSED": "0"},  # ... one launch per level
     {"LYNX_UNROLL": "1"}, {"LYNX_UNROLL": "2"}, {"LYNX_UNROLL": "4"}, {"LYNX_MOM": "2"}, {"LYNX_MOM": "3"},
     {"LYNX_FUSE_MAX_CHUNKS": "64", "LYNX_UNROLL": "1"}, {"LYNX_MIN_TILES_PER_WG": "1"}, {"LYNX_INTERLEAVE": "1"},
     {"LYNX_BUILD_CHUNK": "5"}, {"LYNX_MERGE_STEPS": "0"},
@@ -886,6 +888,9 @@ def test_every_kernel_variant_gives_the_default_answer(lx, dtype, monkeypatch):
         assert np.array_equal(np.isnan(m), np.isnan(m0)), env
         assert np.allclose(m[have], m0[have], rtol=TOL_MOM[dtype] * 0.1, atol=1e-30), env
         assert np.allclose(r, r0, rtol=TOL_MOM[dtype], atol=1e-12), env
+    # the pair tree in one launch or in one launch per level: the same products in the same order
+    tree = [p for env, p, *_ in results if env.get("LYNX_PIECE") == "1"]
+    assert len(tree) == 2 and np.array_equal(tree[0], tree[1])
 
 
 def test_two_kernel_path_is_bit_identical_to_fused(lx):
