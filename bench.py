@@ -489,6 +489,28 @@ def main():
     for _ in range(args.warmup):
         last = step()
     rt.sync()
+    # The practical ceiling on this box -- a plain 16 B/lane device copy of one pass' bytes, five launch shapes -- is
+    # measured HERE, between the warm-up and the timed region, on every rank, for about 0.1 s: after an idle stretch
+    # (the first call's 13 ms of set-up on the host is one) an MI355X needs 20-30 ms of memory-bound work before its
+    # kernels run at the speed a long job sees (BASELINE config 4 from a cold start: 1.00, 1.00, 1.09, 1.17, 1.16, ...
+    # 0.95 ms per launch after 20 launches, with the same curve when nothing runs next to the kernel:
+    # profiles/r03_first_launches.txt), and five warm-up steps end long before that.  LYNX_BENCH_CALIBRATE_FIRST=0
+    # puts the calibration behind the timed region again (rank 0 of a one-GPU run only).
+    copy_gbs = None
+    calibrate_first = os.environ.get("LYNX_BENCH_CALIBRATE_FIRST", "1") != "0"
+
+    def calibrate():
+        nbytes = min(batch * particles * 7 * np.dtype(dtype).itemsize, 4 << 30)
+        est_s = 2 * nbytes / 5e12  # one copy launch
+        repeats = int(min(200, max(10, np.ceil(0.1 / (5 * est_s))))) if calibrate_first else 10
+        try:
+            return rt.copy_bandwidth(nbytes, repeats=repeats)
+        except Exception as exc:  # pragma: no cover
+            print(f"copy calibration failed: {exc}", file=sys.stderr)
+            return None
+
+    if calibrate_first:
+        copy_gbs = calibrate()
     rdzv.barrier()
     rt.sync()
     if not args.no_kernel_timing:
@@ -528,13 +550,8 @@ def main():
             assert whole.shape == (global_batch, 36) and np.all(whole[:, 35] == total_particles), "bench: bad gathered records"
             assert np.all(np.isfinite(whole[~np.isnan(whole)])), "bench: bad gathered records"
 
-    copy_gbs = None
-    if rank == 0 and world == 1:
-        # practical ceiling on this box: plain 16 B/lane device copy of one pass' bytes, three launch shapes
-        try:
-            copy_gbs = rt.copy_bandwidth(min(batch * particles * 7 * np.dtype(dtype).itemsize, 4 << 30))
-        except Exception as exc:  # pragma: no cover
-            print(f"copy calibration failed: {exc}", file=sys.stderr)
+    if not calibrate_first and rank == 0 and world == 1:
+        copy_gbs = calibrate()
 
     # HBM traffic of the streaming kernel as measured with rocprofv3 PMC counters (separate
     # FETCH_SIZE / WRITE_SIZE passes of this same command; profiles/*_pmc_traffic.json).  It
@@ -590,6 +607,7 @@ def main():
             # the practical ceiling: best plain-copy shape measured in this process (MI355X_MICROARCH.md: ~6.3 TB/s)
             "hbm_copy_kernel_gbs": max(copy_gbs.values()) if copy_gbs else None,
             "hbm_copy_kernel_shapes": copy_gbs,
+            "hbm_copy_kernel_when": "between warm-up and timed region" if calibrate_first else "after the timed region",
             "device": rt.info(),
         }
         if baseline is not None:

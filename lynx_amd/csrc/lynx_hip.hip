@@ -24,6 +24,8 @@
 
 using namespace lynx;
 
+static int env_int(const char* name, int dflt);
+
 struct lynx_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -497,9 +499,11 @@ int lynx_profile_end(lynx_ctx* ctx, double* total_ms, int64_t* launches) {
   // the per-launch stop events stood in for the step-table slots' "streamed" events and go away here
   for (bool& v : ctx->streamed_valid) v = false;
   double total = 0.0;
+  const bool dump = env_int("LYNX_PROFILE_DUMP", 0) != 0;  // every launch's duration, in launch order (diagnostics)
   for (auto& pr : ctx->prof_events) {
     float ms = 0.f;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, pr.first, pr.second));
+    if (dump) fprintf(stderr, "lynx_profile_end: launch %zu %.4f ms\n", (size_t)(&pr - ctx->prof_events.data()), ms);
     total += ms;
     (void)hipEventDestroy(pr.first);
     (void)hipEventDestroy(pr.second);
