@@ -1080,11 +1080,6 @@ struct TrackArgs {
   uint32_t tail_seq;
   int32_t tail_wg;
   unsigned int* tail_flag;
-  // > 0 (k_track_units only; the host leaves it 0): workgroup `chunk` owns tiles [chunk n_tiles / chunks,
-  // (chunk + 1) n_tiles / chunks) of its sample.  Dealing a sample's tiles out so that the grid is a whole number of
-  // rounds of resident workgroups was measured and lost (C4 0.995 -> 1.07 ms, the 128-sample shard 0.155 -> 0.162):
-  // DESIGN.md section 5, dead ends.
-  int32_t n_tiles;
   int32_t stash_offset;  // merged tables: byte offset in LDS of the lanes' four-float stashes (kEntryStash), 16-byte aligned
 };
 

@@ -987,7 +987,6 @@ static TrackPlan plan_track(lynx_ctx* ctx, const lynx_lattice* lat, int64_t B, i
   p.a.tail_flag = nullptr;
   p.a.tail_seq = 0;
   p.a.tail_wg = 0;
-  p.a.n_tiles = 0;
   p.a.stash_offset = 0;
   // wave tiles: with non-temporal full-width stores +7 % on single-map float32 programs (BASELINE config 4:
   // 5.4 -> 5.8 TB/s) and +10 % (+7 % of that from the stores) on float64 (config 3 at 8 M particles); slower on

@@ -262,12 +262,10 @@ __global__ __launch_bounds__(kTrackThreads, (units_waves_per_simd<MOM, FULL, PAI
   const float* g_units = units_in + b * (int64_t)U * kUnitStride;
   const float* g_extras = extras_in + b * (int64_t)U * kUnitExtraStride;
 
-  int64_t tile0 = (int64_t)chunk * a.tiles_per_wg;
-  int my_tiles = a.tiles_per_wg;
-  if (a.n_tiles > 0) {  // balanced partition (TrackArgs)
-    tile0 = (int64_t)chunk * a.n_tiles / a.chunks;
-    my_tiles = (int)(((int64_t)(chunk + 1) * a.n_tiles) / a.chunks - tile0);
-  }
+  // (dealing a sample's tiles out so that the grid is a whole number of rounds of resident workgroups was measured and
+  // lost: C4 0.995 -> 1.07 ms, the 128-sample shard 0.155 -> 0.162)
+  const int64_t tile0 = (int64_t)chunk * a.tiles_per_wg;
+  const int my_tiles = a.tiles_per_wg;
   // the first tile's loads go out before anything else
   T zn[UNROLL][7];
   {
