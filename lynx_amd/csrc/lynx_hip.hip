@@ -1357,7 +1357,10 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
   if (side && !p.done) p.done = ring->track_done;  // the side stream's reduction starts behind it
   if (use_units) rc = launch_units(ctx, p, n_units, S, d_p_in, d_p_out, d_energy_out, d_steps, d_units, d_extras, d_partials, moments);
   else rc = launch_direct<T>(ctx, p, lv, d_energy_in, d_p_in, d_p_out, d_energy_out, d_steps, d_partials, d_obs, moments);
-  if (rc) return rc;
+  if (rc) {
+    if (tail) --ctx->tail_seq;  // nothing will announce this number: a later build must not wait for it
+    return rc;
+  }
   if (p.a.n_observers) {
     hipLaunchKernelGGL(k_reduce_observers, dim3((unsigned)B), dim3(64), 0, ctx->stream, d_obs, p.a.chunks,
                        p.a.n_observers, (double)N, d_observations);
