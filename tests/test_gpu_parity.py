@@ -567,6 +567,28 @@ def _same_bits(a, b):
         np.where(np.isnan(a), 0, a) + 0.0, np.where(np.isnan(b), 0, b) + 0.0)
 
 
+def test_lanes_build_with_a_wide_pair_tree_agrees_with_the_workgroup_build(lx, monkeypatch):
+    """
+    A run of 300 elements is 38 pieces of 8: the first level of the pair tree has 19 products -- more than the
+    one-launch form of the tree takes (k_pair_levels: at most 16 per level), so the levels are launched one by one
+    (k_pair_products).  Same table as the workgroup build to rounding, and the oracle's particles.
+    """
+    B, n = 256, 600
+    rng = np.random.default_rng(31)
+    f = lambda v: np.full(B, v)  # noqa: E731
+    desc = []
+    for k in range(150):
+        desc += [("drift", dict(length=f(0.05))), ("quadrupole", dict(length=f(0.02), k1=rng.uniform(-2, 2, B)))]
+    results = {}
+    for name, min_batch in (("workgroup", "1000000"), ("lanes", "1")):
+        monkeypatch.setenv("LYNX_LANES_BUILD_MIN_BATCH", min_batch)
+        out, ref = _particle_case(lx, desc, np.float32, (B,), n, seed=3, energy=1e8)
+        results[name] = np.asarray(out.particles)
+        _assert_particles(out, ref, np.float32)
+    for c in range(7):
+        assert rel_err(results["lanes"][..., c], results["workgroup"][..., c]) < 2e-6, c
+
+
 @pytest.mark.parametrize("case", ["uncoupled", "dispersive", "coupled", "nan_map", "sequential"])
 def test_structured_units_equal_the_dense_step_loop_bit_for_bit(lx, monkeypatch, case):
     """
