@@ -702,6 +702,12 @@ __global__ __launch_bounds__(64) void k_reduce_tbar(const T* __restrict__ partia
   tbar[(b * S + s) * (int64_t)kGradStride + lane] = (T)v;
 }
 
+// LDS of k_build_bwd in front of the (optional) maps: energies and their cotangents [S+1] each, the per-element
+// energy terms [E], and for each of the four waves the running cotangent A and a temporary [49] each
+template <typename T> inline size_t build_bwd_lds_fixed(int S, int E) {
+  return ((size_t)2 * (S + 1) + E + 4 * 98) * sizeof(T);
+}
+
 // ---------------------------------------------------------------------------------------
 // k_build_bwd: one 256-thread workgroup per sample.
 //   scratch (HBM, per sample): maps [E][49] and prefix/M_bar [E+1][49]
@@ -717,8 +723,8 @@ __global__ __launch_bounds__(256) void k_build_bwd(LatticeDev lat, const T* __re
   T* s_energy = reinterpret_cast<T*>(smem_raw);  // [S+1]
   T* s_ebar = s_energy + (S + 1);                // [S+1] energy cotangent per step
   T* s_econ = s_ebar + (S + 1);                  // [E]   per-element contribution to its step's energy cotangent
-  T* s_a = s_econ + E;                           // [49]  running cotangent A
-  T* s_t = s_a + 49;                             // [49]  temp
+  T* s_a = s_econ + E;                           // [4][98] per wave: running cotangent A [49], temp [49]
+  T* s_maps = s_a + 4 * 98;                      // element maps and prefix products, when they fit (maps_in_lds)
 
   const int tid = threadIdx.x;
   const int64_t b = blockIdx.x;
@@ -727,7 +733,7 @@ __global__ __launch_bounds__(256) void k_build_bwd(LatticeDev lat, const T* __re
   // product each, a barrier in between): kept in LDS when they fit (maps_in_lds; BASELINE config 5: 16 KB),
   // every hop is an LDS round trip instead of one to L2 -- the kernel was latency-bound on exactly that
   // (0.88 -> 0.3 ms).  Long lattices (a 1051-element one needs 412 KB) keep them in the HBM scratch.
-  T* g_maps = maps_in_lds ? s_t + 49 : scratch + b * (int64_t)(2 * E + S + 1) * 49;  // M_e
+  T* g_maps = maps_in_lds ? s_maps : scratch + b * (int64_t)(2 * E + S + 1) * 49;  // M_e
   // prefix products of step s live in slots [first+s .. last+s]: slot(first+s) = start
   // (identity), slot(e+s+1) = M_e ... M_first; the reverse sweep then overwrites slot(e+s+1)
   // with M_bar_e.  (The +s keeps neighbouring steps from sharing a slot.)
@@ -770,33 +776,43 @@ __global__ __launch_bounds__(256) void k_build_bwd(LatticeDev lat, const T* __re
   __threadfence_block();
   __syncthreads();
 
-  // 2. per step: prefix products forward, cotangent sweep backward (49 threads, one per entry)
-  for (int s = 0; s < S; ++s) {
+  // 2. per step: prefix products forward, cotangent sweep backward (49 lanes, one per entry).  The steps do not depend
+  //    on each other -- except a run and the cavity it is merged with, which hand T_cav_bar over through the cavity's
+  //    tbar row -- so they are dealt out to the four WAVES, a [run, cavity] pair as one item: each wave walks its
+  //    steps' chains of small dependent products on its own, with hand-overs inside the wave instead of workgroup
+  //    barriers (BASELINE config 5: 130 barrier rounds of the whole workgroup -> 32 hand-overs per wave, four chains
+  //    side by side).
+  const int wave = tid >> 6, lane = tid & 63;
+  T* sa = s_a + wave * 98;   // [49] running cotangent A of this wave's current step
+  T* sm = sa + 49;           // [49] temp
+  const auto hand_over = [] {
+    __threadfence_block();   // the maps may live in HBM scratch: this wave's stores have landed
+    __builtin_amdgcn_wave_barrier();
+  };
+  const auto process_step = [&](int s) {
     const lynx_step st = lat.steps[s];
     const T* tb = tbar + (b * S + s) * (int64_t)kGradStride;
     const bool raw = st.kind == LYNX_STEP_CAVITY || (st.flags & LYNX_STEP_FLAG_RAW);
     // prefix: slot(e) = product of the step's elements up to and including e; slot(first-1)
     // is the start (identity); a raw step's first element has no predecessor product
-    if (tid < 49) g_pref[(int64_t)(st.first + s) * 49 + tid] = (tid % 8 == 0) ? T(1) : T(0);
-    __threadfence_block();
-    __syncthreads();
+    if (lane < 49) g_pref[(int64_t)(st.first + s) * 49 + lane] = (lane % 8 == 0) ? T(1) : T(0);
+    hand_over();
     for (int e = st.first; e < st.last; ++e) {
       T v = T(0);
-      if (tid < 49) v = mat_product_entry<T>(g_maps + (int64_t)e * 49, g_pref + (int64_t)(e + s) * 49, tid);
-      if (tid < 49) g_pref[(int64_t)(e + s + 1) * 49 + tid] = v;
-      __threadfence_block();
-      __syncthreads();
+      if (lane < 49) v = mat_product_entry<T>(g_maps + (int64_t)e * 49, g_pref + (int64_t)(e + s) * 49, lane);
+      if (lane < 49) g_pref[(int64_t)(e + s + 1) * 49 + lane] = v;
+      hand_over();
     }
     if (merged_pairs && s + 1 < S && steps_pair_up(st, lat.steps[s + 1])) {  // uniform
       // k_track_bwd walked this run and the cavity behind it as ONE unit, M = T_cav . T_run, with the kick
       // driven by rows 4 and 5 of T_run: slot s + 1 holds M_bar, this slot the cotangents of those two rows.
-      //   T_run_bar = T_cav^T M_bar (+ the two rows),   T_cav_bar = M_bar T_run^T  (parked for the next round)
+      //   T_run_bar = T_cav^T M_bar (+ the two rows),   T_cav_bar = M_bar T_run^T  (parked for the cavity's turn)
       T* mbar = tbar + (b * S + s + 1) * (int64_t)kGradStride;
       const T* Tc = g_maps + (int64_t)lat.steps[s + 1].first * 49;
       const T* Tr = g_pref + (int64_t)(st.last + s) * 49;
       T run_bar = T(0), cav_bar = T(0);
-      if (tid < 49) {
-        const int i = tid / 7, j = tid - i * 7;
+      if (lane < 49) {
+        const int i = lane / 7, j = lane - i * 7;
         run_bar = Tc[i] * mbar[j];
         cav_bar = mbar[i * 7] * Tr[j * 7];
 #pragma unroll
@@ -807,47 +823,53 @@ __global__ __launch_bounds__(256) void k_build_bwd(LatticeDev lat, const T* __re
         if (i == 4) run_bar += tb[j];
         if (i == 5) run_bar += tb[7 + j];
       }
-      __syncthreads();  // every entry of M_bar has been read
-      if (tid < 49) {
-        s_a[tid] = run_bar;
-        mbar[tid] = cav_bar;
+      hand_over();  // every entry of M_bar has been read
+      if (lane < 49) {
+        sa[lane] = run_bar;
+        mbar[lane] = cav_bar;
       }
-      __threadfence_block();
-    } else if (tid < 49) {
-      s_a[tid] = tb[tid];
+    } else if (lane < 49) {
+      sa[lane] = tb[lane];
     }
-    __syncthreads();
+    hand_over();
     for (int e = st.last - 1; e >= st.first; --e) {
       // M_bar_e = A . P_{e-1}^T ;  A <- M_e^T . A
       T mb = T(0), an = T(0);
-      if (tid < 49) {
-        const int i = tid / 7, j = tid - i * 7;
+      if (lane < 49) {
+        const int i = lane / 7, j = lane - i * 7;
         const T* P = g_pref + (int64_t)(e + s) * 49;
         const T* M = g_maps + (int64_t)e * 49;
         if (raw && e == st.first) {
-          mb = s_a[tid];  // the map itself is the step's product start
+          mb = sa[lane];  // the map itself is the step's product start
         } else {
-          T accv = s_a[i * 7] * P[j * 7];
+          T accv = sa[i * 7] * P[j * 7];
 #pragma unroll
-          for (int k = 1; k < 7; ++k) accv = t_fma(s_a[i * 7 + k], P[j * 7 + k], accv);
+          for (int k = 1; k < 7; ++k) accv = t_fma(sa[i * 7 + k], P[j * 7 + k], accv);
           mb = accv;
         }
-        T acc2 = M[0 * 7 + i] * s_a[0 * 7 + j];
+        T acc2 = M[0 * 7 + i] * sa[0 * 7 + j];
 #pragma unroll
-        for (int k = 1; k < 7; ++k) acc2 = t_fma(M[k * 7 + i], s_a[k * 7 + j], acc2);
+        for (int k = 1; k < 7; ++k) acc2 = t_fma(M[k * 7 + i], sa[k * 7 + j], acc2);
         an = acc2;
       }
-      __syncthreads();
-      if (tid < 49) {
-        s_a[tid] = an;
-        s_t[tid] = mb;
+      hand_over();  // A and P_{e-1} have been read by every lane
+      if (lane < 49) {
+        sa[lane] = an;
+        g_pref[(int64_t)(e + s + 1) * 49 + lane] = mb;  // this slot now holds M_bar_e
       }
-      __syncthreads();
-      if (tid < 49) g_pref[(int64_t)(e + s + 1) * 49 + tid] = s_t[tid];  // this slot now holds M_bar_e
-      __threadfence_block();
-      __syncthreads();
+      hand_over();
+    }
+  };
+  {
+    int item = 0;
+    for (int s = 0; s < S; ++item) {  // uniform walk over the items; wave (item mod 4) takes it
+      const int n = (merged_pairs && s + 1 < S && steps_pair_up(lat.steps[s], lat.steps[s + 1])) ? 2 : 1;
+      if ((item & 3) == wave)
+        for (int q = 0; q < n; ++q) process_step(s + q);
+      s += n;
     }
   }
+  __syncthreads();
 
   // 3. theta_bar = <M_bar, dM/dtheta> (+ <coef_bar, dcoef/dtheta>) by dual evaluation; one task
   //    per (element, parameter), parameter index np = derivative w.r.t. the step energy.

@@ -1552,7 +1552,7 @@ static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const v
   hipLaunchKernelGGL(k_reduce_tbar<T>, dim3((unsigned)(B * S)), dim3(64), 0, ctx->stream, (const T*)ctx->scratch_grad[0],
                      (int)chunks, (int)S, (T*)ctx->scratch_grad[1]);
   HIP_TRY(ctx, hipGetLastError());
-  size_t lds2 = ((size_t)2 * (S + 1) + E + 49 + 49) * sizeof(T);
+  size_t lds2 = build_bwd_lds_fixed<T>(S, E);
   // maps + prefix products, then the kind-sorted task list and the elements' kinds (unsigned short each)
   const size_t maps_bytes = (size_t)(2 * E + S + 1) * 49 * sizeof(T) + ((size_t)bwd_task_capacity(E) + E) * sizeof(unsigned short);
   const int maps_in_lds = E < 4096 && lds2 + maps_bytes <= (size_t)env_int("LYNX_BWD_MAPS_LDS_KB", 40) * 1024;
@@ -1610,7 +1610,7 @@ static int moments_backward_t(lynx_ctx* ctx, lynx_lattice* lat, const void* d_en
                      (const T*)d_mu_in, (const T*)d_cov_in, (const T*)d_mu_bar, (const T*)d_cov_bar,
                      (T*)ctx->scratch_grad[0], (T*)ctx->scratch_grad[1], (T*)d_grad_mu_in, (T*)d_grad_cov_in);
   HIP_TRY(ctx, hipGetLastError());
-  size_t lds2 = ((size_t)2 * (S + 1) + E + 49 + 49) * sizeof(T);
+  size_t lds2 = build_bwd_lds_fixed<T>(S, E);
   // maps + prefix products, then the kind-sorted task list and the elements' kinds (unsigned short each)
   const size_t maps_bytes = (size_t)(2 * E + S + 1) * 49 * sizeof(T) + ((size_t)bwd_task_capacity(E) + E) * sizeof(unsigned short);
   const int maps_in_lds = E < 4096 && lds2 + maps_bytes <= (size_t)env_int("LYNX_BWD_MAPS_LDS_KB", 40) * 1024;
