@@ -11,6 +11,9 @@ composes every sample's element maps, the launch that streams the particles thro
 (moments accumulated in its epilogue), the moment finalisation, and (N > 1) the RCCL
 all-gather of the per-sample moment records.
 Particles, lattice parameters and outputs are resident in HBM when the timed region starts.
+Order of a run: CPU baseline (rank 0 of a one-GPU run, before the GPU is opened), W warm-up steps, the plain-copy
+calibration of this box's HBM ceiling (every rank, about 0.1 s; `hbm_copy_kernel_when` in the line says so,
+LYNX_BENCH_CALIBRATE_FIRST=0 moves it behind the timed region), barrier, K timed steps, barrier.
 
 N > 1: one process per GPU.  Started plainly (`WORLD_SIZE` not in the environment) this process
 becomes the LAUNCHER: it starts N fresh children of itself with RANK / LOCAL_RANK / WORLD_SIZE and a
