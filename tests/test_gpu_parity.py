@@ -370,6 +370,100 @@ def test_the_bench_plan_of_config_4_against_the_oracle(lx):
     assert np.all(records[0][:, 35] == N)
 
 
+def test_config_4_at_its_full_size_is_exactly_linear_and_matches_the_oracle_on_three_samples(lx):
+    """
+    BASELINE config 4 as the bench runs it -- 1024 samples x 100 000 particles x 128-element FODO, float32, beam made
+    in HBM -- is too large to run through the oracle whole.  Two checks that do not depend on the size:
+    (1) drifts and quadrupoles without misalignment have no affine column, so the lattice is LINEAR, and scaling a
+    beam by 2 is exact in binary floating point: the beam with twice the sigmas (same seed) must come out exactly
+    twice as large -- every particle of every sample bit for bit, the means times 2, the second moments times 4 --
+    whatever the launch plan, tile order and reduction tree did on the way (element.py:83-92: P T^T).
+    (2) samples 0, 511 and 1023 against `o.segment_track` on their k1 values: particles at 1e-4 of each coordinate's
+    scale, moments at north_star's 1e-4.
+    """
+    B, N = 1024, 100_000
+    dtype = np.float32
+    desc = _fodo_scan(B)
+    elements, _ = make_lattice(desc, dtype, lx)
+    segment = lx.Segment(elements)
+    sigma = np.array([1e-4, 1e-5, 1e-4, 1e-5, 1e-5, 1e-3])
+    beam = lx.ParticleBeam.synthetic((B,), N, sigma=sigma, energy=1e8, seed=2, dtype=dtype)
+    twice = lx.ParticleBeam.synthetic((B,), N, sigma=2 * sigma, energy=1e8, seed=2, dtype=dtype)
+    pick = [0, 511, 1023]
+    P = np.asarray(beam.particles)[pick]
+    P2 = np.asarray(twice.particles)[pick]
+    assert np.array_equal(P2[..., :6], 2 * P[..., :6]) and np.all(P2[..., 6] == 1)
+    out, out2 = segment.track(beam), segment.track(twice)
+    a, b = np.asarray(out.particles), np.asarray(out2.particles)
+    assert np.array_equal(b[..., :6], 2 * a[..., :6]) and np.array_equal(b[..., 6], a[..., 6])
+    for key in ("mu_x", "mu_xp", "mu_y", "mu_yp", "mu_s", "mu_p", "sigma_x", "sigma_xp", "sigma_y", "sigma_yp", "sigma_s", "sigma_p"):
+        assert np.array_equal(np.asarray(getattr(out2, key)), 2 * np.asarray(getattr(out, key))), key
+    for key in ("sigma_xxp", "sigma_yyp"):
+        assert np.array_equal(np.asarray(getattr(out2, key)), 4 * np.asarray(getattr(out, key))), key
+    assert np.all(np.asarray(out.moment_record())[:, 35] == N)
+    sub = [(kind, {k: np.asarray(v)[pick] for k, v in kw.items()}) for kind, kw in desc]
+    _, specs = make_lattice(sub, dtype)
+    ref = o.segment_track(specs, o.particle_beam(P, np.full(len(pick), 1e8, dtype=dtype), dtype), dtype)
+    m = o.beam_moments(ref, ddof=1)
+    for c in range(7):
+        assert rel_err(a[pick][..., c], ref["particles"][..., c]) < 1e-4, c
+    for key in ("mu_x", "mu_xp", "mu_y", "mu_yp", "mu_s", "mu_p"):
+        sig = m["sigma" + key[2:]]
+        assert np.all(np.abs(np.asarray(getattr(out, key))[pick] - m[key]) <= 1e-4 * (np.abs(m[key]) + sig)), key
+    for key in ("sigma_x", "sigma_xp", "sigma_y", "sigma_yp", "sigma_s", "sigma_p"):
+        assert np.allclose(np.asarray(getattr(out, key))[pick], m[key], rtol=1e-4, atol=0), key
+
+
+def test_config_5_at_its_full_size_structured_equals_dense_and_matches_the_oracle_on_three_samples(lx, monkeypatch):
+    """
+    BASELINE config 5 at its full size -- 4096 environments x 10 000 particles x [Drift, misaligned Quadrupole,
+    Drift, Cavity] x 8, float32 -- through the structured step loop (k_track_units, insisted on) and through the dense
+    one: every particle, every energy and every moment record of the two bit for bit (lynx_units.hpp: skipped terms
+    are exact zeros); and environments 0, 2047 and 4095 against `o.segment_track`: moments at north_star's 1e-4,
+    transverse particle coordinates at 1e-4 of their scale (s and delta behind eight cavities: 3e-3, the float32
+    oracle's own distance from float64 there).  (cavity.py:97-246, quadrupole.py:66-80.)
+    """
+    B, N = 4096, 10_000
+    dtype = np.float32
+    rng = np.random.default_rng(4)
+    f = lambda v: np.full(B, v)  # noqa: E731
+    desc = []
+    for _ in range(8):
+        desc += [("drift", dict(length=f(0.3))),
+                 ("quadrupole", dict(length=f(0.1), k1=rng.uniform(-5, 5, B), misalignment=rng.normal(0, 1e-4, (B, 2)))),
+                 ("drift", dict(length=f(0.3))),
+                 ("cavity", dict(length=f(1.0377), voltage=rng.uniform(5e6, 2e7, B), phase=rng.uniform(-10, 10, B), frequency=f(1.3e9)))]
+    elements, _ = make_lattice(desc, dtype, lx)
+    segment = lx.Segment(elements)
+    # (sigma_s = 1e-4 as in test_c5_shape_moments: with the bench's 1e-5 the float32 cosines of eight kicks are worth
+    # more than 1e-4 of sigma_s in the oracle as in the kernel)
+    beam = lx.ParticleBeam.synthetic((B,), N, sigma=[1e-4, 1e-5, 1e-4, 1e-5, 1e-4, 1e-3], energy=6e6, seed=2, dtype=dtype)
+    outs = {}
+    for units in ("2", "0"):
+        monkeypatch.setenv("LYNX_TRACK_UNITS", units)
+        out = segment.track(beam)
+        outs[units] = (np.asarray(out.particles), np.asarray(out.energy), np.asarray(out.moment_record()), out)
+    for k in range(3):
+        assert _same_bits(outs["2"][k], outs["0"][k]), k
+    out = outs["2"][3]
+    pick = [0, 2047, 4095]
+    P = np.asarray(beam.particles)[pick]
+    sub = [(kind, {k: np.asarray(v)[pick] for k, v in kw.items()}) for kind, kw in desc]
+    _, specs = make_lattice(sub, dtype)
+    ref = o.segment_track(specs, o.particle_beam(P, np.full(len(pick), 6e6, dtype=dtype), dtype), dtype)
+    m = o.beam_moments(ref, ddof=1)
+    got = outs["2"][0][pick]
+    for c in range(7):
+        assert rel_err(got[..., c], ref["particles"][..., c]) < (3e-3 if c in (4, 5) else 1e-4), c
+    assert rel_err(outs["2"][1][pick], ref["energy"]) < 1e-6
+    for key in ("mu_x", "mu_xp", "mu_y", "mu_yp", "mu_s", "mu_p"):
+        sig = m["sigma" + key[2:]]
+        assert np.all(np.abs(np.asarray(getattr(out, key))[pick] - m[key]) <= 1e-4 * (np.abs(m[key]) + sig)), key
+    for key in ("sigma_x", "sigma_xp", "sigma_y", "sigma_yp", "sigma_s", "sigma_p"):
+        assert np.allclose(np.asarray(getattr(out, key))[pick], m[key], rtol=1e-4, atol=0), key
+    assert np.all(outs["2"][2][:, 35] == N)
+
+
 def test_c4_shape_composed_map_is_the_exact_product_of_its_float32_element_maps(lx):
     """The float32 build multiplies in float64: the composed map equals the float64 product of the
     GPU's own float32 element maps to float32 rounding, whatever the association.  (Against the
