@@ -493,12 +493,13 @@ def main():
         last = step()
     rt.sync()
     # The practical ceiling on this box -- a plain 16 B/lane device copy of one pass' bytes, five launch shapes -- is
-    # measured HERE, between the warm-up and the timed region, on every rank, for about 0.1 s: after an idle stretch
-    # (the first call's 13 ms of set-up on the host is one) an MI355X needs 20-30 ms of memory-bound work before its
-    # kernels run at the speed a long job sees (BASELINE config 4 from a cold start: 1.00, 1.00, 1.09, 1.17, 1.16, ...
-    # 0.95 ms per launch after 20 launches, with the same curve when nothing runs next to the kernel:
-    # profiles/r03_first_launches.txt), and five warm-up steps end long before that.  LYNX_BENCH_CALIBRATE_FIRST=0
-    # puts the calibration behind the timed region again (rank 0 of a one-GPU run only).
+    # measured HERE, between the warm-up and the timed region, on every rank, for about 0.1 s.  The streaming kernel
+    # has a start-up transient of 20-30 ms (BASELINE config 4: 1.00, 1.00, 1.09, 1.17, 1.16, ... 0.95 ms per launch
+    # after 20 launches, the same curve with nothing running next to it and also right behind other kernels; plain
+    # copies show none: profiles/r03_first_launches.txt), and five warm-up steps end inside it.
+    # Behind the calibration's copies the kernel's second start is much milder (1.00 -> 0.94 over the 20 timed steps),
+    # which is closer to what a long job sees.  LYNX_BENCH_CALIBRATE_FIRST=0 puts the calibration behind the timed
+    # region again (rank 0 of a one-GPU run only).
     copy_gbs = None
     calibrate_first = os.environ.get("LYNX_BENCH_CALIBRATE_FIRST", "1") != "0"
 
