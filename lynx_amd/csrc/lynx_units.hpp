@@ -315,7 +315,10 @@ __global__ __launch_bounds__(kTrackThreads, (units_waves_per_simd<MOM, FULL, PAI
       for (int p = 0; p < PAIRS; ++p) bad = bad || pair_not_finite(z[p]);
       return __builtin_amdgcn_ballot_w64(bad) != 0;  // wave-uniform
     };
-    bool all_dense = any_not_finite();
+    // (only what comes OUT is looked at: a non-finite coordinate going in leaves its own block of the first unit
+    // non-finite -- m * inf is inf or, for m = 0, NaN -- and nothing on the way makes it finite again, the kick's
+    // cosine and squares included; so the check in front of the units was 10 instructions per tile for nothing)
+    bool all_dense = false;
     for (;;) {
       units_program<PAIRS>(U, g_units, g_extras, g_steps, all_dense, z);
       // what came out: a value that overflowed on the way (or met a non-finite coefficient) would have spread through
