@@ -1278,7 +1278,9 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
       // dense step loop of k_track_direct
       // (LYNX_TRACK_UNITS=2: insist -- an error if this call cannot take the structured loop; for tests)
       const int want_units = env_int("LYNX_TRACK_UNITS", 1);
-      if (S > 1 && (p.unroll == 2 || p.unroll == 4) && !p.xpose && p.a.n_observers == 0 && !p.a.interleave && want_units) {
+      // (k_track_units addresses a sample's particles with 32-bit byte offsets: samples below 4 GiB)
+      if (S > 1 && (p.unroll == 2 || p.unroll == 4) && !p.xpose && p.a.n_observers == 0 && !p.a.interleave && want_units &&
+          (uint64_t)N * 28u + ((uint64_t)1 << 20) < ((uint64_t)1 << 32)) {
         if ((rc = ensure_units_plan(ctx, lat, p.a.merged_pairs != 0))) return rc;
         use_units = lat->units_ok;
       }

@@ -92,6 +92,16 @@ __device__ __forceinline__ bool pair_not_finite(const lynx_f32x2 (&z)[7]) {
   return (acc.x != acc.x) || (acc.y != acc.y);
 }
 
+// particle `i` of a sample whose first particle sits at `base`: a wave-uniform base and a 32-bit byte offset per lane --
+// the address form global loads take without any 64-bit vector arithmetic (the host keeps samples of 4 GiB and more
+// away from this kernel)
+__device__ __forceinline__ const float* particle_at(const float* base, uint32_t i) {
+  return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + i * 28u);
+}
+__device__ __forceinline__ float* particle_at(float* base, uint32_t i) {
+  return reinterpret_cast<float*>(reinterpret_cast<char*>(base) + i * 28u);
+}
+
 template <int MOM, bool FULL, int PAIRS> constexpr int units_waves_per_simd() {
   return PAIRS == 1 ? ((!FULL && (MOM == 0 || MOM == 3)) ? 5 : 1) : ((!FULL && (MOM == 0 || MOM == 3)) ? 4 : 1);
 }
@@ -254,26 +264,26 @@ __global__ __launch_bounds__(kTrackThreads, (units_waves_per_simd<MOM, FULL, PAI
   // is derived from them -- the record addresses of the step loop above all -- then stays scalar
   const int64_t b = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / a.chunks));
   const int chunk = __builtin_amdgcn_readfirstlane((int)(blockIdx.x % a.chunks));
-  const int64_t end = a.n_particles;
-  constexpr int64_t kTile = (int64_t)kTrackThreads * UNROLL;
+  const uint32_t end = (uint32_t)a.n_particles;  // < 2^32 / 28 (launch_units)
+  constexpr uint32_t kTile = (uint32_t)kTrackThreads * UNROLL;
   const T* src = p_in + b * a.in_stride;
-  T* dst = p_out + b * end * 7;
+  T* dst = p_out + b * (int64_t)a.n_particles * 7;
   const float* g_steps = steps_in + b * (int64_t)S * LYNX_STEP_STRIDE;
   const float* g_units = units_in + b * (int64_t)U * kUnitStride;
   const float* g_extras = extras_in + b * (int64_t)U * kUnitExtraStride;
 
   // (dealing a sample's tiles out so that the grid is a whole number of rounds of resident workgroups was measured and
   // lost: C4 0.995 -> 1.07 ms, the 128-sample shard 0.155 -> 0.162)
-  const int64_t tile0 = (int64_t)chunk * a.tiles_per_wg;
+  const uint32_t tile0 = (uint32_t)chunk * (uint32_t)a.tiles_per_wg;
   const int my_tiles = a.tiles_per_wg;
   // the first tile's loads go out before anything else
   T zn[UNROLL][7];
   {
-    const int64_t i0 = tile0 * kTile + tid;
+    const uint32_t i0 = tile0 * kTile + tid;
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
-      const int64_t i = i0 + (int64_t)u * kTrackThreads;
-      load_particle(src + (i < end ? i : (i0 < end ? i0 : 0)) * 7, zn[u]);
+      const uint32_t i = i0 + (uint32_t)u * kTrackThreads;
+      load_particle(particle_at(src, i < end ? i : (i0 < end ? i0 : 0u)), zn[u]);
     }
   }
   if (energy_out && chunk == 0 && tid == 0 && S > 0) energy_out[b] = g_steps[(S - 1) * LYNX_STEP_STRIDE + LYNX_ENERGY_OFFSET];
@@ -285,8 +295,8 @@ __global__ __launch_bounds__(kTrackThreads, (units_waves_per_simd<MOM, FULL, PAI
   for (int i = 0; i < 6; ++i) shift[i] = T(0);
 
   for (int it = 0; it < my_tiles; ++it) {
-    const int64_t tile = tile0 + it;
-    const int64_t i0 = tile * kTile + tid;
+    const uint32_t tile = tile0 + (uint32_t)it;
+    const uint32_t i0 = tile * kTile + tid;
     // (uniform: the whole workgroup leaves together.  A per-lane `i0 >= end` here makes the loop's control flow
     // divergent, and the compiler then keeps every loop-carried scalar -- record registers, addresses -- in VECTOR
     // registers; lanes beyond the end of the sample ride along on a clamped address and are masked where it counts)
@@ -301,11 +311,11 @@ __global__ __launch_bounds__(kTrackThreads, (units_waves_per_simd<MOM, FULL, PAI
         z[p][c].y = zn[2 * p + 1][c];
       }
     if (it + 1 < my_tiles) {  // prefetch the next tile of this workgroup
-      const int64_t j0 = (tile + 1) * kTile + tid;
+      const uint32_t j0 = (tile + 1) * kTile + tid;
 #pragma unroll
       for (int u = 0; u < UNROLL; ++u) {
-        const int64_t j = j0 + (int64_t)u * kTrackThreads;
-        load_particle(src + (j < end ? j : 0) * 7, zn[u]);
+        const uint32_t j = j0 + (uint32_t)u * kTrackThreads;
+        load_particle(particle_at(src, j < end ? j : 0u), zn[u]);
       }
     }
     // a non-finite particle anywhere in the wave: the dense chain, whose zero entries spread it like the reference's
@@ -328,9 +338,9 @@ __global__ __launch_bounds__(kTrackThreads, (units_waves_per_simd<MOM, FULL, PAI
       // reload the tile; the outgoing beam has not been written yet, so in-place tracking is safe
 #pragma unroll
       for (int u = 0; u < UNROLL; ++u) {
-        const int64_t i = i0 + (int64_t)u * kTrackThreads;
+        const uint32_t i = i0 + (uint32_t)u * kTrackThreads;
         T t[7];
-        load_particle(src + (i < end ? i : 0) * 7, t);
+        load_particle(particle_at(src, i < end ? i : 0u), t);
 #pragma unroll
         for (int c = 0; c < 7; ++c) {
           if (u % 2 == 0) z[u / 2][c].x = t[c];
@@ -353,9 +363,9 @@ __global__ __launch_bounds__(kTrackThreads, (units_waves_per_simd<MOM, FULL, PAI
     }
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
-      const int64_t i = i0 + (int64_t)u * kTrackThreads;
+      const uint32_t i = i0 + (uint32_t)u * kTrackThreads;
       if (i < end) {
-        if (a.store) store_particle(dst + i * 7, zo[u]);
+        if (a.store) store_particle(particle_at(dst, i), zo[u]);
         if (MOM) sums.add(zo[u], shift);
       }
     }
