@@ -102,6 +102,16 @@ __device__ __forceinline__ float* particle_at(float* base, uint32_t i) {
   return reinterpret_cast<float*>(reinterpret_cast<char*>(base) + i * 28u);
 }
 
+// A wave-uniform value the compiler must keep in a VECTOR register: the step loop needs every scalar register there is,
+// and the six coordinates of the moments' reference point, left to the compiler, lived in scalar registers that were
+// spilled to vector-register lanes and read back one v_readlane at a time wherever a particle entered the sums (12 per
+// tile) -- a copy per lane costs six registers and nothing else.
+__device__ __forceinline__ float in_vector_register(float uniform) {
+  float v;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(uniform));
+  return v;
+}
+
 template <int MOM, bool FULL, int PAIRS> constexpr int units_waves_per_simd() {
   return PAIRS == 1 ? ((!FULL && (MOM == 0 || MOM == 3)) ? 5 : 1) : ((!FULL && (MOM == 0 || MOM == 3)) ? 4 : 1);
 }
@@ -359,7 +369,7 @@ __global__ __launch_bounds__(kTrackThreads, (units_waves_per_simd<MOM, FULL, PAI
       }
     if (MOM && it == 0) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) shift[k] = wave_first(zo[0][k]);
+      for (int k = 0; k < 6; ++k) shift[k] = in_vector_register(wave_first(zo[0][k]));
     }
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
