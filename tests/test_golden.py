@@ -87,7 +87,7 @@ def test_gpu_reproduces_golden(dtype, built_library):
     seg = lx.Segment(elements)
     out = seg.track(lx.ParticleBeam(G[f"mixed/particles_in/{tag}"], np.full(3, 6e6, dtype), dtype=dtype))
     got, ref = np.asarray(out.particles), G[f"mixed/particles_out/{tag}"]
-    tol = {np.float32: [3e-4] * 4 + [3e-3, 3e-3, 1e-6], np.float64: [1e-9] * 7}[dtype]
+    tol = {np.float32: [1e-4] * 4 + [1e-4, 5e-4, 1e-6], np.float64: [1e-9] * 7}[dtype]
     for c in range(7):
         assert rel_err(got[..., c], ref[..., c]) < tol[c], (c, rel_err(got[..., c], ref[..., c]))
     assert rel_err(out.energy, G[f"mixed/energy_out/{tag}"]) < 1e-6

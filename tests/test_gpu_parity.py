@@ -268,9 +268,10 @@ def test_c5_cavity_lattice_particles(lx, dtype):
     out, ref = _particle_case(lx, desc, dtype, (B,), 2500, seed=3, energy=6e6,
                               sigma=[1e-4, 1e-5, 1e-4, 1e-5, 1e-4, 1e-3])
     got = np.asarray(out.particles)
-    # delta goes through cos(phi + eps) - cos(phi) in the working precision (cavity.py:150-160):
-    # fp32 agreement is bounded by that cancellation, not by the kernel
-    tol = {np.float32: [2e-4] * 4 + [2e-3, 2e-3, 1e-6], np.float64: [1e-9] * 7}[dtype]
+    # delta goes through cos(phi + eps) - cos(phi) in the working precision (cavity.py:150-160): fp32 agreement is
+    # bounded by that cancellation, not by the kernel -- measured 6e-5 .. 1.6e-4 from the float32 oracle, which is
+    # itself 4e-5 .. 1e-4 away from the float64 one (scripts/gpu/r3_c5_particles.py); s: 4e-7 .. 2.5e-6
+    tol = {np.float32: [1e-4] * 4 + [1e-4, 5e-4, 1e-6], np.float64: [1e-9] * 7}[dtype]
     for c in range(7):
         assert rel_err(got[..., c], ref["particles"][..., c]) < tol[c], (c, rel_err(got[..., c], ref["particles"][..., c]))
     assert rel_err(out.energy, ref["energy"]) < 1e-6
@@ -420,8 +421,9 @@ def test_config_5_at_its_full_size_structured_equals_dense_and_matches_the_oracl
     Drift, Cavity] x 8, float32 -- through the structured step loop (k_track_units, insisted on) and through the dense
     one: every particle, every energy and every moment record of the two bit for bit (lynx_units.hpp: skipped terms
     are exact zeros); and environments 0, 2047 and 4095 against `o.segment_track`: moments at north_star's 1e-4,
-    transverse particle coordinates at 1e-4 of their scale (s and delta behind eight cavities: 3e-3, the float32
-    oracle's own distance from float64 there).  (cavity.py:97-246, quadrupole.py:66-80.)
+    particle coordinates at 1e-4 of their scale, delta behind eight cavities at 5e-4 (measured 6e-5 .. 1.6e-4: the
+    float32 cosines of eight kicks, the float32 oracle itself is 4e-5 .. 1e-4 away from the float64 one there:
+    scripts/gpu/r3_c5_particles.py).  (cavity.py:97-246, quadrupole.py:66-80.)
     """
     B, N = 4096, 10_000
     dtype = np.float32
@@ -454,7 +456,7 @@ def test_config_5_at_its_full_size_structured_equals_dense_and_matches_the_oracl
     m = o.beam_moments(ref, ddof=1)
     got = outs["2"][0][pick]
     for c in range(7):
-        assert rel_err(got[..., c], ref["particles"][..., c]) < (3e-3 if c in (4, 5) else 1e-4), c
+        assert rel_err(got[..., c], ref["particles"][..., c]) < (5e-4 if c == 5 else 1e-4), c
     assert rel_err(outs["2"][1][pick], ref["energy"]) < 1e-6
     for key in ("mu_x", "mu_xp", "mu_y", "mu_yp", "mu_s", "mu_p"):
         sig = m["sigma" + key[2:]]
@@ -588,7 +590,7 @@ def test_lanes_build_agrees_with_the_workgroup_build(lx, dtype, B, monkeypatch):
         out, ref = _particle_case(lx, desc, dtype, (B,), 700, seed=8, energy=6e6, sigma=[1e-4, 1e-5, 1e-4, 1e-5, 1e-4, 1e-3])
         results[name] = (np.asarray(out.particles), np.asarray(out.energy), out.moment_record().copy())
         got = np.asarray(out.particles)
-        tol = {np.float32: [3e-4] * 4 + [3e-3, 3e-3, 1e-6], np.float64: [1e-9] * 7}[dtype]
+        tol = {np.float32: [1e-4] * 4 + [1e-4, 5e-4, 1e-6], np.float64: [1e-9] * 7}[dtype]
         for c in range(7):
             assert rel_err(got[..., c], ref["particles"][..., c]) < tol[c], (name, c)
         assert rel_err(out.energy, ref["energy"]) < 1e-6
@@ -1193,7 +1195,7 @@ def test_active_bpms_are_read_inside_the_streaming_pass(lx, dtype, n):
         assert np.all(np.abs(got - want) <= tol * (np.abs(want) + 3 * sig_x)), (name, got, want)
     assert seg.idle.reading is None
     got = np.asarray(out.particles)
-    ptol = {np.float32: [2e-4] * 4 + [2e-3, 2e-3, 1e-6], np.float64: [1e-9] * 7}[dtype]
+    ptol = {np.float32: [1e-4] * 4 + [1e-4, 5e-4, 1e-6], np.float64: [1e-9] * 7}[dtype]
     for c in range(7):
         assert rel_err(got[..., c], ref["particles"][..., c]) < ptol[c], c
     _assert_moments(out, ref, dtype)
