@@ -379,7 +379,8 @@ def main():
               "fused_moments": not args.no_moments, "reverse_pass": bool(args.grad),
               "incoming_beam": "one beam shared by the batch (lazy broadcast)" if args.shared_input else "one physical beam per sample",
               "gather": "none", "parallelism": parallelism, "pipelined_calls": not args.sync_every_step,
-              "launcher": "torchrun/external" if os.environ.get("TORCHELASTIC_RUN_ID") or "LYNX_RDZV_KEY" not in os.environ
+              "launcher": "none (one process)" if world == 1 and "WORLD_SIZE" not in os.environ
+                          else "torchrun/external" if os.environ.get("TORCHELASTIC_RUN_ID") or "LYNX_RDZV_KEY" not in os.environ
                           else "bench.py"}
     scaling = "weak" if (args.weak and world > 1) else "strong"
 
