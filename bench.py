@@ -11,9 +11,11 @@ composes every sample's element maps, the launch that streams the particles thro
 (moments accumulated in its epilogue), the moment finalisation, and (N > 1) the RCCL
 all-gather of the per-sample moment records.
 Particles, lattice parameters and outputs are resident in HBM when the timed region starts.
-Order of a run: CPU baseline (rank 0 of a one-GPU run, before the GPU is opened), W warm-up steps, the plain-copy
-calibration of this box's HBM ceiling (every rank, about 0.1 s; `hbm_copy_kernel_when` in the line says so,
-LYNX_BENCH_CALIBRATE_FIRST=0 moves it behind the timed region), barrier, K timed steps, barrier.
+Order of a run: CPU baseline (rank 0 of a one-GPU run -- the launcher parent of an N-GPU run --, before the GPU is
+opened), W warm-up steps, barrier, K timed steps, barrier (the COLD leg: `ms_per_step_cold`, exactly what the command
+line asks for), the plain-copy calibration of this box's HBM ceiling (every rank, about 0.1 s), barrier, the same K
+timed steps again, barrier (`value`, `ms_per_step`: the streaming kernel's 20-30 ms start-up transient is behind it by
+then).  `hbm_copy_kernel_when` in the line says so; LYNX_BENCH_CALIBRATE_FIRST=0: no cold leg, calibration last.
 
 N > 1: one process per GPU.  Started plainly (`WORLD_SIZE` not in the environment) this process
 becomes the LAUNCHER: it starts N fresh children of itself with RANK / LOCAL_RANK / WORLD_SIZE and a
@@ -57,6 +59,9 @@ WORKLOADS = {
     # name: (batch per GPU, particles, FODO cells (x4 elements), dtype, description)
     "c4": (1024, 100_000, 32, np.float32,
            "BASELINE config 4: 1024 k1-scan samples x 128-element FODO x 100k particles fp32 (one scan, sharded over the GPUs)"),
+    "c4a": (1024, 100_000, 32, np.float32,
+            "BASELINE config 4, corrector-angle variant: 1024 angle-scan samples x 128-element FODO with an H and a V "
+            "corrector per cell x 100k particles fp32"),
     "c3": (1, 1_000_000, 32, np.float64, "BASELINE config 3: 128-element FODO x 1M particles fp64, batch 1"),
     "c3big": (1, 8_000_000, 32, np.float64, "config 3 at 8M particles (896 MB: defeats the 256 MB Infinity Cache)"),
     "c2": (1, 100_000, 0, np.float32, "BASELINE config 2: 11-element ARES-style segment x 100k particles fp32"),
@@ -65,42 +70,80 @@ WORKLOADS = {
 }
 
 
-def build_segment(lx, name, sample_ids, cells, dtype, seed):
+def describe(name, sample_ids, cells, dtype, seed):
     """
-    The lattice of workload `name` for the GLOBAL samples `sample_ids` (this rank's slice of the scan: the k1 of a
-    sample depends on its global index only, so the N-rank job is the 1-rank job cut in N pieces).
+    The lattice of workload `name` for the GLOBAL samples `sample_ids` (this rank's slice of the scan: a sample's
+    parameters depend on its global index only, so the N-rank job is the 1-rank job cut in N pieces), as a list of
+    (kind, keyword arguments): the product's elements AND the oracle's specifications are made from it
+    (`build_segment`, `oracle_specs`; tests/test_gpu_parity.py checks the very lattices that are timed here).
     """
     batch = len(sample_ids)
     f = lambda v: np.full((batch,), v, dtype=dtype)  # noqa: E731
     if name == "c2":
-        return lx.Segment([
-            lx.BPM(name="BPM1SMATCH"), lx.Drift(f(1.0), dtype=dtype), lx.BPM(name="BPM6SMATCH"),
-            lx.Drift(f(1.0), dtype=dtype), lx.VerticalCorrector(f(0.3), angle=f(3.142e-3), name="V7SMATCH", dtype=dtype),
-            lx.Drift(f(0.2), dtype=dtype), lx.HorizontalCorrector(f(0.3), angle=f(1e-4), name="H10SMATCH", dtype=dtype),
-            lx.Drift(f(7.0), dtype=dtype), lx.HorizontalCorrector(f(0.3), angle=f(-1e-4), name="H12SMATCH", dtype=dtype),
-            lx.Drift(f(0.05), dtype=dtype), lx.BPM(name="BPM13SMATCH")])
+        return [("bpm", {}), ("drift", dict(length=f(1.0))), ("bpm", {}), ("drift", dict(length=f(1.0))),
+                ("vcor", dict(length=f(0.3), angle=f(3.142e-3))), ("drift", dict(length=f(0.2))),
+                ("hcor", dict(length=f(0.3), angle=f(1e-4))), ("drift", dict(length=f(7.0))),
+                ("hcor", dict(length=f(0.3), angle=f(-1e-4))), ("drift", dict(length=f(0.05))), ("bpm", {})]
     if name == "c5":
         # every environment's parameters are drawn for the whole job and cut to this rank's environments
         rng = np.random.default_rng(seed)
         total = int(sample_ids.max()) + 1 if batch else 0
         pick = lambda a: np.ascontiguousarray(a[sample_ids]).astype(dtype)  # noqa: E731
-        elements = []
+        desc = []
         for _ in range(cells):
-            elements += [lx.Drift(f(0.3), dtype=dtype),
-                         lx.Quadrupole(f(0.1), k1=pick(rng.uniform(-5, 5, total)),
-                                       misalignment=pick(rng.normal(0, 1e-4, (total, 2))), dtype=dtype),
-                         lx.Drift(f(0.3), dtype=dtype),
-                         lx.Cavity(f(1.0377), voltage=pick(rng.uniform(5e6, 2e7, total)),
-                                   phase=pick(rng.uniform(-10, 10, total)), frequency=f(1.3e9), dtype=dtype)]
-        return lx.Segment(elements)
-    # k1 scan: global sample g gets k1 = +-4.2 (0.5 + (g mod 1024)/1023)   (SURVEY.md section 8d)
-    scale = (0.5 + (sample_ids % 1024) / 1023.0) if batch > 1 else np.ones(1)
-    k = (4.2 * scale).astype(dtype)
-    elements = []
+            desc += [("drift", dict(length=f(0.3))),
+                     ("quadrupole", dict(length=f(0.1), k1=pick(rng.uniform(-5, 5, total)),
+                                         misalignment=pick(rng.normal(0, 1e-4, (total, 2))))),
+                     ("drift", dict(length=f(0.3))),
+                     ("cavity", dict(length=f(1.0377), voltage=pick(rng.uniform(5e6, 2e7, total)),
+                                     phase=pick(rng.uniform(-10, 10, total)), frequency=f(1.3e9)))]
+        return desc
+    # position of global sample g in the scan: u = (g mod 1024) / 1023   (SURVEY.md section 8d)
+    u = (sample_ids % 1024) / 1023.0 if batch > 1 else np.full(1, 0.5)
+    if name == "c4a":
+        # the corrector-angle variant of BASELINE config 4 ("k1/angle scan"): the same FODO, its drifts replaced by a
+        # horizontal and a vertical corrector of the drift's length (a corrector IS a drift plus a kick into the affine
+        # column: horizontal_corrector.py:52-67, vertical_corrector.py:52-66), k1 fixed, the angles scanned
+        k = f(4.2)
+        ah, av = (2e-5 * (2 * u - 1)).astype(dtype), (-1e-5 * (2 * u - 1)).astype(dtype)
+        desc = []
+        for _ in range(cells):
+            desc += [("quadrupole", dict(length=f(0.2), k1=k)), ("hcor", dict(length=f(0.5), angle=ah)),
+                     ("quadrupole", dict(length=f(0.2), k1=-k)), ("vcor", dict(length=f(0.5), angle=av))]
+        return desc
+    # k1 scan: k1 = +-4.2 (0.5 + u)
+    k = (4.2 * (0.5 + u)).astype(dtype) if batch > 1 else f(4.2)
+    desc = []
     for _ in range(cells):
-        elements += [lx.Quadrupole(f(0.2), k1=k, dtype=dtype), lx.Drift(f(0.5), dtype=dtype),
-                     lx.Quadrupole(f(0.2), k1=-k, dtype=dtype), lx.Drift(f(0.5), dtype=dtype)]
+        desc += [("quadrupole", dict(length=f(0.2), k1=k)), ("drift", dict(length=f(0.5))),
+                 ("quadrupole", dict(length=f(0.2), k1=-k)), ("drift", dict(length=f(0.5)))]
+    return desc
+
+
+_KINDS = {"drift": "Drift", "quadrupole": "Quadrupole", "hcor": "HorizontalCorrector", "vcor": "VerticalCorrector",
+          "cavity": "Cavity", "bpm": "BPM"}
+
+
+def build_segment(lx, name, sample_ids, cells, dtype, seed):
+    """The product's `Segment` of `describe(...)`."""
+    elements = []
+    for kind, kw in describe(name, sample_ids, cells, dtype, seed):
+        ctor = getattr(lx, _KINDS[kind])
+        elements.append(ctor(**kw) if kind == "bpm" else ctor(**kw, dtype=dtype))
     return lx.Segment(elements)
+
+
+def oracle_specs(o, name, sample_ids, cells, dtype, seed):
+    """The oracle's specification list of `describe(...)` (cpu_baseline leg and tests only)."""
+    return [getattr(o, _KINDS[kind])(**kw) for kind, kw in describe(name, sample_ids, cells, dtype, seed)]
+
+
+# what every workload's incoming beam looks like (6-D Gaussian, made in HBM: ParticleBeam.synthetic)
+BEAM_SIGMA = [1e-4, 1e-5, 1e-4, 1e-5, 1e-5, 1e-3]
+
+
+def beam_energy(name):
+    return 6e6 if name == "c5" else 1e8
 
 
 def shard_of(batch, particles, world, rank, weak):
@@ -143,24 +186,11 @@ def _cpu_sample(name, particles, cells, dtype, bs, seed):
     from oracle import lynx_oracle as o
 
     n = particles if name != "c3big" else 1_000_000
-    if name == "c2":
-        specs = o.ares_like_segment(dtype, (bs,))
-    elif name == "c5":
-        rng = np.random.default_rng(seed)
-        f = lambda v: np.full((bs,), v, dtype=dtype)  # noqa: E731
-        specs = []
-        for _ in range(cells):
-            specs += [o.Drift(f(0.3)),
-                      o.Quadrupole(f(0.1), k1=rng.uniform(-5, 5, bs).astype(dtype),
-                                   misalignment=rng.normal(0, 1e-4, (bs, 2)).astype(dtype)),
-                      o.Drift(f(0.3)),
-                      o.Cavity(f(1.0377), voltage=rng.uniform(5e6, 2e7, bs).astype(dtype),
-                               phase=rng.uniform(-10, 10, bs).astype(dtype), frequency=f(1.3e9))]
-    else:
-        scale = 0.5 + np.arange(bs) / max(bs - 1, 1) if bs > 1 else None
-        specs = o.fodo_segment(cells, np.dtype(dtype).type, (bs,), scale)
-    P = o.gaussian_particles((bs,), n, seed=seed, dtype=dtype, sigma=[1e-4, 1e-5, 1e-4, 1e-5, 1e-5, 1e-3])
-    beam = o.particle_beam(P, np.full((bs,), 6e6 if name == "c5" else 1e8, dtype=dtype), dtype)
+    # `bs` samples spread over the scan (config 5: environments drawn like the job's)
+    ids = np.arange(bs) if name == "c5" or bs == 1 else np.linspace(0, 1023, bs).round().astype(np.int64)
+    specs = oracle_specs(o, name, ids, cells, dtype, seed)
+    P = o.gaussian_particles((bs,), n, seed=seed, dtype=dtype, sigma=BEAM_SIGMA)
+    beam = o.particle_beam(P, np.full((bs,), beam_energy(name), dtype=dtype), dtype)
 
     def run():
         o.beam_moments(o.segment_track(specs, beam, dtype))
@@ -203,7 +233,7 @@ def cpu_baseline(name, particles, cells, dtype, budget_s=10.0):
         from threadpoolctl import threadpool_limits
     except Exception:  # pragma: no cover
         threadpool_limits = None
-    bs = 8 if name == "c4" else (64 if name == "c5" else 1)
+    bs = 8 if name in ("c4", "c4a") else (64 if name == "c5" else 1)
     run, steps_per_pass, E, n = _cpu_sample(name, particles, cells, dtype, bs, 2)
     limiter = threadpool_limits(limits=1) if threadpool_limits else None
     try:
@@ -221,7 +251,7 @@ def cpu_baseline(name, particles, cells, dtype, budget_s=10.0):
     one = steps_per_pass * reps / dt
 
     cores = min(host_cores(), 64)
-    per_worker = 2 if name == "c4" else (16 if name == "c5" else 1)
+    per_worker = 2 if name in ("c4", "c4a") else (16 if name == "c5" else 1)
     t_start = time.time() + 3.0 + 0.05 * cores  # every worker has built its sample by then
     jobs = [(name, particles, cells, dtype, per_worker, 100 + w, t_start, t_start + budget_s) for w in range(cores)]
     with mp.get_context("fork").Pool(cores) as pool:
@@ -268,30 +298,24 @@ def bring_up_rccl(rt, rdzv, rank, world, timeout_s):
     return attempt.get("comm"), attempt.get("error"), False
 
 
-def launch_ranks(n_ranks: int) -> int:
-    """
-    `python bench.py --gpus N` without a launcher around it: become one.  N children of this very command, one
-    per GPU, each with RANK / LOCAL_RANK / WORLD_SIZE and the same rendezvous key, started BEFORE this process has
-    touched the GPU (it never does: no re-exec of a process that has opened the device).  Rank 0 inherits stdout
-    (its JSON line is the run's line), the other ranks' stdout goes to stderr.  Returns the worst exit code; when a
-    rank fails the others get a grace period to notice through the rendezvous, then they are ended by pid.
-    """
-    import secrets
+def _run_ranks(n_ranks: int, env: dict):
+    """One set of N children of this very command -> (exit codes, rank 0's stdout)."""
     import signal
     import subprocess
 
-    env = dict(os.environ)
-    env.update(WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1",
-               LYNX_RDZV_KEY=f"bench-{os.getpid()}-{secrets.token_hex(8)}")
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # RCCL across processes: dmabuf IPC only on this driver
-    env.setdefault("MASTER_PORT", "0")
     children = []
     for r in range(n_ranks):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        # rank 0's stdout is held back: its JSON line is the run's line only if this attempt is the last one
         children.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=e,
-                                         stdout=None if r == 0 else sys.stderr))
-    worst, failed_at = 0, None
+                                         stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    failed_at = None
     grace = float(os.environ.get("LYNX_LAUNCH_GRACE_S", "30"))
+    import threading
+
+    captured = []
+    reader = threading.Thread(target=lambda: captured.append(children[0].stdout.read()), daemon=True)
+    reader.start()
     try:
         while any(c.poll() is None for c in children):
             for c in children:
@@ -308,11 +332,62 @@ def launch_ranks(n_ranks: int) -> int:
         for c in children:
             if c.poll() is None:
                 c.send_signal(signal.SIGTERM)
-    for c in children:
-        rc = c.wait()
-        if rc != 0:
-            worst = max(worst, rc if rc > 0 else 1)
-    return worst
+    codes = [c.wait() for c in children]
+    reader.join(timeout=10)
+    return codes, (captured[0] if captured else b"")
+
+
+def launch_ranks(n_ranks: int, baseline=None) -> int:
+    """
+    `python bench.py --gpus N` without a launcher around it: become one.  N children of this very command, one
+    per GPU, each with RANK / LOCAL_RANK / WORLD_SIZE and the same rendezvous key, started BEFORE this process has
+    touched the GPU (it never does: no re-exec of a process that has opened the device).  Rank 0's stdout is the run's
+    JSON line, the other ranks' stdout goes to stderr.  Returns the worst exit code; when a rank fails the others get a
+    grace period to notice through the rendezvous, then they are ended by pid.
+
+    `baseline`: the CPU-baseline legs, run by this parent before it starts the children (they fork worker processes
+    and take ~25 s: not something a rank should do while its peers wait at the rendezvous); rank 0 puts it in the line.
+
+    ONE retry: the ranks run with HSA_ENABLE_IPC_MODE_LEGACY=0 unless the caller's environment says otherwise -- this
+    pool's images export it, and its documentation gives the reason: the host driver supports dmabuf IPC only, without
+    it RCCL across processes fails in hipIpcGetMemHandle.  The builder has had no multi-GPU box to confirm it on.  If
+    EVERY rank comes back with exit code 3 and rank 0's line says the communicator could not be built, the launcher
+    -- which has not touched the GPU -- starts a second, fresh set of ranks with the variable UNSET and marks the
+    line (`config.launcher_retry`).
+    """
+    import secrets
+    import tempfile
+
+    env = dict(os.environ)
+    env.update(WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_PORT", "0")
+    handed = None
+    if baseline is not None:
+        with tempfile.NamedTemporaryFile("w", suffix=".json", prefix="lynx-cpu-baseline-", delete=False) as fh:
+            json.dump(baseline, fh)
+            handed = fh.name
+        env["LYNX_BENCH_CPU_BASELINE_FILE"] = handed
+    try:
+        for attempt in (0, 1):
+            env["LYNX_RDZV_KEY"] = f"bench-{os.getpid()}-{secrets.token_hex(8)}"
+            codes, line = _run_ranks(n_ranks, env)
+            rccl_failed = all(c == 3 for c in codes) and b'"rccl-failed"' in line
+            if attempt == 0 and rccl_failed and "HSA_ENABLE_IPC_MODE_LEGACY" in env:
+                print(f"[launcher] every rank failed to build its RCCL communicator with HSA_ENABLE_IPC_MODE_LEGACY="
+                      f"{env['HSA_ENABLE_IPC_MODE_LEGACY']}; one more set of ranks with the variable unset", file=sys.stderr, flush=True)
+                env["LYNX_LAUNCHER_RETRY"] = f"second set of ranks, HSA_ENABLE_IPC_MODE_LEGACY unset (first set with ={env.pop('HSA_ENABLE_IPC_MODE_LEGACY')}: RCCL bring-up failed on every rank)"
+                continue
+            break
+    finally:
+        if handed:
+            try:
+                os.unlink(handed)
+            except OSError:
+                pass
+    sys.stdout.buffer.write(line)
+    sys.stdout.flush()
+    return max([0] + [c if c > 0 else 1 for c in codes if c != 0])
 
 
 def main():
@@ -347,7 +422,14 @@ def main():
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(launch_ranks(args.gpus))  # nothing has touched the GPU yet
+        # nothing has touched the GPU yet, and this process never will: CPU baseline here, then the ranks
+        w = WORKLOADS[args.workload]
+        parent_baseline = None
+        # (a rehearsal runs it only when a test asks for it: LYNX_BENCH_TEST_CPU_BASELINE=1)
+        if not args.no_cpu_baseline and (not args.rendezvous_only or os.environ.get("LYNX_BENCH_TEST_CPU_BASELINE") == "1"):
+            parent_baseline = cpu_baseline(args.workload, args.particles or w[1], w[2], np.dtype(w[3]).type,
+                                           budget_s=float(os.environ.get("LYNX_BENCH_CPU_BUDGET_S", "10")))
+        sys.exit(launch_ranks(args.gpus, parent_baseline))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
@@ -363,7 +445,13 @@ def main():
     # CPU baseline first: it forks worker processes, which must happen before this process opens the GPU
     baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.rendezvous_only:
-        baseline = cpu_baseline(args.workload, particles, cells, dtype)
+        baseline = cpu_baseline(args.workload, particles, cells, dtype,
+                                budget_s=float(os.environ.get("LYNX_BENCH_CPU_BUDGET_S", "10")))
+    elif rank == 0 and os.environ.get("LYNX_BENCH_CPU_BASELINE_FILE"):  # the launcher parent ran it (N > 1)
+        try:
+            baseline = json.loads(Path(os.environ["LYNX_BENCH_CPU_BASELINE_FILE"]).read_text())
+        except (OSError, ValueError) as exc:
+            print(f"cpu baseline of the launcher not readable: {exc}", file=sys.stderr)
 
     from lynx_amd.rendezvous import Rendezvous
 
@@ -382,6 +470,10 @@ def main():
               "launcher": "none (one process)" if world == 1 and "WORLD_SIZE" not in os.environ
                           else "torchrun/external" if os.environ.get("TORCHELASTIC_RUN_ID") or "LYNX_RDZV_KEY" not in os.environ
                           else "bench.py"}
+    if os.environ.get("LYNX_LAUNCHER_RETRY"):
+        config["launcher_retry"] = os.environ["LYNX_LAUNCHER_RETRY"]
+    if world > 1:
+        config["HSA_ENABLE_IPC_MODE_LEGACY"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
     scaling = "weak" if (args.weak and world > 1) else "strong"
 
     if args.rendezvous_only:
@@ -399,11 +491,19 @@ def main():
             if strong and batch == 1:
                 assert sum(p[2] for p in plan) == particles
             assert slowest == world - 1
-            print(json.dumps({"metric": METRIC, "value": None, "unit": "particle-element-steps/s", "n_gpus": world,
-                              "steps": args.steps, "warmup": args.warmup, "scaling": scaling, "dry_run": True,
-                              "config": dict(config, shard_plan=[{"first_sample": p[0], "samples": p[1], "particles": p[2]}
-                                                                 for p in plan])}))
+            line = {"metric": METRIC, "value": None, "unit": "particle-element-steps/s", "n_gpus": world,
+                    "steps": args.steps, "warmup": args.warmup, "scaling": scaling, "dry_run": True,
+                    "config": dict(config, shard_plan=[{"first_sample": p[0], "samples": p[1], "particles": p[2]}
+                                                       for p in plan])}
+            if baseline is not None:
+                line["cpu_baseline"] = baseline
+            # rehearsal of the launcher's one retry (tests/test_distributed.py): behave like ranks whose RCCL bring-up failed
+            if os.environ.get("LYNX_BENCH_TEST_RCCL_FAILS_WITH_IPC_LEGACY") and "HSA_ENABLE_IPC_MODE_LEGACY" in os.environ:
+                line["config"]["gather"] = "rccl-failed"
+            print(json.dumps(line))
         rdzv.close()
+        if os.environ.get("LYNX_BENCH_TEST_RCCL_FAILS_WITH_IPC_LEGACY") and "HSA_ENABLE_IPC_MODE_LEGACY" in os.environ:
+            sys.exit(3)
         sys.exit(int(os.environ.get("LYNX_BENCH_TEST_EXIT", "0")) if rank == int(os.environ.get("LYNX_BENCH_TEST_EXIT_RANK", "-1")) else 0)
 
     import lynx_amd as lx
@@ -417,9 +517,8 @@ def main():
     config["elements"] = n_elements
     batch = my_batch        # from here on: this rank's samples and particles
     particles = my_particles
-    beam = lx.ParticleBeam.synthetic((1,) if args.shared_input else (batch,), particles,
-                                     sigma=[1e-4, 1e-5, 1e-4, 1e-5, 1e-5, 1e-3],
-                                     energy=6e6 if args.workload == "c5" else 1e8, seed=2 + rank, dtype=dtype)
+    beam = lx.ParticleBeam.synthetic((1,) if args.shared_input else (batch,), particles, sigma=BEAM_SIGMA,
+                                     energy=beam_energy(args.workload), seed=2 + rank, dtype=dtype)
     if args.shared_input:
         beam = beam.broadcast((batch,))
         assert beam.is_shared
@@ -490,6 +589,7 @@ def main():
         parts = rdzv.all_gather(mine.tobytes())
         return out, np.stack([np.frombuffer(p, dtype=np.float64).reshape(rows, 36) for p in parts])
 
+    last = None
     for _ in range(args.warmup):
         last = step()
     rt.sync()
@@ -514,20 +614,35 @@ def main():
             print(f"copy calibration failed: {exc}", file=sys.stderr)
             return None
 
+    def timed(steps):
+        """K steps between two barriers -> (slowest rank's seconds, this rank's seconds, kernel ms, launches, per-launch ms, gather ms)."""
+        nonlocal last
+        rdzv.barrier()
+        rt.sync()
+        if not args.no_kernel_timing:
+            rt.profile_begin()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            last = step()
+        rt.sync()
+        mine = time.perf_counter() - t0  # this rank's K steps, GPU drained
+        rdzv.barrier()
+        kern_ms, launches = rt.profile_end() if not args.no_kernel_timing else (0.0, 0)
+        per_launch = rt.profile_launches() if not args.no_kernel_timing else []
+        gathers = rt.profile_gathers() if not args.no_kernel_timing else []
+        return rdzv.max(mine), mine, kern_ms, launches, per_launch, gathers
+
+    # The same K steps twice.  COLD: right behind the W warm-up steps, as the command line says -- this is what a short
+    # job sees (`ms_per_step_cold`, `launch_ms_cold`).  Then the calibration copies, then the K steps `value` is
+    # computed from (LYNX_BENCH_CALIBRATE_FIRST=0: no cold leg, calibration behind the timed region).
+    cold = None
     if calibrate_first:
+        cold = timed(args.steps)
         copy_gbs = calibrate()
-    rdzv.barrier()
-    rt.sync()
-    if not args.no_kernel_timing:
-        rt.profile_begin()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        last = step()
-    rt.sync()
-    elapsed = time.perf_counter() - t0  # this rank's K steps, GPU drained
-    rdzv.barrier()
-    kern_ms, launches = rt.profile_end() if not args.no_kernel_timing else (0.0, 0)
-    elapsed = rdzv.max(elapsed)  # the slowest rank's clock between the two barriers
+    elapsed, my_elapsed, kern_ms, launches, per_launch, gather_ms = timed(args.steps)
+    import struct
+
+    per_rank_s = [struct.unpack("<d", b)[0] for b in rdzv.all_gather(struct.pack("<d", my_elapsed))]
 
     # sanity on the last result (outside the timed region): finite moments, right count
     out, gathered = last
@@ -595,6 +710,9 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            # the same K steps right behind the W warm-up steps, before the calibration copies (the streaming kernel's
+            # start-up transient, DESIGN.md section 5, is in this figure and mostly out of `ms_per_step`)
+            "ms_per_step_cold": (cold[0] / args.steps * 1e3) if cold else None,
             "higher_is_better": True,
             "scaling": scaling,
             "vs_baseline": None,
@@ -607,14 +725,25 @@ def main():
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "avg_launch_ms": kern_s * 1e3, "launches": launches},
+                         "avg_launch_ms": kern_s * 1e3, "launches": launches,
+                         "avg_launch_ms_cold": (cold[2] / max(cold[3], 1)) if cold else None,
+                         # every launch of the timed steps, in order (at most the first 64 of each leg)
+                         "launch_ms": [round(v, 4) for v in per_launch[:64]],
+                         "launch_ms_cold": [round(v, 4) for v in cold[4][:64]] if cold else None},
             "hbm_gbs_whole_step": (alg_bytes if args.shared_input else 2 * passes * 7 * itemsize) * args.steps / elapsed / 1e9,
             # the practical ceiling: best plain-copy shape measured in this process (MI355X_MICROARCH.md: ~6.3 TB/s)
             "hbm_copy_kernel_gbs": max(copy_gbs.values()) if copy_gbs else None,
             "hbm_copy_kernel_shapes": copy_gbs,
-            "hbm_copy_kernel_when": "between warm-up and timed region" if calibrate_first else "after the timed region",
+            "hbm_copy_kernel_when": "between the cold leg (W warm-up steps + K timed steps: ms_per_step_cold) and the timed region of `value`"
+                                    if calibrate_first else "after the timed region",
             "device": rt.info(),
         }
+        if world > 1 or comm is not None:
+            # diagnosis of a scaling result from ONE run: every rank's own clock, and what the gathers took on the stream
+            # they ran on (with more than one rank that includes the wait for the slowest rank of the step)
+            result["ms_per_step_per_rank"] = [round(t / args.steps * 1e3, 5) for t in per_rank_s]
+            result["gather_ms"] = {"n": len(gather_ms), "mean": float(np.mean(gather_ms)) if gather_ms else None,
+                                   "max": float(np.max(gather_ms)) if gather_ms else None, "rank": 0}
         if baseline is not None:
             result["cpu_baseline"] = baseline
         print(json.dumps(result))

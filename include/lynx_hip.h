@@ -148,6 +148,16 @@ int lynx_timer_stop(lynx_ctx* ctx, float* elapsed_ms);
  * figure bench.py's roofline uses; it matches rocprofv3's per-kernel duration. */
 int lynx_profile_begin(lynx_ctx* ctx);
 int lynx_profile_end(lynx_ctx* ctx, double* total_ms, int64_t* launches);
+/* every launch of the profile that lynx_profile_end closed last, in launch order: up to `capacity` durations in
+ * milliseconds into ms_out, their number into *launches (bench.py: the per-launch curve of the timed steps) */
+int lynx_profile_launches(lynx_ctx* ctx, double* ms_out, int64_t capacity, int64_t* launches);
+/* ... and every lynx_gather_moments of that profile: its duration on the stream it ran on (with more than one rank
+ * this includes the wait for the slowest rank) */
+int lynx_profile_gathers(lynx_ctx* ctx, double* ms_out, int64_t capacity, int64_t* gathers);
+/* The launch-plan switches (environment variables LYNX_XPOSE, LYNX_UNROLL, ... -- listed with what each selects at
+ * `struct Knobs` in lynx_amd/csrc/lynx_hip.hip) are read ONCE, by lynx_ctx_create; a tracking call reads none.  This
+ * reads them again: for tests and A/B scripts that change the environment of a live context.                       */
+int lynx_ctx_reload_knobs(lynx_ctx* ctx);
 
 /* Calibration: average time of a plain 16-byte-per-lane copy of `bytes` (read + write),
  * i.e. the practical HBM ceiling of this GPU for a stream shaped like a tracking pass.

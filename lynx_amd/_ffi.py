@@ -69,6 +69,9 @@ SIGNATURES = {
     "lynx_timer_stop": (_i, [_vp, C.POINTER(C.c_float)]),
     "lynx_profile_begin": (_i, [_vp]),
     "lynx_profile_end": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "lynx_profile_launches": (_i, [_vp, C.POINTER(C.c_double), _i64, C.POINTER(C.c_int64)]),
+    "lynx_profile_gathers": (_i, [_vp, C.POINTER(C.c_double), _i64, C.POINTER(C.c_int64)]),
+    "lynx_ctx_reload_knobs": (_i, [_vp]),
     "lynx_diag_copy": (_i, [_vp, _vp, _vp, _sz, _i, _i, C.POINTER(C.c_float)]),
     "lynx_buf_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "lynx_buf_free": (_i, [_vp, _vp]),

@@ -1069,7 +1069,6 @@ struct TrackArgs {
   int32_t store;         // 1: write p_out
   int32_t lds_scratch_bytes;  // build scratch / moment-reduction slab in front of the step table
   int32_t build_chunk;   // fused prologue: elements per compose round
-  int32_t interleave;    // 1 = a workgroup takes every `chunks`-th tile
   int64_t in_stride;     // scalars between the samples of p_in: N*7, or 0 for one shared incoming beam
   int32_t merged_pairs;  // the step table holds [run, cavity] pairs in merged form (the builder marks them: LYNX_DESC_PAIR)
   int32_t n_observers;   // LYNX_STEP_FLAG_OBSERVE steps of the program (their sums live behind the step table in LDS)
@@ -1605,16 +1604,15 @@ __global__ __launch_bounds__(kTrackThreads, (track_waves_per_simd<T, MOM, FULL, 
   const int chunk = blockIdx.x % a.chunks;
   const int64_t end = a.n_particles;
   const int S = lat.n_steps;
-  // This workgroup's `a.tiles_per_wg` tiles of 256*UNROLL particles: either one contiguous
-  // stretch, or (a.interleave) every `chunks`-th tile, so that the workgroups of a sample
-  // advance through it side by side.
+  // This workgroup's `a.tiles_per_wg` tiles of 256*UNROLL particles: one contiguous stretch (taking every
+  // `chunks`-th tile instead, so that a sample's workgroups advance side by side, measured 2-5 % slower).
   constexpr int64_t kTile = (int64_t)kTrackThreads * UNROLL;
   constexpr int64_t kWaveSpan = 64 * UNROLL;  // XPOSE: particles of a wave tile
   // first particle of this lane within a tile, and the distance between its UNROLL particles
   const int64_t lane_first = XPOSE ? (int64_t)wave * kWaveSpan + (int64_t)lane * UNROLL : (int64_t)tid;
   constexpr int64_t kLaneStep = XPOSE ? 1 : kTrackThreads;
   unsigned char* s_wave = s_scratch + wave * kWaveTileBytes;  // XPOSE: this wave's private tile
-#define LYNX_TILE_OF(IT) (a.interleave ? ((int64_t)(IT)*a.chunks + chunk) : ((int64_t)chunk * a.tiles_per_wg + (IT)))
+#define LYNX_TILE_OF(IT) ((int64_t)chunk * a.tiles_per_wg + (IT))
 #define LYNX_WAVE_BASE(TILE) ((TILE)*kTile + (int64_t)wave * kWaveSpan)
 
   // Software pipeline: the loads of a tile are issued one iteration ahead (the first ones

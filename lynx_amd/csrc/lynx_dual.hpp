@@ -56,6 +56,24 @@ LYNX_DUAL_ALL(double)
 #undef LYNX_DUAL_ALL
 #undef LYNX_DUAL_FN
 
+// cavity_r55_bracket (lynx_maps.hpp) without its cancellations: with a = 1/g0^2, b = 1/g1^2,
+//   beta0 beta1 - 1 = ((1 - a)(1 - b) - 1) / (beta0 beta1 + 1) = -(a + b - a b) / (1 + beta0 beta1)          =: -eps
+//   g0 g1 (a + b - a b) = g1/g0 + g0/g1 - 1/(g0 g1) = 2 + ((g0 - g1)^2 - 1) / (g0 g1)                          =: 2 + u
+//   bracket = 1 - (2 + u) / (1 + beta0 beta1) = ((2 - eps) - (2 + u)) / (2 - eps) = -(eps + u) / (1 + beta0 beta1)
+// eps and u are small and (for an energy change of more than one rest mass) of one sign.
+template <typename R> LYNX_HD Dual<R> cavity_r55_bracket_dual(Dual<R> g0, Dual<R> g1, Dual<R> beta0, Dual<R> beta1) {
+  const Dual<R> one(R(1));
+  const Dual<R> a = one / (g0 * g0), b = one / (g1 * g1), sum = one + beta0 * beta1;
+  const Dual<R> eps = (a + b - a * b) / sum, dg = g0 - g1, u = (dg * dg - one) / (g0 * g1);
+  return -(eps + u) / sum;
+}
+template <> LYNX_HD Dual<float> cavity_r55_bracket<Dual<float>>(Dual<float> g0, Dual<float> g1, Dual<float> b0, Dual<float> b1) {
+  return cavity_r55_bracket_dual<float>(g0, g1, b0, b1);
+}
+template <> LYNX_HD Dual<double> cavity_r55_bracket<Dual<double>>(Dual<double> g0, Dual<double> g1, Dual<double> b0, Dual<double> b1) {
+  return cavity_r55_bracket_dual<double>(g0, g1, b0, b1);
+}
+
 template <> LYNX_HD Dual<float> t_fma<Dual<float>>(Dual<float> a, Dual<float> b, Dual<float> c) { return a * b + c; }
 template <> LYNX_HD Dual<double> t_fma<Dual<double>>(Dual<double> a, Dual<double> b, Dual<double> c) { return a * b + c; }
 

@@ -204,6 +204,88 @@ __device__ __forceinline__ void zapply(const float* m, int kind, int flags, floa
 __device__ __forceinline__ void zapply(const double* m, int kind, int flags, double (&z)[7]) { apply_step<double>(m, kind, flags, z); }
 __device__ __forceinline__ void zapply(const float* m, int kind, int flags, lynx_f32x2 (&z)[7]) { apply_step_pair(m, kind, flags, z); }
 
+// sin(d) and cos(d) - 1, the second WITHOUT the cancellation of `cos(d) - 1` (d is s beta0 k: milliradians)
+__device__ __forceinline__ void sin_cosm1(double d, double& sd, double& cm1) {
+  sd = t_sin(d);
+  const double h = t_sin(0.5 * d);
+  cm1 = -2.0 * h * h;
+}
+__device__ __forceinline__ void sin_cosm1(float d, float& sd, float& cm1) {
+  if (__builtin_expect(__builtin_fabsf(d) <= 0.75f, 1)) {  // the polynomials of sincos_reduced, quadrant 0, without the "1 +"
+    const float z = d * d;
+    float ps = fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = fmaf(ps, z, -1.6666654611e-1f);
+    sd = fmaf(ps * z, d, d);
+    float pc = fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = fmaf(pc, z, 4.166664568298827e-2f);
+    cm1 = fmaf(pc * z, z, z * -0.5f);
+  } else {
+    float sh, ch;
+    phase_sincos(0.5f * d, sh, ch);
+    sd = 2.0f * sh * ch;
+    cm1 = -2.0f * sh * sh;
+  }
+}
+__device__ __forceinline__ void sin_cosm1(lynx_f32x2 d, lynx_f32x2& sd, lynx_f32x2& cm1) {
+  const float big = __builtin_fmaxf(__builtin_fabsf(d.x), __builtin_fabsf(d.y));
+  if (__builtin_amdgcn_ballot_w64(!(big <= 0.75f)) == 0) {  // whole wave (as good as always): packed
+    const lynx_f32x2 z = d * d;
+    lynx_f32x2 ps = vfma(z, lynx_f32x2(-1.9515295891e-4f), lynx_f32x2(8.3321608736e-3f));
+    ps = vfma(ps, z, lynx_f32x2(-1.6666654611e-1f));
+    sd = vfma(ps * z, d, d);
+    lynx_f32x2 pc = vfma(z, lynx_f32x2(2.443315711809948e-5f), lynx_f32x2(-1.388731625493765e-3f));
+    pc = vfma(pc, z, lynx_f32x2(4.166664568298827e-2f));
+    cm1 = vfma(pc * z, z, z * -0.5f);
+    return;
+  }
+  float s0, c0, s1, c1;
+  sin_cosm1(d.x, s0, c0);
+  sin_cosm1(d.y, s1, c1);
+  sd = lynx_f32x2{s0, s1};
+  cm1 = lynx_f32x2{c0, c1};
+}
+
+// Cotangents of an active cavity's kick (cavity.py:141-161, 219-226), shared by the three reverse kernels:
+//   o5 = z5 c0 + c1 (cos(a) - c4),  a = -z4 c2 + c3;   o4 = o4_lin + c5 z5^2 + c6 z4 z5 + c7 z4^2
+// with z4, z5 the s and delta that ENTER the cavity, o4b / o5b the cotangents of its outputs.  -> the eight coefficient
+// cotangents cc[LYNX_C_*] and the direct terms d/dz4, d/dz5.
+// The forward value repeats the reference's operations, cancellation included.  Its DERIVATIVES need the differences
+// sin(a) - sin(phi) (phase) and cos(a) - cos(phi) (voltage) once more, and those are formed here without the
+// cancellation, from d = a - phi = -z4 c2 (milliradians) and the addition theorems:
+//   sin a - sin phi = sin phi (cos d - 1) + cos phi sin d,   cos a - cos phi = cos phi (cos d - 1) - sin phi sin d.
+// The phase cotangent is handed over COMPLETE -- d/dc3 and the path through c4 = cos(phi) in one number, c4's own slot
+// stays zero --, because as two separate sums over the particles (sum -o5b c1 sin a and sum -o5b c1, the second times
+// -sin phi in k_build_bwd) they cancel to 1/300 of their size on a 10 um bunch: float32 gradients w.r.t. the phase were
+// 1e-2 away from the float64 pass that way, voltage 2e-3 (tests/test_gpu_grad.py, BASELINE config 5 at its shape).
+template <typename T, typename Z>
+__device__ __forceinline__ void kick_cotangents(const T* cf, T sphi, T cphi, Z z4, Z z5, Z o4b, Z o5b, Z (&cc)[8], Z& dir4,
+                                                Z& dir5) {
+  const Z d = T(-1) * z4 * cf[LYNX_C_BK];
+  Z sd, cm1;
+  sin_cosm1(d, sd, cm1);
+  const Z dsin = zfma(sd, cphi, cm1 * sphi);            // sin(a) - sin(phi)
+  const Z dcos = zfma(sd, -sphi, cm1 * cphi);           // cos(a) - cos(phi)
+  const Z sa = dsin + sphi;
+  const Z ab = -o5b * cf[LYNX_C_DKICK] * sa;            // cotangent of a through the cosine
+  cc[LYNX_C_DSCALE] = o5b * z5;
+  cc[LYNX_C_DKICK] = o5b * dcos;
+  cc[LYNX_C_BK] = ab * (-z4);
+  cc[LYNX_C_PHI] = -o5b * cf[LYNX_C_DKICK] * dsin;      // complete: d/dc3 - sin(phi) d/dc4
+  cc[LYNX_C_COSPHI] = Z(T(0));
+  cc[LYNX_C_T566] = o4b * (z5 * z5);
+  cc[LYNX_C_T556] = o4b * (z4 * z5);
+  cc[LYNX_C_T555] = o4b * (z4 * z4);
+  dir4 = ab * (-cf[LYNX_C_BK]) + o4b * (cf[LYNX_C_T556] * z5 + T(2) * cf[LYNX_C_T555] * z4);
+  dir5 = o5b * cf[LYNX_C_DSCALE] + o4b * (T(2) * cf[LYNX_C_T566] * z5 + cf[LYNX_C_T556] * z4);
+}
+// sine and cosine of the cavity's phase, once per unit (wave-uniform)
+template <typename T> __device__ __forceinline__ void phase_of(T phi, T& sphi, T& cphi) {
+  T s, c;
+  phase_sincos(phi, s, c);
+  sphi = uniform_value(s);
+  cphi = uniform_value(c);
+}
+
 // one unit of the forward / recompute sweeps
 template <typename T, typename Z>
 __device__ __forceinline__ void apply_unit(const T* g_steps, int slot, Z (&z)[7]) {
@@ -388,21 +470,9 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
         if (kick) {
           // o5' = z5 c0 + c1 (cos(a) - c4), a = -z4 c2 + c3 ; o4' = o4 + c5 z5^2 + c6 z4 z5 + c7 z4^2
           const T* cf = m + LYNX_COEF_OFFSET;
-          const Z z4 = s_in, z5 = d_in, o4b = zb[4], o5b = zb[5];
-          const Z arg = T(-1) * z4 * cf[LYNX_C_BK] + cf[LYNX_C_PHI];
-          Z ca, sa;
-          zsincos(arg, sa, ca);
-          const Z ab = -o5b * cf[LYNX_C_DKICK] * sa;
-          cc[LYNX_C_DSCALE] = o5b * z5;
-          cc[LYNX_C_DKICK] = o5b * (ca - cf[LYNX_C_COSPHI]);
-          cc[LYNX_C_BK] = ab * (-z4);
-          cc[LYNX_C_PHI] = ab;
-          cc[LYNX_C_COSPHI] = -o5b * cf[LYNX_C_DKICK];
-          cc[LYNX_C_T566] = o4b * (z5 * z5);
-          cc[LYNX_C_T556] = o4b * (z4 * z5);
-          cc[LYNX_C_T555] = o4b * (z4 * z4);
-          dir4 = ab * (-cf[LYNX_C_BK]) + o4b * (cf[LYNX_C_T556] * z5 + T(2) * cf[LYNX_C_T555] * z4);
-          dir5 = o5b * cf[LYNX_C_DSCALE] + o4b * (T(2) * cf[LYNX_C_T566] * z5 + cf[LYNX_C_T556] * z4);
+          T sphi, cphi;
+          phase_of<T>(cf[LYNX_C_PHI], sphi, cphi);
+          kick_cotangents<T, Z>(cf, sphi, cphi, s_in, d_in, zb[4], zb[5], cc, dir4, dir5);
           olin[5] = Z(T(0));  // the linear delta was overwritten
         }
 
@@ -622,20 +692,16 @@ __global__ __launch_bounds__(64) void k_moments_bwd(LatticeDev lat, const T* __r
       const T z4 = s_mu[4], z5 = s_mu[5], c44 = s_c[32], c45 = s_c[33], c55 = s_c[40];
       const T m4 = s_mb[4], m5 = s_mb[5];
       const T vb = s_g[32] + s_g[33] + s_g[39];
-      const T arg = T(-1) * z4 * cf[LYNX_C_BK] + cf[LYNX_C_PHI];
-      T sa, ca;
-      phase_sincos(arg, sa, ca);
-      const T ab = -m5 * cf[LYNX_C_DKICK] * sa;
-      s_k[LYNX_C_DSCALE] = m5 * z5;
-      s_k[LYNX_C_DKICK] = m5 * (ca - cf[LYNX_C_COSPHI]);
-      s_k[LYNX_C_BK] = ab * (-z4);
-      s_k[LYNX_C_PHI] = ab;
-      s_k[LYNX_C_COSPHI] = -m5 * cf[LYNX_C_DKICK];
-      s_k[LYNX_C_T566] = vb * (c55 * c55) + m4 * (z5 * z5);
-      s_k[LYNX_C_T556] = vb * (c45 * c55) + m4 * (z4 * z5);
-      s_k[LYNX_C_T555] = vb * (c44 * c44) + m4 * (z4 * z4);
-      s_k[8] = ab * (-cf[LYNX_C_BK]) + m4 * (cf[LYNX_C_T556] * z5 + T(2) * cf[LYNX_C_T555] * z4);   // d/d mu_in[4]
-      s_k[9] = m5 * cf[LYNX_C_DSCALE] + m4 * (T(2) * cf[LYNX_C_T566] * z5 + cf[LYNX_C_T556] * z4);  // d/d mu_in[5]
+      T sphi, cphi, kc[8], d4, d5;
+      phase_sincos(cf[LYNX_C_PHI], sphi, cphi);
+      kick_cotangents<T, T>(cf, sphi, cphi, z4, z5, m4, m5, kc, d4, d5);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s_k[q] = kc[q];
+      s_k[LYNX_C_T566] += vb * (c55 * c55);
+      s_k[LYNX_C_T556] += vb * (c45 * c55);
+      s_k[LYNX_C_T555] += vb * (c44 * c44);
+      s_k[8] = d4;  // d/d mu_in[4]
+      s_k[9] = d5;  // d/d mu_in[5]
       s_k[10] = vb * T(2) * cf[LYNX_C_T555] * c44;                                                   // d/d c44
       s_k[11] = vb * cf[LYNX_C_T556] * c55;                                                          // d/d c45
       s_k[12] = s_g[40] + vb * (T(2) * cf[LYNX_C_T566] * c55 + cf[LYNX_C_T556] * c45);               // d/d c55

@@ -209,21 +209,9 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_bwd_units(
         if (kick) {
           // o5' = z5 c0 + c1 (cos(a) - c4), a = -z4 c2 + c3 ; o4' = o4 + c5 z5^2 + c6 z4 z5 + c7 z4^2   (k_track_bwd)
           const T* cf = kickr.v + kUnitCoef;
-          const Z z4 = s_in, z5 = d_in, o4b = zb[4], o5b = zb[5];
-          const Z arg = T(-1) * z4 * cf[LYNX_C_BK] + cf[LYNX_C_PHI];
-          Z ca, sa;
-          zsincos(arg, sa, ca);
-          const Z ab = -o5b * cf[LYNX_C_DKICK] * sa;
-          cc[LYNX_C_DSCALE] = o5b * z5;
-          cc[LYNX_C_DKICK] = o5b * (ca - cf[LYNX_C_COSPHI]);
-          cc[LYNX_C_BK] = ab * (-z4);
-          cc[LYNX_C_PHI] = ab;
-          cc[LYNX_C_COSPHI] = -o5b * cf[LYNX_C_DKICK];
-          cc[LYNX_C_T566] = o4b * (z5 * z5);
-          cc[LYNX_C_T556] = o4b * (z4 * z5);
-          cc[LYNX_C_T555] = o4b * (z4 * z4);
-          dir4 = ab * (-cf[LYNX_C_BK]) + o4b * (cf[LYNX_C_T556] * z5 + T(2) * cf[LYNX_C_T555] * z4);
-          dir5 = o5b * cf[LYNX_C_DSCALE] + o4b * (T(2) * cf[LYNX_C_T566] * z5 + cf[LYNX_C_T556] * z4);
+          T sphi, cphi;
+          phase_of<T>(cf[LYNX_C_PHI], sphi, cphi);
+          kick_cotangents<T, Z>(cf, sphi, cphi, s_in, d_in, zb[4], zb[5], cc, dir4, dir5);
           olin[5] = Z(T(0));  // the linear delta was overwritten
         }
 

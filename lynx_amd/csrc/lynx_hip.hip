@@ -24,9 +24,55 @@
 
 using namespace lynx;
 
-static int env_int(const char* name, int dflt);
+// Launch-plan switches.  The planner picks a form of the computation by shape (wave tiles or per-particle accesses,
+// particles per lane, which stream builds and reduces, ...); every knob forces one of the forms it would otherwise pick
+// for another shape, for tests (test_every_kernel_variant_gives_the_default_answer) and the A/B scripts under
+// scripts/gpu/.  They are read from the environment ONCE, when the context is created (lynx_ctx_reload_knobs reads them
+// again); a `track` call reads none.  -1 = not set: the planner decides.
+struct Knobs {
+  int xpose = -1;             // LYNX_XPOSE             wave tiles through LDS (1) / per-particle accesses (0)
+  int unroll = -1;            // LYNX_UNROLL            particles per lane: 1 | 2 | 4
+  int mom = -1;               // LYNX_MOM               moment accumulation mode of the float32 kernels: 2 | 3
+  int min_tiles_per_wg = -1;  // LYNX_MIN_TILES_PER_WG
+  int async_build = -1;       // LYNX_ASYNC_BUILD       build on the second stream (1) / in line (0)
+  int side_reduce = -1;       // LYNX_SIDE_REDUCE       moment reduction on the side stream (1) / in line (0)
+  int build_host_wait = -1;   // LYNX_BUILD_HOST_WAIT   the host (1) / the main stream (0) waits for an asynchronous build
+  int gather_overlap = -1;    // LYNX_GATHER_OVERLAP    RCCL gather on the side stream (1) / in line (0)
+  int lanes_build_min_batch = 256;  // LYNX_LANES_BUILD_MIN_BATCH  lanes = samples build from this batch on
+  int piece = 8;              // LYNX_PIECE             elements per piece of the lanes build (tests: 1 and 3 make short lattices grow a pair tree)
+  int pair_levels_fused = 1;  // LYNX_PAIR_LEVELS_FUSED narrow pair trees in one launch (wide ones always take one per level)
+  int fuse_max_chunks = 0;    // LYNX_FUSE_MAX_CHUNKS   fused build prologue for samples of <= n workgroups (0: never)
+  int merge_steps = 1;        // LYNX_MERGE_STEPS       [run, cavity] pairs as one unit
+  int reduce_wide = 1;        // LYNX_REDUCE_WIDE       one 1024-thread reduction for beams of few samples
+  int track_units = 1;        // LYNX_TRACK_UNITS       structured step loop (2: insist)
+  int bwd_units = 1;          // LYNX_BWD_UNITS         structured reverse pass
+  int bwd_merge = 1;          // LYNX_BWD_MERGE         merged pairs in the reverse pass
+  int bwd_pairs = 1;          // LYNX_BWD_PAIRS         two particles per lane in the float32 reverse pass
+  int build_in_tail = 1;      // LYNX_BUILD_IN_TAIL     start the next build in the tail of the streaming kernel
+  int small_inline = -1;      // LYNX_SMALL_INLINE      short calls: build, stream and reduce back to back on ONE stream, no events
+};
+
+static void load_knobs(Knobs* k) {
+  *k = Knobs();
+  const struct { const char* name; int* value; } table[] = {
+      {"LYNX_XPOSE", &k->xpose}, {"LYNX_UNROLL", &k->unroll}, {"LYNX_MOM", &k->mom},
+      {"LYNX_MIN_TILES_PER_WG", &k->min_tiles_per_wg}, {"LYNX_ASYNC_BUILD", &k->async_build},
+      {"LYNX_SIDE_REDUCE", &k->side_reduce}, {"LYNX_BUILD_HOST_WAIT", &k->build_host_wait},
+      {"LYNX_GATHER_OVERLAP", &k->gather_overlap}, {"LYNX_LANES_BUILD_MIN_BATCH", &k->lanes_build_min_batch},
+      {"LYNX_PIECE", &k->piece}, {"LYNX_PAIR_LEVELS_FUSED", &k->pair_levels_fused},
+      {"LYNX_FUSE_MAX_CHUNKS", &k->fuse_max_chunks}, {"LYNX_MERGE_STEPS", &k->merge_steps},
+      {"LYNX_REDUCE_WIDE", &k->reduce_wide}, {"LYNX_TRACK_UNITS", &k->track_units}, {"LYNX_BWD_UNITS", &k->bwd_units},
+      {"LYNX_BWD_MERGE", &k->bwd_merge}, {"LYNX_BWD_PAIRS", &k->bwd_pairs}, {"LYNX_BUILD_IN_TAIL", &k->build_in_tail},
+      {"LYNX_SMALL_INLINE", &k->small_inline}};
+  for (const auto& t : table) {
+    const char* v = getenv(t.name);
+    if (v && *v) *t.value = atoi(v);
+  }
+}
+static inline int knob(int value, int dflt) { return value >= 0 ? value : dflt; }
 
 struct lynx_ctx {
+  Knobs knobs;
   int device = 0;
   hipStream_t stream = nullptr;
   // Second stream for k_build.  The map build of a `track` call depends on the lattice and the
@@ -122,6 +168,9 @@ struct lynx_ctx {
   // per-launch profiling of k_track (lynx_profile_begin / _end)
   bool profiling = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  std::vector<double> prof_ms;  // every launch of the last finished profile, in launch order
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_gather_events;  // ... and every RCCL gather (on the stream it ran on)
+  std::vector<double> prof_gather_ms;
   hipEvent_t last_stream_stop = nullptr;
 };
 
@@ -150,12 +199,14 @@ struct lynx_lattice {
   BuildPiece* d_pieces = nullptr;
   PairTask* d_tasks = nullptr;
   int32_t* d_step_slot = nullptr;
-  // multi-step float32 programs as units (lynx_units.hpp): the plan for `units_key` (-1: none yet; else the `merged`
-  // flag it was made for), whether the program fits it, and what k_emit_steps is told about every step
-  UnitPlan units;
-  int units_key = -1;
-  bool units_ok = false;
-  int32_t* d_step_unit = nullptr;
+  // multi-step float32 programs as units (lynx_units.hpp), one plan per value of `merged` (the forward and the reverse
+  // pass may disagree about it, and a training loop that alternates between them must not re-plan every call):
+  // whether it has been made since the flags last changed, whether the program fits it, and what k_emit_steps is told
+  // about every step
+  UnitPlan units[2];
+  bool units_made[2] = {false, false};
+  bool units_ok[2] = {false, false};
+  int32_t* d_step_unit[2] = {nullptr, nullptr};
 };
 
 static thread_local std::string g_err;
@@ -226,12 +277,22 @@ static void release_block(lynx_ctx* ctx, void* p) {
 // Side operations whose "done" event has fired leave the in-flight list (oldest first: s_side runs them in order);
 // blocks that were freed meanwhile go back to the allocator now.  `wait`: block on every one of them.  Caller holds ctx->mu.
 static void retire_side_ops(lynx_ctx* ctx, bool wait) {
+  // a freed block goes back only with the LAST operation in flight that touches it (a reduction and the gather of
+  // its result name the same block): an earlier one hands its mark on
+  auto hand_on_or_release = [ctx](const void* p) {
+    for (size_t k = 1; k < ctx->side_ops.size(); ++k) {
+      lynx_ctx::SideOp& later = ctx->side_ops[k];
+      if (later.a == p) { later.a_freed = true; return; }
+      if (later.b == p) { later.b_freed = true; return; }
+    }
+    release_block(ctx, const_cast<void*>(p));
+  };
   while (!ctx->side_ops.empty()) {
     lynx_ctx::SideOp& g = ctx->side_ops.front();
     if (wait) (void)hipEventSynchronize(g.done);
     else if (hipEventQuery(g.done) != hipSuccess) break;
-    if (g.a_freed) release_block(ctx, const_cast<void*>(g.a));
-    if (g.b_freed) release_block(ctx, g.b);
+    if (g.a_freed) hand_on_or_release(g.a);
+    if (g.b_freed && g.b != g.a) hand_on_or_release(g.b);
     if (g.owned) ctx->side_events.push_back(g.done);
     ctx->side_ops.erase(ctx->side_ops.begin());
   }
@@ -294,6 +355,7 @@ int lynx_ctx_create(int device, lynx_ctx** out) {
                 std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "count = 0"));
   if (device < 0 || device >= n) return fail(nullptr, LYNX_ERR_INVALID, "device ordinal out of range");
   lynx_ctx* ctx = new lynx_ctx();
+  load_knobs(&ctx->knobs);
   ctx->device = device;
   HIP_TRY(nullptr, hipSetDevice(device));
   HIP_TRY(nullptr, hipGetDeviceProperties(&ctx->prop, device));
@@ -321,9 +383,16 @@ int lynx_ctx_create(int device, lynx_ctx** out) {
   HIP_TRY(nullptr, hipHostMalloc((void**)&ctx->h_status, 2 * sizeof(int32_t), hipHostMallocMapped));
   ctx->h_status[0] = ctx->h_status[1] = 0;
   HIP_TRY(nullptr, hipHostGetDevicePointer((void**)&ctx->d_status, ctx->h_status, 0));
-  HIP_TRY(nullptr, hipMalloc((void**)&ctx->d_tail_flag, sizeof(unsigned int)));
-  HIP_TRY(nullptr, hipMemset(ctx->d_tail_flag, 0, sizeof(unsigned int)));
+  // the word hipStreamWaitValue32 polls: signal memory (what HIP documents for it); without it the build simply
+  // starts at the head of the streaming kernel instead of in its tail
   if (hipDeviceGetAttribute(&ctx->can_wait_value, hipDeviceAttributeCanUseStreamWaitValue, device) != hipSuccess) ctx->can_wait_value = 0;
+  if (ctx->can_wait_value &&
+      hipExtMallocWithFlags((void**)&ctx->d_tail_flag, 8, hipMallocSignalMemory) != hipSuccess) {
+    (void)hipGetLastError();
+    ctx->d_tail_flag = nullptr;
+    ctx->can_wait_value = 0;
+  }
+  if (ctx->d_tail_flag) HIP_TRY(nullptr, hipMemset(ctx->d_tail_flag, 0, 8));
   *out = ctx;
   return LYNX_OK;
 }
@@ -339,6 +408,11 @@ int lynx_ctx_destroy(lynx_ctx* ctx) {
     std::lock_guard<std::mutex> lock(ctx->mu);
     retire_side_ops(ctx, true);
   }
+  for (auto* list : {&ctx->prof_events, &ctx->prof_gather_events})
+    for (auto& pr : *list) {
+      (void)hipEventDestroy(pr.first);
+      (void)hipEventDestroy(pr.second);
+    }
   (void)hipEventDestroy(ctx->ev_side_in);
   (void)hipEventDestroy(ctx->ev_main_mark);
   for (hipEvent_t e : ctx->side_events) (void)hipEventDestroy(e);
@@ -488,6 +562,11 @@ int lynx_profile_begin(lynx_ctx* ctx) {
     (void)hipEventDestroy(pr.second);
   }
   ctx->prof_events.clear();
+  for (auto& pr : ctx->prof_gather_events) {
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
+  ctx->prof_gather_events.clear();
   ctx->profiling = true;
   return LYNX_OK;
 }
@@ -499,11 +578,11 @@ int lynx_profile_end(lynx_ctx* ctx, double* total_ms, int64_t* launches) {
   // the per-launch stop events stood in for the step-table slots' "streamed" events and go away here
   for (bool& v : ctx->streamed_valid) v = false;
   double total = 0.0;
-  const bool dump = env_int("LYNX_PROFILE_DUMP", 0) != 0;  // every launch's duration, in launch order (diagnostics)
+  ctx->prof_ms.clear();
   for (auto& pr : ctx->prof_events) {
     float ms = 0.f;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, pr.first, pr.second));
-    if (dump) fprintf(stderr, "lynx_profile_end: launch %zu %.4f ms\n", (size_t)(&pr - ctx->prof_events.data()), ms);
+    ctx->prof_ms.push_back(ms);
     total += ms;
     (void)hipEventDestroy(pr.first);
     (void)hipEventDestroy(pr.second);
@@ -511,6 +590,41 @@ int lynx_profile_end(lynx_ctx* ctx, double* total_ms, int64_t* launches) {
   *total_ms = total;
   *launches = (int64_t)ctx->prof_events.size();
   ctx->prof_events.clear();
+  ctx->prof_gather_ms.clear();
+  if (!ctx->prof_gather_events.empty()) {
+    const int rc = wait_for_side(ctx);  // the gathers' stop events must have fired
+    if (rc) return rc;
+  }
+  for (auto& pr : ctx->prof_gather_events) {
+    float ms = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, pr.first, pr.second));
+    ctx->prof_gather_ms.push_back(ms);
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
+  ctx->prof_gather_events.clear();
+  return LYNX_OK;
+}
+
+int lynx_profile_launches(lynx_ctx* ctx, double* ms_out, int64_t capacity, int64_t* launches) {
+  if (!ctx || !launches || (capacity > 0 && !ms_out)) return fail(ctx, LYNX_ERR_INVALID, "null argument");
+  *launches = (int64_t)ctx->prof_ms.size();
+  for (int64_t i = 0; i < capacity && i < *launches; ++i) ms_out[i] = ctx->prof_ms[(size_t)i];
+  return LYNX_OK;
+}
+
+int lynx_profile_gathers(lynx_ctx* ctx, double* ms_out, int64_t capacity, int64_t* gathers) {
+  if (!ctx || !gathers || (capacity > 0 && !ms_out)) return fail(ctx, LYNX_ERR_INVALID, "null argument");
+  *gathers = (int64_t)ctx->prof_gather_ms.size();
+  for (int64_t i = 0; i < capacity && i < *gathers; ++i) ms_out[i] = ctx->prof_gather_ms[(size_t)i];
+  return LYNX_OK;
+}
+
+int lynx_ctx_reload_knobs(lynx_ctx* ctx) {
+  if (!ctx) return fail(ctx, LYNX_ERR_INVALID, "null argument");
+  // plans made under the old settings (lanes-build pieces, unit plans) are keyed by what they depend on and are
+  // re-made on demand; nothing in flight reads the knobs
+  load_knobs(&ctx->knobs);
   return LYNX_OK;
 }
 
@@ -709,7 +823,7 @@ int lynx_lattice_set_flags(lynx_lattice* lat, const int32_t* elem_flags, const i
   lynx_ctx* ctx = lat->ctx;
   for (int32_t e = 0; e < lat->n_elems; ++e) lat->h_elems[e].flags = elem_flags[e];
   for (int32_t s = 0; s < lat->n_steps; ++s) lat->h_steps[s].flags = step_flags[s];
-  lat->units_key = -1;  // the proposed classes depend on the elements' flags
+  lat->units_made[0] = lat->units_made[1] = false;  // the proposed classes depend on the elements' flags
   {
     const int rc = count_observers(ctx, lat);
     if (rc) return rc;
@@ -729,7 +843,8 @@ int lynx_lattice_destroy(lynx_lattice* lat) {
   ctx_free(ctx, lat->d_pool);
   if (lat->d_cav_words) ctx_free(ctx, lat->d_cav_words);
   if (lat->d_cavs) ctx_free(ctx, lat->d_cavs);
-  if (lat->d_step_unit) ctx_free(ctx, lat->d_step_unit);
+  for (int32_t* p : lat->d_step_unit)
+    if (p) ctx_free(ctx, p);
   if (lat->d_pieces) ctx_free(ctx, lat->d_pieces);
   if (lat->d_tasks) ctx_free(ctx, lat->d_tasks);
   if (lat->d_step_slot) ctx_free(ctx, lat->d_step_slot);
@@ -762,11 +877,6 @@ static int allow_lds(lynx_ctx* ctx, K kernel, size_t bytes) {
 
 // ---- build + compose -------------------------------------------------------------------
 
-static int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return (v && *v) ? atoi(v) : dflt;
-}
-
 // Launch shape of k_build: 256 threads and chunks of <= 64 elements (<= 32 for float32 lattices, whose
 // staging area would otherwise halve the resident workgroups) when the batch fills the GPU; 1024
 // threads and chunks of <= 128 when it does not -- then the tree depth is what a call waits for.
@@ -777,14 +887,12 @@ static int env_int(const char* name, int dflt) {
 template <typename T>
 static void build_shape(lynx_ctx* ctx, const lynx_lattice* lat, bool underneath, int* threads, int* chunk) {
   const int64_t cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
-  const bool wide = lat->batch * 2 <= cus && !(underneath && env_int("LYNX_BUILD_NARROW_UNDERNEATH", 1));
+  const bool wide = lat->batch * 2 <= cus && !underneath;
   *threads = wide ? 1024 : 256;
   // (float32, at most one workgroup per CU: 64 again -- half the rounds; the 128-sample shard of BASELINE config 4
   // underneath its streaming kernel: 0.1573 -> 0.1543 ms/step, medians of four, same box)
   int limit = wide ? 128 : ((sizeof(T) == 4 && lat->batch > cus) ? 32 : 64);
-  limit = env_int("LYNX_BUILD_CHUNK", limit);
   if (limit > *threads) limit = *threads;
-  if (limit < 2) limit = 2;
   *chunk = build_chunk(lat->n_elems, limit);
 }
 
@@ -797,15 +905,12 @@ static int launch_cavity_flags(lynx_ctx* ctx, lynx_lattice* lat, hipStream_t str
   if ((rc = ensure_scratch(ctx, &ctx->scratch_erun, &ctx->scratch_erun_bytes, (size_t)lat->batch * sizeof(T)))) return rc;
   // the predicates for every cavity at once, assuming every batch gains energy (one lane per sample), then one small
   // workgroup that checks the assumption, publishes the bits and -- should it not hold -- walks the serial way
-  const bool spec = env_int("LYNX_CAVITY_FLAGS_SPEC", 1) != 0;
-  if (spec) {
-    hipLaunchKernelGGL(k_cavity_flags_spec<T>, dim3((unsigned)((lat->batch + 255) / 256)), dim3(256), 0, stream, dev_view(lat),
-                       lat->d_cavs, lat->n_cavities, (const T*)d_energy_in, lat->d_cav_words);
-    HIP_TRY(ctx, hipGetLastError());
-  }
+  hipLaunchKernelGGL(k_cavity_flags_spec<T>, dim3((unsigned)((lat->batch + 255) / 256)), dim3(256), 0, stream, dev_view(lat),
+                     lat->d_cavs, lat->n_cavities, (const T*)d_energy_in, lat->d_cav_words);
+  HIP_TRY(ctx, hipGetLastError());
   hipLaunchKernelGGL(k_cavity_flags<T>, dim3(1), dim3(256), 0, stream, dev_view(lat), lat->d_elems, lat->d_steps,
                      (const T*)d_energy_in, (T*)ctx->scratch_erun, ctx->d_status, lat->d_cavs, lat->n_cavities,
-                     spec ? lat->d_cav_words : (int32_t*)nullptr);
+                     lat->d_cav_words);
   HIP_TRY(ctx, hipGetLastError());
   return LYNX_OK;
 }
@@ -868,7 +973,7 @@ static int launch_build_lanes(lynx_ctx* ctx, lynx_lattice* lat, hipStream_t stre
                               void* d_steps_out, void* d_energy_out, int merge_pairs, float* d_units = nullptr,
                               float* d_extras = nullptr) {
   int rc;
-  if ((rc = plan_lanes_build(ctx, lat, std::max(1, env_int("LYNX_PIECE", 8))))) return rc;
+  if ((rc = plan_lanes_build(ctx, lat, std::max(1, ctx->knobs.piece)))) return rc;
   const int64_t groups = (lat->batch + 63) / 64, Bp = groups * 64;
   if (lat->n_pieces > 65535 || lat->n_steps > 65535) return fail(ctx, LYNX_ERR_INVALID, "lattice too long for the lanes build");
   if ((rc = ensure_scratch(ctx, &ctx->scratch_products, &ctx->scratch_products_bytes, (size_t)lat->n_slots * 49 * Bp * sizeof(double))))
@@ -882,7 +987,7 @@ static int launch_build_lanes(lynx_ctx* ctx, lynx_lattice* lat, hipStream_t stre
   HIP_TRY(ctx, hipGetLastError());
   // narrow trees (BASELINE config 4: 8, 4, 2, 1 tasks per level) in one launch: underneath a streaming kernel every
   // launch of the chain costs ~20 us, the product itself 3-6 (config 4: 0.995 -> 0.985 ms/step, same box)
-  bool narrow = !lat->levels.empty() && (int)lat->levels.size() <= kPairLevelsMax && env_int("LYNX_PAIR_LEVELS_FUSED", 1) != 0;
+  bool narrow = !lat->levels.empty() && (int)lat->levels.size() <= kPairLevelsMax && ctx->knobs.pair_levels_fused != 0;
   for (const auto& level : lat->levels) narrow = narrow && level.second <= kPairLevelsMaxTasks;
   if (narrow) {
     PairLevels lv{};
@@ -904,12 +1009,13 @@ static int launch_build_lanes(lynx_ctx* ctx, lynx_lattice* lat, hipStream_t stre
   hipLaunchKernelGGL(k_emit_steps<T>, dim3((unsigned)groups, (unsigned)lat->n_steps), dim3(64), emit_steps_lds<T>(), stream, lv,
                      lat->d_step_slot, (const T*)d_energy_in, Bp, (const double*)ctx->scratch_products,
                      (const T*)ctx->scratch_coefs, merge_pairs, (T*)d_steps_out, (T*)d_energy_out,
-                     d_units ? lat->d_step_unit : (const int32_t*)nullptr, lat->units.n_units, d_units, d_extras);
+                     d_units ? lat->d_step_unit[merge_pairs ? 1 : 0] : (const int32_t*)nullptr,
+                     lat->units[merge_pairs ? 1 : 0].n_units, d_units, d_extras);
   HIP_TRY(ctx, hipGetLastError());
   return LYNX_OK;
 }
 
-// `d_units` / `d_extras`: also pack the unit records of a multi-step float32 program (lat->units must be current);
+// `d_units` / `d_extras`: also pack the unit records of a multi-step float32 program (the lattice's unit plan for `merge_pairs` must have been made);
 // the lanes build does it while it writes the table, the workgroup build with k_pack_units behind it
 template <typename T>
 static int launch_build(lynx_ctx* ctx, lynx_lattice* lat, hipStream_t stream, const void* d_energy_in,
@@ -921,7 +1027,7 @@ static int launch_build(lynx_ctx* ctx, lynx_lattice* lat, hipStream_t stream, co
   }
   // large batches: lanes = samples (an order of magnitude fewer wave-instructions); small ones: one
   // workgroup per sample, whose tree is shallower than a chain of launches
-  if (lat->n_steps > 0 && lat->batch >= env_int("LYNX_LANES_BUILD_MIN_BATCH", 256))
+  if (lat->n_steps > 0 && lat->batch >= ctx->knobs.lanes_build_min_batch)
     return launch_build_lanes<T>(ctx, lat, stream, d_energy_in, d_steps_out, d_energy_out, merge_pairs, d_units, d_extras);
   int threads, chunk;
   build_shape<T>(ctx, lat, underneath, &threads, &chunk);
@@ -934,8 +1040,9 @@ static int launch_build(lynx_ctx* ctx, lynx_lattice* lat, hipStream_t stream, co
   HIP_TRY(ctx, hipGetLastError());
   if constexpr (sizeof(T) == 4) {
     if (d_units) {
-      const int64_t n = lat->batch * lat->units.n_units;
-      hipLaunchKernelGGL(k_pack_units, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, lat->units, lat->batch,
+      const UnitPlan& up = lat->units[merge_pairs ? 1 : 0];
+      const int64_t n = lat->batch * up.n_units;
+      hipLaunchKernelGGL(k_pack_units, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, up, lat->batch,
                          lat->n_steps, (const float*)d_steps_out, d_units, d_extras);
       HIP_TRY(ctx, hipGetLastError());
     }
@@ -976,13 +1083,13 @@ static TrackPlan plan_track(lynx_ctx* ctx, const lynx_lattice* lat, int64_t B, i
   p.full_cov = full_cov;
   constexpr int P = 16 / (int)sizeof(T);  // particles per lane of a wave tile
   const int64_t cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
-  const int64_t target = (int64_t)env_int("LYNX_WGS_PER_CU", 512) * cus;
-  p.mom_mode = env_int("LYNX_MOM", sizeof(T) == 4 ? 2 : 1);
+  const Knobs& kn = ctx->knobs;
+  const int64_t target = 512 * cus;  // workgroups per CU over the whole launch
+  p.mom_mode = knob(kn.mom, sizeof(T) == 4 ? 2 : 1);
   if (sizeof(T) == 8 || p.mom_mode < 2 || p.mom_mode > 3) p.mom_mode = sizeof(T) == 4 ? 2 : 1;
   p.a.n_particles = N;
   p.a.fused_build = (fused && S > 0) ? 1 : 0;
   p.a.store = 0;
-  p.a.interleave = env_int("LYNX_INTERLEAVE", 0);
   p.a.build_chunk = 1;
   p.a.tail_flag = nullptr;
   p.a.tail_seq = 0;
@@ -997,8 +1104,8 @@ static TrackPlan plan_track(lynx_ctx* ctx, const lynx_lattice* lat, int64_t B, i
   // (with the whole covariance in float32 lane sums the tile form runs out of registers: 1.23 vs 1.13 ms on C4)
   // (and short samples leave most wave tiles cut: 700 particles per sample 0.79 vs 0.72 ms per 20 M particles)
   p.xpose = !p.a.fused_build &&
-            env_int("LYNX_XPOSE", ((sizeof(T) == 8 || (single_map && !full_cov)) && N >= 8 * 64 * P) ? 1 : 0) != 0;
-  int u = env_int("LYNX_UNROLL", p.xpose ? P : (sizeof(T) == 4 ? (S > 1 ? 2 : 4) : 1));
+            knob(kn.xpose, ((sizeof(T) == 8 || (single_map && !full_cov)) && N >= 8 * 64 * P) ? 1 : 0) != 0;
+  int u = knob(kn.unroll, p.xpose ? P : (sizeof(T) == 4 ? (S > 1 ? 2 : 4) : 1));
   if (u != 1 && u != 2 && u != 4) u = 2;
   if (sizeof(T) == 8 && u > 2) u = 2;
   // small jobs: fewer particles per lane so that more workgroups exist
@@ -1013,7 +1120,7 @@ static TrackPlan plan_track(lynx_ctx* ctx, const lynx_lattice* lat, int64_t B, i
   // programs like many short-lived workgroups -- 2 tiles each: C4 5.26 -> 5.49 TB/s, c3big 4.83 -> 5.09 --
   // while multi-step programs also fetch S step records per iteration and want long-lived ones (C5 with
   // 2 / 4 / 8 / 16 tiles: 1.25 / 1.14 / 1.10 / 1.09 ms).
-  int64_t min_tpw = env_int("LYNX_MIN_TILES_PER_WG", S > 1 ? 16 : 2);
+  int64_t min_tpw = std::max(1, knob(kn.min_tiles_per_wg, S > 1 ? 16 : 2));
   while (min_tpw > 1 && B * ((ntiles + min_tpw - 1) / min_tpw) < 4 * cus) --min_tpw;
   int64_t chunks = std::max<int64_t>(1, std::min<int64_t>((ntiles + min_tpw - 1) / min_tpw, (target + B - 1) / B));
   int64_t tpw = (ntiles + chunks - 1) / chunks;
@@ -1021,7 +1128,7 @@ static TrackPlan plan_track(lynx_ctx* ctx, const lynx_lattice* lat, int64_t B, i
   p.a.chunks = (int32_t)chunks;
   p.a.tiles_per_wg = (int32_t)tpw;
   // float32 lane sums for the whole workgroup are fine while a lane sees few particles
-  if (p.mom_mode == 2 && !getenv("LYNX_MOM") && tpw * u <= 32) p.mom_mode = 3;
+  if (p.mom_mode == 2 && kn.mom < 0 && tpw * u <= 32) p.mom_mode = 3;
   if (p.mom_mode == 3 && tpw * u > 64) p.mom_mode = 2;
   size_t scratch = 4 * kPartialStride * sizeof(double);
   if (moments)
@@ -1151,19 +1258,20 @@ static bool plan_units(const lynx_lattice* lat, bool merged, UnitPlan* plan) {
 
 // The lattice's unit plan for `merged`, made once per lattice and flag change; with it the table k_emit_steps reads.
 static int ensure_units_plan(lynx_ctx* ctx, lynx_lattice* lat, bool merged) {
-  if (lat->units_key == (merged ? 1 : 0)) return LYNX_OK;
-  lat->units_ok = plan_units(lat, merged, &lat->units) && lat->batch * lat->units.n_units * kUnitStride < 0x7fffffffLL;
-  lat->units_key = merged ? 1 : 0;
-  if (!lat->units_ok) return LYNX_OK;
+  const int m = merged ? 1 : 0;
+  if (lat->units_made[m]) return LYNX_OK;
+  UnitPlan& up = lat->units[m];
+  lat->units_ok[m] = plan_units(lat, merged, &up) && lat->batch * up.n_units * kUnitStride < 0x7fffffffLL;
+  lat->units_made[m] = true;
+  if (!lat->units_ok[m]) return LYNX_OK;
   std::vector<int32_t> code((size_t)lat->n_steps, -1);
-  for (int u = 0; u < lat->units.n_units; ++u)
-    code[lat->units.slot[u]] = step_unit_code(u, lat->units.cls[u], lat->units.pair[u]);
+  for (int u = 0; u < up.n_units; ++u) code[up.slot[u]] = step_unit_code(u, up.cls[u], up.pair[u]);
   int rc;
-  if (!lat->d_step_unit && (rc = ctx_alloc(ctx, code.size() * sizeof(int32_t), (void**)&lat->d_step_unit))) return rc;
+  if (!lat->d_step_unit[m] && (rc = ctx_alloc(ctx, code.size() * sizeof(int32_t), (void**)&lat->d_step_unit[m]))) return rc;
   // rare (new lattice, or its flags changed): nothing may still be reading the old table
   HIP_TRY(ctx, hipStreamSynchronize(ctx->s_build));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  HIP_TRY(ctx, hipMemcpy(lat->d_step_unit, code.data(), code.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(lat->d_step_unit[m], code.data(), code.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   return LYNX_OK;
 }
 
@@ -1217,7 +1325,7 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
   // sample is covered by <= n workgroups.
   const bool full_cov = (flags & LYNX_TRACK_COVARIANCE) != 0;
   TrackPlan p = plan_track<T>(ctx, lat, B, N, S, true, moments, full_cov);
-  bool fused = S > 0 && !(flags & LYNX_TRACK_TWO_KERNEL) && p.a.chunks <= env_int("LYNX_FUSE_MAX_CHUNKS", 0) && p.unroll == 1;
+  bool fused = S > 0 && !(flags & LYNX_TRACK_TWO_KERNEL) && p.a.chunks <= ctx->knobs.fuse_max_chunks && p.unroll == 1;
   if (!fused) p = plan_track<T>(ctx, lat, B, N, S, false, moments, full_cov);
   p.a.store = d_p_out ? 1 : 0;
   const bool shared_in = (flags & LYNX_TRACK_SHARED_INPUT) != 0;
@@ -1243,7 +1351,7 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
       has_pair |= lat->h_steps[s].kind == LYNX_STEP_CAVITY && lat->h_steps[s - 1].kind == LYNX_STEP_RUN &&
                   !(lat->h_steps[s - 1].flags & LYNX_STEP_FLAG_OBSERVE);
     p.a.merged_pairs = has_pair && sizeof(T) == 4 && p.unroll == 2 &&
-                       !(flags & LYNX_TRACK_SEQUENTIAL_STEPS) && env_int("LYNX_MERGE_STEPS", 1);
+                       !(flags & LYNX_TRACK_SEQUENTIAL_STEPS) && ctx->knobs.merge_steps;
     if (p.a.merged_pairs) {  // four floats of LDS per lane for pairs that take the rows form (kEntryStash)
       p.lds = (p.lds + 15) / 16 * 16;
       p.a.stash_offset = (int32_t)p.lds;
@@ -1252,7 +1360,7 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
     // The second stream pays once the streaming kernel is long enough to hide a build under; below half a
     // million particles per call the extra event traffic costs more host time than the overlap returns
     // (BASELINE config 2: 31 -> 46 us per call with it).
-    const bool async = env_int("LYNX_ASYNC_BUILD", B * N >= (int64_t)512 << 10 ? 1 : 0) != 0;
+    const bool async = knob(ctx->knobs.async_build, B * N >= (int64_t)512 << 10 ? 1 : 0) != 0;
     async_build = async;
     hipStream_t bs = async ? ctx->s_build : ctx->stream;
     if (async) {
@@ -1260,7 +1368,7 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
       if (ctx->streamed_valid[slot]) HIP_TRY(ctx, hipStreamWaitEvent(bs, ctx->ev_streamed[slot], 0));
       // ... and the build starts in the TAIL of the streaming kernel before the one enqueued last (which has the GPU
       // to itself when it gets there), not at that kernel's head
-      tail = ctx->can_wait_value && env_int("LYNX_BUILD_IN_TAIL", 1);
+      tail = ctx->can_wait_value && ctx->knobs.build_in_tail;
       if (tail && ctx->tail_seq >= 2)
         HIP_TRY(ctx, hipStreamWaitValue32(bs, ctx->d_tail_flag, ctx->tail_seq - 1, hipStreamWaitValueGte, 0xffffffffu));
       // what the build reads (energy, lattice pool) may have been written on the main stream
@@ -1277,24 +1385,24 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
       // multi-step programs: walked as units with structured maps (lynx_units.hpp); LYNX_TRACK_UNITS=0 keeps the
       // dense step loop of k_track_direct
       // (LYNX_TRACK_UNITS=2: insist -- an error if this call cannot take the structured loop; for tests)
-      const int want_units = env_int("LYNX_TRACK_UNITS", 1);
+      const int want_units = ctx->knobs.track_units;
       // (k_track_units addresses a sample's particles with 32-bit byte offsets: samples below 4 GiB)
-      if (S > 1 && (p.unroll == 2 || p.unroll == 4) && !p.xpose && p.a.n_observers == 0 && !p.a.interleave && want_units &&
+      if (S > 1 && (p.unroll == 2 || p.unroll == 4) && !p.xpose && p.a.n_observers == 0 && want_units &&
           (uint64_t)N * 28u + ((uint64_t)1 << 20) < ((uint64_t)1 << 32)) {
         if ((rc = ensure_units_plan(ctx, lat, p.a.merged_pairs != 0))) return rc;
-        use_units = lat->units_ok;
+        use_units = lat->units_ok[p.a.merged_pairs ? 1 : 0];
       }
       if (want_units == 2 && !use_units)
         return fail(ctx, LYNX_ERR_INVALID, "LYNX_TRACK_UNITS=2: this call does not take the structured step loop");
       if (use_units) {
-        const int64_t n = B * lat->units.n_units;
+        const int64_t n = B * lat->units[p.a.merged_pairs ? 1 : 0].n_units;
         const int xs = lynx_ctx::kTableSlots + slot;
         if ((rc = ensure_scratch(ctx, &ctx->scratch_units[slot], &ctx->scratch_units_bytes[slot], (size_t)n * kUnitStride * sizeof(float))) ||
             (rc = ensure_scratch(ctx, &ctx->scratch_units[xs], &ctx->scratch_units_bytes[xs], (size_t)n * kUnitExtraStride * sizeof(float))))
           return rc;
         d_units = d_units_w = (float*)ctx->scratch_units[slot];
         d_extras = d_extras_w = (float*)ctx->scratch_units[xs];
-        n_units = lat->units.n_units;
+        n_units = lat->units[p.a.merged_pairs ? 1 : 0].n_units;
       }
     }
     if ((rc = launch_build<T>(ctx, lat, bs, d_energy_in, ctx->scratch_steps[slot], nullptr, p.a.merged_pairs, async, d_units_w, d_extras_w)))
@@ -1311,7 +1419,7 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
       // Nor for short streaming kernels (BASELINE config 3, 1 M particles: 29 us of kernel, 22 us of build -- the
       // host would be the pacemaker: 48 -> 75 us/step): from 128 MB of particles per call.
       const bool long_kernel = (size_t)B * N * 7 * sizeof(T) >= ((size_t)128 << 20);
-      if (env_int("LYNX_BUILD_HOST_WAIT", (lat->has_cavity || !long_kernel) ? 0 : 1)) HIP_TRY(ctx, hipEventSynchronize(ctx->ev_built[slot]));
+      if (knob(ctx->knobs.build_host_wait, (lat->has_cavity || !long_kernel) ? 0 : 1)) HIP_TRY(ctx, hipEventSynchronize(ctx->ev_built[slot]));
       else HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_built[slot], 0));
     }
     d_steps = ctx->scratch_steps[slot];
@@ -1327,7 +1435,7 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
   lynx_ctx::PartialSlot* ring = nullptr;
   // The reduction leaves the main stream once the streaming kernel is long enough to hide it under (same threshold
   // as the build's second stream: below it the extra event traffic costs more host time than it returns).
-  const bool side = moments && env_int("LYNX_SIDE_REDUCE", B * N >= (int64_t)512 << 10 ? 1 : 0) != 0;
+  const bool side = moments && knob(ctx->knobs.side_reduce, B * N >= (int64_t)512 << 10 ? 1 : 0) != 0;
   if (moments) {
     ring = &ctx->partial_ring[ctx->partial_seq++ % lynx_ctx::kPartialRing];
     if (ring->pending) {
@@ -1390,7 +1498,7 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
     }
     int rows = p.a.chunks;
     const double* level_in = d_partials;
-    const bool wide = B <= 4 && rows > kReduceStage && rows <= 3 * kReduceStageWide && env_int("LYNX_REDUCE_WIDE", 1);
+    const bool wide = B <= 4 && rows > kReduceStage && rows <= 3 * kReduceStageWide && ctx->knobs.reduce_wide;
     if (wide) {
       constexpr size_t lds = reduce_lds_bytes<1024, kReduceStageWide>();
       if ((rc = allow_lds(ctx, k_reduce_moments<true, 1024, kReduceStageWide>, lds))) return rc;
@@ -1461,6 +1569,9 @@ int lynx_track_particles(lynx_ctx* ctx, lynx_lattice* lat, int64_t n_particles, 
 
 // ---- reverse pass -----------------------------------------------------------------------
 
+constexpr int kBwdWgsPerCu = 24;                     // workgroups per CU of the reverse streaming kernels
+constexpr size_t kBwdMapsLdsBytes = (size_t)40 << 10;  // k_build_bwd keeps maps and prefix products in LDS up to this
+
 template <typename T, typename Z = T>
 static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const void* d_energy_in, const void* d_p_in,
                             const double* d_moments_fwd, const double* d_grad_moments, void* d_grad_params,
@@ -1473,7 +1584,7 @@ static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const v
   constexpr int W = LaneOf<Z>::W;
   BwdArgs a;
   int merged = 0;
-  if (W == 2 && env_int("LYNX_BWD_MERGE", 1))
+  if (W == 2 && ctx->knobs.bwd_merge)
     for (int32_t s = 1; s < S; ++s)
       merged |= lat->h_steps[s].kind == LYNX_STEP_CAVITY && lat->h_steps[s - 1].kind == LYNX_STEP_RUN &&
                 !(lat->h_steps[s - 1].flags & LYNX_STEP_FLAG_OBSERVE);
@@ -1495,10 +1606,11 @@ static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const v
   float* d_units = nullptr;
   float* d_extras = nullptr;
   if constexpr (W == 2) {
-    if (env_int("LYNX_BWD_UNITS", 1)) {
+    if (ctx->knobs.bwd_units) {
       if ((rc = ensure_units_plan(ctx, lat, merged != 0))) return rc;
-      bool same = lat->units_ok && lat->units.n_units == a.n_units;
-      for (int u = 0; same && u < a.n_units; ++u) same = lat->units.slot[u] == a.unit_slot[u];
+      const UnitPlan& up = lat->units[merged ? 1 : 0];
+      bool same = lat->units_ok[merged ? 1 : 0] && up.n_units == a.n_units;
+      for (int u = 0; same && u < a.n_units; ++u) same = up.slot[u] == a.unit_slot[u];
       if (same) {
         const int64_t n = B * a.n_units;
         if ((rc = ensure_scratch(ctx, &ctx->scratch_units_bwd[0], &ctx->scratch_units_bwd_bytes[0], (size_t)n * kUnitStride * sizeof(float))) ||
@@ -1518,7 +1630,7 @@ static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const v
   using Geo = ExGeom<T, W>;
   const int64_t cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
   const int64_t ntiles = (N + kTrackThreads * W - 1) / (kTrackThreads * W);
-  int64_t chunks = std::max<int64_t>(1, std::min<int64_t>(ntiles, ((int64_t)env_int("LYNX_BWD_WGS_PER_CU", 24) * cus + B - 1) / B));
+  int64_t chunks = std::max<int64_t>(1, std::min<int64_t>(ntiles, ((int64_t)kBwdWgsPerCu * cus + B - 1) / B));
   const int64_t tpw = (ntiles + chunks - 1) / chunks;
   chunks = (ntiles + tpw - 1) / tpw;
   a.n_particles = N;
@@ -1557,7 +1669,7 @@ static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const v
   size_t lds2 = build_bwd_lds_fixed<T>(S, E);
   // maps + prefix products, then the kind-sorted task list and the elements' kinds (unsigned short each)
   const size_t maps_bytes = (size_t)(2 * E + S + 1) * 49 * sizeof(T) + ((size_t)bwd_task_capacity(E) + E) * sizeof(unsigned short);
-  const int maps_in_lds = E < 4096 && lds2 + maps_bytes <= (size_t)env_int("LYNX_BWD_MAPS_LDS_KB", 40) * 1024;
+  const int maps_in_lds = E < 4096 && lds2 + maps_bytes <= kBwdMapsLdsBytes;
   if (maps_in_lds) lds2 += maps_bytes;
   if ((rc = allow_lds(ctx, k_build_bwd<T>, lds2))) return rc;
   HIP_TRY(ctx, hipMemsetAsync(d_grad_params, 0, (size_t)B * E * kGradParams * sizeof(T), ctx->stream));
@@ -1582,7 +1694,7 @@ int lynx_track_particles_backward(lynx_ctx* ctx, lynx_lattice* lat, int64_t n_pa
   return lat->dtype == LYNX_F64
              ? track_backward_t<double>(ctx, lat, n_particles, d_energy_in, d_p_in, d_moments_fwd, d_grad_moments,
                                         d_grad_params, d_grad_energy_in, d_grad_p_in)
-         : env_int("LYNX_BWD_PAIRS", 1)
+         : ctx->knobs.bwd_pairs
              ? track_backward_t<float, lynx_f32x2>(ctx, lat, n_particles, d_energy_in, d_p_in, d_moments_fwd,
                                                    d_grad_moments, d_grad_params, d_grad_energy_in, d_grad_p_in)
              : track_backward_t<float>(ctx, lat, n_particles, d_energy_in, d_p_in, d_moments_fwd, d_grad_moments,
@@ -1615,7 +1727,7 @@ static int moments_backward_t(lynx_ctx* ctx, lynx_lattice* lat, const void* d_en
   size_t lds2 = build_bwd_lds_fixed<T>(S, E);
   // maps + prefix products, then the kind-sorted task list and the elements' kinds (unsigned short each)
   const size_t maps_bytes = (size_t)(2 * E + S + 1) * 49 * sizeof(T) + ((size_t)bwd_task_capacity(E) + E) * sizeof(unsigned short);
-  const int maps_in_lds = E < 4096 && lds2 + maps_bytes <= (size_t)env_int("LYNX_BWD_MAPS_LDS_KB", 40) * 1024;
+  const int maps_in_lds = E < 4096 && lds2 + maps_bytes <= kBwdMapsLdsBytes;
   if (maps_in_lds) lds2 += maps_bytes;
   if ((rc = allow_lds(ctx, k_build_bwd<T>, lds2))) return rc;
   HIP_TRY(ctx, hipMemsetAsync(d_grad_params, 0, (size_t)B * E * kGradParams * sizeof(T), ctx->stream));
@@ -1665,7 +1777,7 @@ static int launch_track_moments(lynx_ctx* ctx, lynx_lattice* lat, const void* d_
                                 const void* d_cov_in, void* d_mu_out, void* d_cov_out, void* d_energy_out) {
   int rc;
   if constexpr (sizeof(T) == 4)  // (float64: 98 VGPRs of covariance per lane -- the compiler spills; workgroup form below)
-  if (lat->n_steps > 0 && lat->batch >= env_int("LYNX_LANES_BUILD_MIN_BATCH", 256)) {
+  if (lat->n_steps > 0 && lat->batch >= ctx->knobs.lanes_build_min_batch) {
     // large batches: lanes = samples all the way (step table from the lanes build, then one lane per sample)
     const size_t need = (size_t)lat->batch * lat->n_steps * LYNX_STEP_STRIDE * sizeof(T);
     if ((rc = ensure_scratch(ctx, &ctx->scratch_steps[lynx_ctx::kTablePb], &ctx->scratch_steps_bytes[lynx_ctx::kTablePb], need))) return rc;
@@ -1908,10 +2020,20 @@ int lynx_gather_moments(lynx_ctx* ctx, const double* d_send, double* d_recv, int
   // Default with more than one rank: the side stream.  With one rank (LYNX_FORCE_COMM rehearsals) the "gather" is
   // a copy; it follows the reduction wherever that ran.
   const bool produced_on_side = ctx->side_wrote && ctx->side_wrote == (const void*)d_send;
-  if (env_int("LYNX_GATHER_OVERLAP", (ctx->comm_ranks > 1 || produced_on_side) ? 1 : 0) == 0) {  // in line, on the main stream
+  if (knob(ctx->knobs.gather_overlap, (ctx->comm_ranks > 1 || produced_on_side) ? 1 : 0) == 0) {  // in line, on the main stream
     int rc = join_side(ctx);  // the records may come from a reduction on the side stream
     if (rc) return rc;
+    hipEvent_t g0 = nullptr, g1 = nullptr;
+    if (ctx->profiling) {
+      HIP_TRY(ctx, hipEventCreate(&g0));
+      HIP_TRY(ctx, hipEventCreate(&g1));
+      HIP_TRY(ctx, hipEventRecord(g0, ctx->stream));
+    }
     NCCL_TRY(ctx, ncclAllGather(d_send, d_recv, (size_t)count, ncclDouble, ctx->comm, ctx->stream));
+    if (g1) {
+      HIP_TRY(ctx, hipEventRecord(g1, ctx->stream));
+      ctx->prof_gather_events.emplace_back(g0, g1);
+    }
     return LYNX_OK;
   }
   // The gather is latency (a few hundred KB over xGMI, and it couples this GPU to the slowest rank of the step) and
@@ -1930,7 +2052,17 @@ int lynx_gather_moments(lynx_ctx* ctx, const double* d_send, double* d_recv, int
   hipEvent_t done = nullptr;
   int rc = side_event(ctx, &done);
   if (rc) return rc;
+  hipEvent_t g0 = nullptr, g1 = nullptr;
+  if (ctx->profiling) {  // the gather's own duration on its stream (bench.py at N > 1: how long a rank waits for the others)
+    HIP_TRY(ctx, hipEventCreate(&g0));
+    HIP_TRY(ctx, hipEventCreate(&g1));
+    HIP_TRY(ctx, hipEventRecord(g0, ctx->s_side));
+  }
   NCCL_TRY(ctx, ncclAllGather(d_send, d_recv, (size_t)count, ncclDouble, ctx->comm, ctx->s_side));
+  if (g1) {
+    HIP_TRY(ctx, hipEventRecord(g1, ctx->s_side));
+    ctx->prof_gather_events.emplace_back(g0, g1);
+  }
   HIP_TRY(ctx, hipEventRecord(done, ctx->s_side));
   side_op_issued(ctx, done, d_send, d_recv);
   return LYNX_OK;

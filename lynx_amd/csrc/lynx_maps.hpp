@@ -287,6 +287,16 @@ template <typename T> LYNX_FN void build_corrector(const T* p, bool vertical, T 
   M[(vertical ? 3 : 1) * 7 + 6] = p[1];
 }
 
+// The bracket of r55_cor (cavity.py:296-305), `g0 g1 (beta0 beta1 - 1) + 1`, as the reference evaluates it.  On an
+// ultra-relativistic beam it cancels twice -- beta0 beta1 - 1 ~ -4e-5 at gamma ~ 150-180, times g0 g1 = 27 000 is
+// -1.017, plus 1 --: in float32 the VALUE is off by 20-30 % there (r55_cor itself is ~1e-5 next to the 1 of M[4][4], so
+// the forward pass does not notice: it repeats the reference's operations, this template).  A derivative taken through
+// the same operations is off by as much, and it multiplies the whole cotangent of M[4][4]; the dual-number instantiation
+// (lynx_dual.hpp) therefore specialises this function with an algebraically equal form that does not cancel.
+template <typename T> LYNX_HD T cavity_r55_bracket(T g0, T g1, T beta0, T beta1) {
+  return g0 * g1 * (beta0 * beta1 - T(1)) + T(1);
+}
+
 // lynx/accelerator/cavity.py:248-325 (`_cavity_rmatrix`) plus, when `coef` is non-null,
 // the per-sample coefficients of the non-linear step (cavity.py:97-246, `_track_beam`).
 // p = [L, V, phase_deg, f].  Returns the outgoing energy.
@@ -314,7 +324,7 @@ template <typename T> LYNX_FN T build_cavity(const T* p, int flags, T energy, T*
     beta1 = t_sqrt(T(1) - T(1) / (Ef * Ef));
     r56 = -L / (Ef * Ef * Ei * beta1) * (Ef + Ei) / (beta1 + beta0);
     T g0 = Ei, g1 = Ef;
-    r55_cor = k * L * beta0 * V / me * sphi * (g0 * g1 * (beta0 * beta1 - T(1)) + T(1)) /
+    r55_cor = k * L * beta0 * V / me * sphi * cavity_r55_bracket<T>(g0, g1, beta0, beta1) /
               (beta1 * g1 * ((g0 - g1) * (g0 - g1)));
   }
   T r66 = Ei / Ef * beta0 / beta1;

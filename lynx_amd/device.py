@@ -91,6 +91,26 @@ class Runtime:
         self.check(self.lib.lynx_profile_end(self.ctx, C.byref(ms), C.byref(n)))
         return float(ms.value), int(n.value)
 
+    def profile_launches(self) -> list:
+        """Milliseconds of every streaming-kernel launch of the profile closed last, in launch order."""
+        n = C.c_int64()
+        self.check(self.lib.lynx_profile_launches(self.ctx, None, 0, C.byref(n)))
+        out = (C.c_double * max(n.value, 1))()
+        self.check(self.lib.lynx_profile_launches(self.ctx, out, n.value, C.byref(n)))
+        return [float(v) for v in out[: n.value]]
+
+    def profile_gathers(self) -> list:
+        """Milliseconds of every RCCL gather of the profile closed last (on the stream it ran on), in issue order."""
+        n = C.c_int64()
+        self.check(self.lib.lynx_profile_gathers(self.ctx, None, 0, C.byref(n)))
+        out = (C.c_double * max(n.value, 1))()
+        self.check(self.lib.lynx_profile_gathers(self.ctx, out, n.value, C.byref(n)))
+        return [float(v) for v in out[: n.value]]
+
+    def reload_knobs(self):
+        """Read the LYNX_* launch-plan switches from the environment again (they are read once, at context creation)."""
+        self.check(self.lib.lynx_ctx_reload_knobs(self.ctx))
+
     def copy_bandwidth(self, nbytes: int, repeats: int = 10, shapes=(1, 4, 0, 101, 104)) -> dict:
         """
         GB/s (read + write bytes) of a plain 16 B/lane device copy of `nbytes` for each launch shape in

@@ -49,6 +49,40 @@ def host_harness():
     return ctypes.CDLL(str(so))
 
 
+@pytest.fixture(autouse=True)
+def _knobs_follow_the_environment(request, monkeypatch):
+    """
+    liblynxhip reads its launch-plan switches (LYNX_XPOSE, LYNX_TRACK_UNITS, ...) once, when the context is created
+    (include/lynx_hip.h: lynx_ctx_reload_knobs).  GPU tests flip them with `monkeypatch.setenv` on the live context:
+    every such change -- and its undoing at the end of the test -- is followed by a reload here.
+    """
+    if "gpu" not in request.keywords:
+        yield
+        return
+    from lynx_amd import device
+
+    def reload():
+        rt = device._runtime
+        if rt is not None and not rt.closed:
+            rt.reload_knobs()
+
+    setenv, delenv = monkeypatch.setenv, monkeypatch.delenv
+
+    def setenv_and_reload(name, value, *args, **kwargs):
+        setenv(name, value, *args, **kwargs)
+        reload()
+
+    def delenv_and_reload(name, *args, **kwargs):
+        delenv(name, *args, **kwargs)
+        reload()
+
+    monkeypatch.setenv, monkeypatch.delenv = setenv_and_reload, delenv_and_reload  # this test's instance only
+    reload()
+    yield
+    monkeypatch.undo()
+    reload()
+
+
 def pytest_collection_modifyitems(config, items):
     """`-m gpu` on a box without a GPU must fail loudly, not pass by skipping."""
     if any("gpu" in item.keywords for item in items) and config.getoption("-m") == "gpu":

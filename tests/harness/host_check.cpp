@@ -38,3 +38,13 @@ extern "C" void harness_build_dual_f64(int kind, int flags, const double* p, int
   for (int q = 0; q < 49; ++q) { M[q] = dm[q].v; dM[q] = dm[q].d; }
   for (int q = 0; q < 8; ++q) { coef[q] = dc[q].v; dcoef[q] = dc[q].d; }
 }
+extern "C" void harness_build_dual_f32(int kind, int flags, const float* p, int n_params, float energy, int seed,
+                                       float* M, float* dM, float* coef, float* dcoef, int want_coef) {
+  lynx::Dual<float> dp[49], dm[49], dc[8];
+  for (int q = 0; q < 49; ++q) dp[q] = lynx::Dual<float>(q < n_params ? p[q] : 0.0f, q == seed ? 1.0f : 0.0f);
+  for (int q = 0; q < 8; ++q) dc[q] = lynx::Dual<float>(0.0f);
+  lynx::Dual<float> de(energy, seed == n_params ? 1.0f : 0.0f);
+  lynx::build_element<lynx::Dual<float>>(kind, flags, dp, de, dm, want_coef ? dc : nullptr);
+  for (int q = 0; q < 49; ++q) { M[q] = dm[q].v; dM[q] = dm[q].d; }
+  for (int q = 0; q < 8; ++q) { coef[q] = dc[q].v; dcoef[q] = dc[q].d; }
+}

@@ -110,3 +110,46 @@ def singular_entry_voltage(energy, phase, length, frequency, lo, hi):
         mid = 0.5 * (lo + hi)
         lo, hi = (mid, hi) if det(mid) * det(lo) > 0 else (lo, mid)
     return 0.5 * (lo + hi)
+
+
+def random_samples(batch, count, always=(), record=None):
+    """
+    `count` sample indices of a batch drawn at random PER RUN (a k1-dependent error in samples nobody ever picks would
+    otherwise pass for ever), plus the ones in `always`; the seed is printed -- and handed to `record`, pytest's
+    `record_property` -- so that a failure can be replayed with LYNX_TEST_SAMPLE_SEED=<seed>.
+    """
+    import os
+
+    seed = int(os.environ.get("LYNX_TEST_SAMPLE_SEED") or int.from_bytes(os.urandom(4), "little"))
+    print(f"random_samples: LYNX_TEST_SAMPLE_SEED={seed}")
+    if record is not None:
+        record("sample_seed", seed)
+    rng = np.random.default_rng(seed)
+    drawn = rng.choice(batch, size=min(count, batch), replace=False)
+    return sorted(set(int(i) for i in always) | set(int(i) for i in drawn)), seed
+
+
+MOMENT_KEYS = ("mu_x", "mu_xp", "mu_y", "mu_yp", "mu_s", "mu_p", "sigma_x", "sigma_xp", "sigma_y", "sigma_yp", "sigma_s",
+               "sigma_p", "sigma_xxp", "sigma_yyp")
+
+
+def moment_distances(got, ref, scale=None):
+    """
+    Per beam moment, the largest distance over the samples between `got` and `ref` (dicts key -> array, or objects with
+    those attributes) in units of north_star's tolerance scale: |mu| + sigma for a mean, sigma for a sigma,
+    sigma_a sigma_b for a correlation; the scales are taken from `scale` (default `ref`).
+    """
+    get = lambda obj, key: np.asarray(obj[key] if isinstance(obj, dict) else getattr(obj, key), dtype=np.float64)  # noqa: E731
+    scale = ref if scale is None else scale
+    out = {}
+    for key in MOMENT_KEYS:
+        g, r = get(got, key), get(ref, key)
+        if key.startswith("mu_"):
+            s = np.abs(get(scale, key)) + get(scale, "sigma" + key[2:])
+        elif key in ("sigma_xxp", "sigma_yyp"):
+            a, b = ("sigma_x", "sigma_xp") if key == "sigma_xxp" else ("sigma_y", "sigma_yp")
+            s = get(scale, a) * get(scale, b)
+        else:
+            s = get(scale, key)
+        out[key] = float(np.max(np.abs(g - r) / s))
+    return out

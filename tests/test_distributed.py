@@ -314,3 +314,34 @@ def test_bench_under_an_external_launcher_uses_the_ranks_it_is_given():
     one = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "4", "--rendezvous-only"],
                          env=dict(base, RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=60)
     assert one.returncode != 0 and "WORLD_SIZE=2" in one.stderr
+
+
+def test_bench_launcher_retries_once_without_the_ipc_variable_when_every_rank_fails_rccl():
+    """
+    The ranks run with HSA_ENABLE_IPC_MODE_LEGACY=0 (this pool's images export it; bench.py: launch_ranks).  Should
+    every rank fail its RCCL bring-up with it (exit 3, rank 0's line says "rccl-failed"), the launcher -- which never
+    touches the GPU -- starts ONE more, fresh set of ranks with the variable unset; the run's line is the second set's
+    and says so.  Rehearsed with ranks that pretend: LYNX_BENCH_TEST_RCCL_FAILS_WITH_IPC_LEGACY.
+    """
+    rc, lines, err = _bench("--gpus", "2", "--rendezvous-only",
+                            env={"LYNX_BENCH_TEST_RCCL_FAILS_WITH_IPC_LEGACY": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert rc == 0, (rc, err)
+    assert len(lines) == 1, lines  # the first set's line is held back
+    assert "HSA_ENABLE_IPC_MODE_LEGACY unset" in lines[0]["config"]["launcher_retry"]
+    assert lines[0]["config"]["gather"] == "none" and lines[0]["config"]["HSA_ENABLE_IPC_MODE_LEGACY"] is None
+    assert "one more set of ranks" in err
+    # no retry for anything else: a rank that simply fails stays a failure
+    rc, lines, err = _bench("--gpus", "2", "--rendezvous-only", env={"LYNX_BENCH_TEST_EXIT": "3", "LYNX_BENCH_TEST_EXIT_RANK": "0"})
+    assert rc == 3 and "one more set of ranks" not in err
+    # without the pretence the first set succeeds and carries the variable
+    rc, lines, err = _bench("--gpus", "2", "--rendezvous-only", env={"HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert rc == 0 and "launcher_retry" not in lines[0]["config"] and lines[0]["config"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_bench_launcher_runs_the_cpu_baseline_before_the_ranks_and_rank_0_reports_it():
+    """N > 1: the CPU-baseline legs run in the launcher parent (they fork; no rank waits for them) and reach the line."""
+    rc, lines, err = _bench("--gpus", "2", "--rendezvous-only", "--particles", "2000",
+                            env={"LYNX_BENCH_TEST_CPU_BASELINE": "1", "LYNX_BENCH_CPU_BUDGET_S": "0.2"})
+    assert rc == 0, err
+    base = lines[0]["cpu_baseline"]
+    assert base["kind"] == "port" and base["value"] > 0 and base["cores"] >= 1 and base["one_thread"]["value"] > 0

@@ -70,3 +70,32 @@ def test_dual_derivatives_match_finite_differences(host_harness, case):
         for got, fd, what in ((dM, fdM, "map"), (dc, fdc, "coef")):
             scale = np.max(np.abs(fd)) + 1e-300
             assert np.max(np.abs(got - fd)) <= 2e-5 * scale + 1e-12 * np.max(np.abs(got)), (what, seed, got, fd)
+
+
+def _dual32(h, kind, flags, p, energy, seed):
+    fn = h.harness_build_dual_f32
+    fn.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_int] + [C.c_void_p] * 4 + [C.c_int]
+    fn.restype = None
+    p = np.ascontiguousarray(p, dtype=np.float32)
+    M, dM, c, dc = (np.zeros(n, np.float32) for n in (49, 49, 8, 8))
+    fn(kind, flags, p.ctypes.data, len(p), float(energy), seed, M.ctypes.data, dM.ctypes.data, c.ctypes.data, dc.ctypes.data, 1)
+    return M, dM, c, dc
+
+
+@pytest.mark.parametrize("energy", [6e6, 3e7, 8e7, 1.2e8])
+def test_float32_map_derivatives_of_the_cavity_do_not_cancel(host_harness, energy):
+    """
+    cavity.py:296-305: r55_cor carries the bracket g0 g1 (beta0 beta1 - 1) + 1, which cancels twice on an
+    ultra-relativistic beam; evaluated in float32 as the reference writes it, d M[4][4] / d(V, phase, f, L, E) was 15-35 %
+    off at gamma ~ 150-230 (BASELINE config 5's later cavities) -- and with it every float32 gradient w.r.t. a cavity
+    parameter of a loss that sees the (s, delta) plane.  The dual-number instantiation uses an equal form without the
+    cancellation (lynx_dual.hpp: cavity_r55_bracket_dual): every derivative of every map entry within 1e-4 of the
+    float64 evaluation.  (The forward builders keep the reference's operations.)
+    """
+    flags = _ffi.FLAG_CAV_BETA | _ffi.FLAG_CAV_GAIN | _ffi.FLAG_CAV_T5XX
+    p = np.array([1.0377, 1.5e7, 7.0, 1.3e9], dtype=np.float32)
+    e32 = np.float32(energy)
+    for seed in range(5):
+        _, dM32, _, _ = _dual32(host_harness, _ffi.KIND_CAVITY, flags, p, e32, seed)
+        _, dM64, _, _ = _dual(host_harness, _ffi.KIND_CAVITY, flags, p.astype(np.float64), float(e32), seed, True)
+        assert np.all(np.abs(dM32 - dM64) <= 1e-4 * np.abs(dM64) + 1e-30), (seed, dM32[32], dM64[32])
