@@ -210,6 +210,15 @@ int lynx_track_particles(lynx_ctx* ctx, lynx_lattice* lat, int64_t n_particles,
                          const void* d_energy_in, const void* d_p_in, void* d_p_out,
                          void* d_energy_out, double* d_moments_out, int flags, double* d_observations);
 
+/* The allocating form: `Segment.track` returns a NEW beam and leaves the incoming one alone (element.py:75-92), so the
+ * blocks of the outgoing beam come from the library's own pool -- one call where the caller of lynx_track_particles
+ * makes up to five.  d_out[4]: the particles [B][N][7]; the outgoing energy [B] (only if want_energy_out, else NULL);
+ * the moment records [B][36] float64 (only with LYNX_TRACK_MOMENTS / _COVARIANCE); the observations
+ * [B][n_observers][2] float64 (only if the program has observer steps).  The caller owns them (lynx_buf_free).
+ * On failure nothing is allocated and all four are NULL.                                                          */
+int lynx_track_particles_new(lynx_ctx* ctx, lynx_lattice* lat, int64_t n_particles, const void* d_energy_in,
+                             const void* d_p_in, int flags, int32_t want_energy_out, void** d_out);
+
 /* Segment.track on a ParameterBeam (reference: element.py:71-82 mu'=T mu, cov'=T cov T^T;
  * cavity.py:134-140,202-218).  d_mu [B][7], d_cov [B][7][7] (in/out may alias).            */
 int lynx_track_moments(lynx_ctx* ctx, lynx_lattice* lat, const void* d_energy_in,

@@ -87,6 +87,7 @@ SIGNATURES = {
     "lynx_lattice_destroy": (_i, [_vp]),
     "lynx_build_compose": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "lynx_track_particles": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "lynx_track_particles_new": (_i, [_vp, _vp, _i64, _vp, _vp, _i, C.c_int32, C.POINTER(_vp)]),
     "lynx_track_moments": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "lynx_track_particles_backward": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "lynx_track_moments_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

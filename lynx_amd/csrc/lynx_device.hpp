@@ -998,16 +998,22 @@ __device__ __forceinline__ void merged_pair_entry(const float* pre /*14*/, const
 }
 
 // ---------------------------------------------------------------------------------------
-// k_build: standalone build+compose, one workgroup per sample: 256 threads and chunks of up to
-// 64 elements when the batch fills the GPU, 1024 threads and chunks of up to 128 when it does not
-// (a single sample's 128-element lattice is then 7 tree levels deep instead of two rounds of 6).
+// k_build: standalone build+compose, one workgroup of 256 threads per sample; chunks of up to 64 elements
+// when the batch fills the GPU, of up to 128 when it does not (a single sample's 128-element lattice is
+// then 7 tree levels deep instead of two rounds of 6; lynx_hip.hip: build_shape).
+// (Round 4 tried the tree's 7x7 products on the matrix cores -- v_mfma_f64_16x16x4_f64, two products per wave as the
+// diagonal blocks of a 14x14 one: correct, 205 GPU tests green, and SLOWER: 13.8 us against 11.3 for one sample's
+// 128-element float64 lattice.  A level is latency, not arithmetic: an LDS read, two dependent matrix instructions and
+// an LDS write per pair of products, in a loop the waves walk serially; the vector form keeps seven independent
+// multiply-add chains per lane in flight.  Where the 11 us go: launch 2.5, element maps 4.7 (one float64 quadrupole:
+// sqrt, cos, sin, cosh, sinh and six divisions, one dependent chain), tree ~3, table write 0.5.)
 // Depends on the lattice and the incoming energy only -- not on the particles -- so consecutive
 // `track` calls can run it on a second stream underneath the previous call's streaming kernel.
 // The outgoing energy is parked in the last step's row (LYNX_ENERGY_OFFSET) for the streaming
 // kernel to publish; `energy_out` is only used by the synchronous lynx_build_compose entry.
 // ---------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(1024) void k_build(LatticeDev lat, const T* __restrict__ energy_in,
+__global__ __launch_bounds__(256) void k_build(LatticeDev lat, const T* __restrict__ energy_in,
                                                 T* __restrict__ steps_out, T* __restrict__ energy_out,
                                                 int chunk, int merge_pairs) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1947,6 +1953,124 @@ __global__ __launch_bounds__(THREADS) void k_reduce_moments(const double* __rest
   }
 }
 
+// k_reduce_moments_ticket: both levels of the tree in ONE launch, for beams whose samples have more records than one
+// workgroup should walk (a B = 1 beam of 1 M particles has 1954, of 8 M ~8000).  grid = B x groups, groups <= 64.
+// Every workgroup adds its group's rows up exactly like the level form above, publishes the group's record and takes a
+// ticket of its sample; the workgroup that draws the last ticket adds the group records in group order (so the result
+// does not depend on who arrives last) and writes the sample's moment record.  A launch less per call: kernels of
+// one queue follow each other without a gap, but every one of these small ones takes 5-6 us from dispatch to retirement
+// (BASELINE config 3: 5.8 + 5.8 us -> one launch).
+// Coherence: the eight XCDs' L2 caches are not coherent with each other.  Group records are written and read with
+// agent-scope atomic accesses (they bypass the L2 of the writer and of the reader), the ticket is an agent-scope
+// acquire-release read-modify-write; this kernel runs behind the streaming kernel's end-of-kernel write-back, so
+// there is no dirty streaming data for the release to push out (the same protocol INSIDE the streaming kernel cost more
+// than the launch it saved: round 2).
+template <int THREADS, int STAGE>
+__global__ __launch_bounds__(THREADS) void k_reduce_moments_ticket(const double* __restrict__ in, int rows, int rows_per_group,
+                                                                    int groups, double* level /* [B][groups][36] */,
+                                                                    unsigned int* tickets /* [B], zero between launches */,
+                                                                    double* __restrict__ out) {
+  constexpr int kSets = THREADS / kPartialStride;
+  static_assert(STAGE % kSets == 0 && STAGE >= 64, "every set takes the same number of staged rows; the second level fits one pass");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* s_rows = reinterpret_cast<double*>(smem_raw);        // [STAGE][36]
+  double* s_set = s_rows + STAGE * kPartialStride;              // [kSets][36]
+  double* s = s_set + kSets * kPartialStride;                   // [36]
+  __shared__ int s_last;
+  const int64_t b = blockIdx.x / groups;
+  const int g = blockIdx.x % groups;
+  const int tid = threadIdx.x;
+  const int q = tid / kPartialStride, j = tid - q * kPartialStride;
+  int mi = 0, mj = 0;
+  if (j >= 7 && j < 28) {
+    int k = j - 7, len = 6;
+    while (k >= len) { k -= len; --len; ++mi; }
+    mj = mi + k;
+  }
+  // rows [0, n) staged in s_rows, reference point = the first one's: this thread's share of the sums (moment_slot_moved)
+  const auto add_staged = [&](int n, double v) {
+    if (q < kSets && (j < 28 || j == 35)) {
+      if (j == 6 || j == 35) {
+#pragma unroll 4
+        for (int r = q; r < n; r += kSets) v += s_rows[r * kPartialStride + j];
+      } else if (j < 6) {
+        const double c0j = s[28 + j];
+#pragma unroll 4
+        for (int r = q; r < n; r += kSets) {
+          const double* row = s_rows + r * kPartialStride;
+          v += row[j] + row[35] * (row[28 + j] - c0j);
+        }
+      } else {
+        const double c0i = s[28 + mi], c0j = s[28 + mj];
+#pragma unroll 4
+        for (int r = q; r < n; r += kSets) {
+          const double* row = s_rows + r * kPartialStride;
+          const double ei = row[28 + mi] - c0i, ej = row[28 + mj] - c0j;
+          v += row[j] + ei * row[mj] + row[mi] * ej + row[35] * ei * ej;
+        }
+      }
+    }
+    return v;
+  };
+  const auto fold_sets = [&](double v) {
+    if (q < kSets) s_set[q * kPartialStride + j] = v;
+    __syncthreads();
+    if (tid < kPartialStride && (tid < 28 || tid == 35)) {
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < kSets; ++k) t += s_set[k * kPartialStride + tid];
+      s[tid] = t;
+    }
+    __syncthreads();
+  };
+  // level one: this group's rows
+  const int lo = g * rows_per_group;
+  const int hi = (lo + rows_per_group) < rows ? (lo + rows_per_group) : rows;
+  const double* src = in + (b * (int64_t)rows + lo) * kPartialStride;
+  double v = 0.0;
+  for (int base = 0; base < hi - lo; base += STAGE) {
+    const int n_stage = (hi - lo - base) < STAGE ? (hi - lo - base) : STAGE;
+    __syncthreads();
+    constexpr int kPerThread = (STAGE * kPartialStride + THREADS - 1) / THREADS;
+    double staged[kPerThread];
+#pragma unroll
+    for (int k = 0; k < kPerThread; ++k) {
+      const int i = tid + k * THREADS;
+      staged[k] = i < n_stage * kPartialStride ? src[(int64_t)base * kPartialStride + i] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < kPerThread; ++k) {
+      const int i = tid + k * THREADS;
+      if (i < n_stage * kPartialStride) s_rows[i] = staged[k];
+    }
+    __syncthreads();
+    if (base == 0 && tid < 8) s[28 + tid] = tid < 7 ? s_rows[28 + tid] : 0.0;
+    __syncthreads();
+    v = add_staged(n_stage, v);
+  }
+  fold_sets(v);
+  // publish, take a ticket
+  double* mine = level + (b * (int64_t)groups + g) * kPartialStride;
+  if (tid < kPartialStride) __hip_atomic_store(mine + tid, s[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();  // (s_waitcnt in front of the barrier: the stores have been issued by every thread)
+  if (tid == 0) {
+    const unsigned int ticket = __hip_atomic_fetch_add(tickets + b, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = ticket == (unsigned int)(groups - 1);
+  }
+  __syncthreads();
+  if (!s_last) return;  // uniform
+  // level two: the group records, in group order
+  const double* lv = level + b * (int64_t)groups * kPartialStride;
+  for (int i = tid; i < groups * kPartialStride; i += THREADS)
+    s_rows[i] = __hip_atomic_load(lv + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (tid < 8) s[28 + tid] = tid < 7 ? s_rows[28 + tid] : 0.0;
+  __syncthreads();
+  fold_sets(add_staged(groups, 0.0));
+  write_moment_record(s, out + b * LYNX_MOMENT_STRIDE, tid);
+  if (tid == 0) __hip_atomic_store(tickets + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+}
+
 // k_reduce_observers: per-workgroup sums of x and y at the observers -> BPM readings [B][n_observers][2]
 // (mean x, mean y of the beam entering each active BPM), chunks added in chunk order.
 __global__ __launch_bounds__(64) void k_reduce_observers(const double* __restrict__ obs_partials, int chunks,
@@ -1967,7 +2091,7 @@ __global__ __launch_bounds__(64) void k_reduce_observers(const double* __restric
 // parallelises over elements.  The moment propagation itself uses 49 lanes.
 // ---------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(1024) void k_track_moments(LatticeDev lat, const T* __restrict__ energy_in,
+__global__ __launch_bounds__(256) void k_track_moments(LatticeDev lat, const T* __restrict__ energy_in,
                                                         const T* mu_in, const T* cov_in, T* mu_out,
                                                         T* cov_out, T* __restrict__ energy_out, int chunk) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];

@@ -43,7 +43,8 @@ struct Knobs {
   int pair_levels_fused = 1;  // LYNX_PAIR_LEVELS_FUSED narrow pair trees in one launch (wide ones always take one per level)
   int fuse_max_chunks = 0;    // LYNX_FUSE_MAX_CHUNKS   fused build prologue for samples of <= n workgroups (0: never)
   int merge_steps = 1;        // LYNX_MERGE_STEPS       [run, cavity] pairs as one unit
-  int reduce_wide = 1;        // LYNX_REDUCE_WIDE       one 1024-thread reduction for beams of few samples
+  int reduce_wide = 0;        // LYNX_REDUCE_WIDE       1: one 1024-thread workgroup per sample for beams of few samples with a few hundred records each
+  int reduce_ticket = 1;      // LYNX_REDUCE_TICKET     samples with more records than one workgroup walks: both levels in one launch (0: two launches)
   int track_units = 1;        // LYNX_TRACK_UNITS       structured step loop (2: insist)
   int bwd_units = 1;          // LYNX_BWD_UNITS         structured reverse pass
   int bwd_merge = 1;          // LYNX_BWD_MERGE         merged pairs in the reverse pass
@@ -61,7 +62,7 @@ static void load_knobs(Knobs* k) {
       {"LYNX_GATHER_OVERLAP", &k->gather_overlap}, {"LYNX_LANES_BUILD_MIN_BATCH", &k->lanes_build_min_batch},
       {"LYNX_PIECE", &k->piece}, {"LYNX_PAIR_LEVELS_FUSED", &k->pair_levels_fused},
       {"LYNX_FUSE_MAX_CHUNKS", &k->fuse_max_chunks}, {"LYNX_MERGE_STEPS", &k->merge_steps},
-      {"LYNX_REDUCE_WIDE", &k->reduce_wide}, {"LYNX_TRACK_UNITS", &k->track_units}, {"LYNX_BWD_UNITS", &k->bwd_units},
+      {"LYNX_REDUCE_WIDE", &k->reduce_wide}, {"LYNX_REDUCE_TICKET", &k->reduce_ticket}, {"LYNX_TRACK_UNITS", &k->track_units}, {"LYNX_BWD_UNITS", &k->bwd_units},
       {"LYNX_BWD_MERGE", &k->bwd_merge}, {"LYNX_BWD_PAIRS", &k->bwd_pairs}, {"LYNX_BUILD_IN_TAIL", &k->build_in_tail},
       {"LYNX_SMALL_INLINE", &k->small_inline}};
   for (const auto& t : table) {
@@ -113,6 +114,8 @@ struct lynx_ctx {
   // internal scratch (grown on demand, stream-ordered reuse)
   void* scratch_level = nullptr;  // second level of the moment reduction (long beams)
   size_t scratch_level_bytes = 0;
+  unsigned int* scratch_tickets = nullptr;  // ... and its per-sample tickets (k_reduce_moments_ticket): zero between launches
+  size_t scratch_tickets_count = 0;
   void* scratch_obs = nullptr;  // per-workgroup sums of x, y at the observers [B][chunks][2 * LYNX_MAX_OBSERVERS]
   size_t scratch_obs_bytes = 0;
   void* scratch_erun = nullptr;      // k_cavity_flags: every sample's energy on its way through the cavities
@@ -233,6 +236,14 @@ static int fail(lynx_ctx* ctx, int code, const std::string& msg) {
       return fail((ctx), LYNX_ERR_RCCL, std::string(#expr) + ": " + ncclGetErrorString(_e)); \
   } while (0)
 
+// The context's device as this thread's current one.  hipGetDevice reads a thread-local of the runtime; hipSetDevice,
+// which every entry point used to call, takes the runtime's lock -- once per thread is enough.
+static hipError_t use_device(lynx_ctx* ctx) {
+  int current = -1;
+  if (hipGetDevice(&current) == hipSuccess && current == ctx->device) return hipSuccess;
+  return hipSetDevice(ctx->device);
+}
+
 static size_t dtype_size(int dtype) { return dtype == LYNX_F64 ? 8 : 4; }
 
 static size_t size_class(size_t bytes) {
@@ -333,6 +344,19 @@ static int ensure_scratch(lynx_ctx* ctx, void** buf, size_t* have, size_t need) 
   return LYNX_OK;
 }
 
+// per-sample tickets of k_reduce_moments_ticket, zeroed when they are (re)allocated; the kernel leaves them zero
+static int ensure_tickets(lynx_ctx* ctx, size_t count) {
+  if (ctx->scratch_tickets_count >= count) return LYNX_OK;
+  void* buf = ctx->scratch_tickets;
+  size_t have = ctx->scratch_tickets_count * sizeof(unsigned int);
+  const int rc = ensure_scratch(ctx, &buf, &have, std::max<size_t>(count, 1024) * sizeof(unsigned int));
+  if (rc) return rc;
+  ctx->scratch_tickets = (unsigned int*)buf;
+  ctx->scratch_tickets_count = have / sizeof(unsigned int);
+  HIP_TRY(ctx, hipMemset(buf, 0, have));
+  return LYNX_OK;
+}
+
 // The API functions below get C linkage from their declarations in include/lynx_hip.h.
 
 const char* lynx_version(void) { return "lynxhip 0.1.0 (gfx950)"; }
@@ -425,6 +449,7 @@ int lynx_ctx_destroy(lynx_ctx* ctx) {
   for (auto& kv : ctx->free_blocks) (void)hipFree(kv.second);
   for (auto& kv : ctx->live) (void)hipFree(kv.first);
   if (ctx->scratch_level) (void)hipFree(ctx->scratch_level);
+  if (ctx->scratch_tickets) (void)hipFree(ctx->scratch_tickets);
   if (ctx->scratch_obs) (void)hipFree(ctx->scratch_obs);
   if (ctx->scratch_erun) (void)hipFree(ctx->scratch_erun);
   if (ctx->scratch_products) (void)hipFree(ctx->scratch_products);
@@ -530,7 +555,7 @@ static int join_side(lynx_ctx* ctx) {
 }
 
 int lynx_sync(lynx_ctx* ctx) {
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, use_device(ctx));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   const int rc = wait_for_side(ctx);
   return rc ? rc : check_status(ctx);
@@ -629,7 +654,7 @@ int lynx_ctx_reload_knobs(lynx_ctx* ctx) {
 }
 
 int lynx_buf_alloc(lynx_ctx* ctx, size_t bytes, void** d_out) {
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, use_device(ctx));
   return ctx_alloc(ctx, bytes, d_out);
 }
 
@@ -759,7 +784,7 @@ int lynx_lattice_create(lynx_ctx* ctx, int dtype, int64_t batch, int32_t n_elems
   }
   if (next != n_elems) return fail(ctx, LYNX_ERR_INVALID, "steps do not cover every element");
 
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, use_device(ctx));
   lynx_lattice* lat = new lynx_lattice();
   lat->ctx = ctx;
   lat->dtype = dtype;
@@ -877,22 +902,24 @@ static int allow_lds(lynx_ctx* ctx, K kernel, size_t bytes) {
 
 // ---- build + compose -------------------------------------------------------------------
 
-// Launch shape of k_build: 256 threads and chunks of <= 64 elements (<= 32 for float32 lattices, whose
-// staging area would otherwise halve the resident workgroups) when the batch fills the GPU; 1024
-// threads and chunks of <= 128 when it does not -- then the tree depth is what a call waits for.
-// The wide shape is for a build the GPU has to itself: 16 waves and ~110 KB of LDS per workgroup cannot be placed on a
-// CU before all of a streaming kernel's workgroups there have drained, so a build that runs underneath the previous
-// call's streaming kernel (`underneath`) keeps the narrow shape (128-sample shard of BASELINE config 4: 18 us alone
-// either way, 117-150 us wide vs the narrow shape's share of the GPU under the streaming kernel).
+// Launch shape of k_build: 256 threads; chunks of <= 64 elements (<= 32 for float32 lattices, whose staging area
+// would otherwise halve the resident workgroups) when the batch fills the GPU, of <= 128 when it does not -- then the
+// tree depth is what a call waits for.  (Round 2 gave such a build 1024 threads; measured alone on one sample's
+// 128-element float64 FODO, scripts/gpu/experiments/build_phases.hip: 1024 threads 18.0 us, 512: 13.1, 256: 11.3,
+// 128: 13.6 -- sixteen waves of eight busy lanes each fetch the builders' code sixteen times and take 8.4 us for the
+// first quadrupole where four waves of 32 take 4.6.)
+// The long chunk needs ~90-115 KB of LDS: such a workgroup cannot be placed on a CU before a streaming kernel's
+// workgroups there have drained, so a build that runs underneath the previous call's streaming kernel (`underneath`)
+// keeps the short one (128-sample shard of BASELINE config 4: 18 us alone either way, 117-150 us with the long chunk vs
+// the short chunk's share of the GPU under the streaming kernel).
 template <typename T>
 static void build_shape(lynx_ctx* ctx, const lynx_lattice* lat, bool underneath, int* threads, int* chunk) {
   const int64_t cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
-  const bool wide = lat->batch * 2 <= cus && !underneath;
-  *threads = wide ? 1024 : 256;
+  const bool deep = lat->batch * 2 <= cus && !underneath;
+  *threads = 256;
   // (float32, at most one workgroup per CU: 64 again -- half the rounds; the 128-sample shard of BASELINE config 4
   // underneath its streaming kernel: 0.1573 -> 0.1543 ms/step, medians of four, same box)
-  int limit = wide ? 128 : ((sizeof(T) == 4 && lat->batch > cus) ? 32 : 64);
-  if (limit > *threads) limit = *threads;
+  const int limit = deep ? 128 : ((sizeof(T) == 4 && lat->batch > cus) ? 32 : 64);
   *chunk = build_chunk(lat->n_elems, limit);
 }
 
@@ -1054,7 +1081,7 @@ int lynx_build_compose(lynx_ctx* ctx, lynx_lattice* lat, const void* d_energy_in
                        void* d_energy_out) {
   if (!ctx || !lat || !d_energy_in || !d_steps_out) return fail(ctx, LYNX_ERR_INVALID, "null argument");
   if (lat->batch > 0x7fffffffLL) return fail(ctx, LYNX_ERR_INVALID, "batch too large");
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, use_device(ctx));
   ctx->main_dirty = true;
   return lat->dtype == LYNX_F64 ? launch_build<double>(ctx, lat, ctx->stream, d_energy_in, d_steps_out, d_energy_out)
                                 : launch_build<float>(ctx, lat, ctx->stream, d_energy_in, d_steps_out, d_energy_out);
@@ -1340,6 +1367,7 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
   int rc;
   int slot = -1;
   bool async_build = false;
+  bool short_call = false;
   if (S > 0 && !fused) {
     slot = (int)(ctx->seq++ % (unsigned)lynx_ctx::kTableSlots);
     const size_t need = (size_t)B * S * LYNX_STEP_STRIDE * sizeof(T);
@@ -1360,7 +1388,20 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
     // The second stream pays once the streaming kernel is long enough to hide a build under; below half a
     // million particles per call the extra event traffic costs more host time than the overlap returns
     // (BASELINE config 2: 31 -> 46 us per call with it).
-    const bool async = knob(ctx->knobs.async_build, B * N >= (int64_t)512 << 10 ? 1 : 0) != 0;
+    // SHORT calls in between (from half a million particles up to 128 MB of them: BASELINE config 3, 1 M particles,
+    // 29 us of kernel) take what the queue says: kernels of one queue follow each other without a gap, a hop to
+    // another queue costs 10-20 us of latency (kernel timeline, profiles/r04_*_timeline.txt).  If the main stream is
+    // IDLE -- the caller waits for every result -- there is nothing to hide the build under and the hops are pure
+    // loss: build, stream and reduce back to back on the main stream, no event at all.  If it is BUSY -- calls are
+    // pipelined -- the build goes to the second stream, where it runs underneath the previous call's kernels, and only
+    // the reduction stays in line (the side stream's hop is worth it for long kernels only).
+    const bool half_million = B * N >= (int64_t)512 << 10;
+    short_call = half_million && (size_t)B * N * 7 * sizeof(T) < ((size_t)128 << 20) && !lat->has_cavity;
+    bool inline_all = false;
+    if (short_call && ctx->knobs.async_build < 0)
+      inline_all = knob(ctx->knobs.small_inline, hipStreamQuery(ctx->stream) == hipSuccess ? 1 : 0) != 0;
+    (void)hipGetLastError();  // hipErrorNotReady of the query is an answer, not an error
+    const bool async = knob(ctx->knobs.async_build, half_million && !inline_all ? 1 : 0) != 0;
     async_build = async;
     hipStream_t bs = async ? ctx->s_build : ctx->stream;
     if (async) {
@@ -1368,7 +1409,7 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
       if (ctx->streamed_valid[slot]) HIP_TRY(ctx, hipStreamWaitEvent(bs, ctx->ev_streamed[slot], 0));
       // ... and the build starts in the TAIL of the streaming kernel before the one enqueued last (which has the GPU
       // to itself when it gets there), not at that kernel's head
-      tail = ctx->can_wait_value && ctx->knobs.build_in_tail;
+      tail = ctx->can_wait_value && ctx->knobs.build_in_tail && !short_call;  // (a short kernel has no tail worth waiting for)
       if (tail && ctx->tail_seq >= 2)
         HIP_TRY(ctx, hipStreamWaitValue32(bs, ctx->d_tail_flag, ctx->tail_seq - 1, hipStreamWaitValueGte, 0xffffffffu));
       // what the build reads (energy, lattice pool) may have been written on the main stream
@@ -1435,7 +1476,7 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
   lynx_ctx::PartialSlot* ring = nullptr;
   // The reduction leaves the main stream once the streaming kernel is long enough to hide it under (same threshold
   // as the build's second stream: below it the extra event traffic costs more host time than it returns).
-  const bool side = moments && knob(ctx->knobs.side_reduce, B * N >= (int64_t)512 << 10 ? 1 : 0) != 0;
+  const bool side = moments && knob(ctx->knobs.side_reduce, (B * N >= (int64_t)512 << 10 && !short_call) ? 1 : 0) != 0;
   if (moments) {
     ring = &ctx->partial_ring[ctx->partial_seq++ % lynx_ctx::kPartialRing];
     if (ring->pending) {
@@ -1498,7 +1539,7 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
     }
     int rows = p.a.chunks;
     const double* level_in = d_partials;
-    const bool wide = B <= 4 && rows > kReduceStage && rows <= 3 * kReduceStageWide && ctx->knobs.reduce_wide;
+    const bool wide = B <= 4 && rows > kReduceStage && rows <= 3 * kReduceStageWide && ctx->knobs.reduce_wide == 1;
     if (wide) {
       constexpr size_t lds = reduce_lds_bytes<1024, kReduceStageWide>();
       if ((rc = allow_lds(ctx, k_reduce_moments<true, 1024, kReduceStageWide>, lds))) return rc;
@@ -1508,7 +1549,7 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
     } else {
       constexpr size_t lds = reduce_lds_bytes<256, kReduceStage>();
       if (rows > kReduceStage) {
-        const int rpg = (rows + 63) / 64;
+        const int rpg = std::max((rows + 63) / 64, B <= 4 ? 32 : 1);  // (few samples: no point in groups of a handful of rows)
         const int groups = (rows + rpg - 1) / rpg;
         const size_t need = (size_t)B * groups * kPartialStride * sizeof(double);
         // one buffer: its users follow each other on one stream (side or main), and a change of stream joins first
@@ -1522,15 +1563,26 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
           }
           ctx->level_on_side = side;
         }
-        hipLaunchKernelGGL((k_reduce_moments<false, 256, kReduceStage>), dim3((unsigned)(B * groups)), dim3(256), lds, rs,
-                           level_in, rows, rpg, groups, (double*)ctx->scratch_level);
-        HIP_TRY(ctx, hipGetLastError());
-        level_in = (const double*)ctx->scratch_level;
-        rows = groups;
+        if (ctx->knobs.reduce_ticket) {
+          // both levels in one launch: the workgroup that draws a sample's last ticket adds its group records up
+          if ((rc = ensure_tickets(ctx, (size_t)B))) return rc;
+          hipLaunchKernelGGL((k_reduce_moments_ticket<256, kReduceStage>), dim3((unsigned)(B * groups)), dim3(256), lds, rs,
+                             level_in, rows, rpg, groups, (double*)ctx->scratch_level, ctx->scratch_tickets, d_moments_out);
+          HIP_TRY(ctx, hipGetLastError());
+          rows = 0;
+        } else {
+          hipLaunchKernelGGL((k_reduce_moments<false, 256, kReduceStage>), dim3((unsigned)(B * groups)), dim3(256), lds, rs,
+                             level_in, rows, rpg, groups, (double*)ctx->scratch_level);
+          HIP_TRY(ctx, hipGetLastError());
+          level_in = (const double*)ctx->scratch_level;
+          rows = groups;
+        }
       }
-      hipLaunchKernelGGL((k_reduce_moments<true, 256, kReduceStage>), dim3((unsigned)B), dim3(256), lds, rs, level_in,
-                         rows, rows, 1, d_moments_out);
-      HIP_TRY(ctx, hipGetLastError());
+      if (rows > 0) {
+        hipLaunchKernelGGL((k_reduce_moments<true, 256, kReduceStage>), dim3((unsigned)B), dim3(256), lds, rs, level_in,
+                           rows, rows, 1, d_moments_out);
+        HIP_TRY(ctx, hipGetLastError());
+      }
     }
     if (side) {
       // one event: the ring slot's.  The host has seen its previous recording complete before this call took the
@@ -1558,13 +1610,39 @@ int lynx_track_particles(lynx_ctx* ctx, lynx_lattice* lat, int64_t n_particles, 
     return fail(ctx, LYNX_ERR_INVALID, "LYNX_TRACK_MOMENTS / LYNX_TRACK_COVARIANCE need d_moments_out");
   if ((flags & LYNX_TRACK_SHARED_INPUT) && d_p_in == d_p_out)
     return fail(ctx, LYNX_ERR_INVALID, "a shared incoming beam cannot be tracked in place");
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, use_device(ctx));
   LatticeDev lv = dev_view(lat);
   return lat->dtype == LYNX_F64
              ? track_particles_t<double>(ctx, lat, lv, lat->batch, n_particles, d_energy_in, d_p_in, d_p_out,
                                          d_energy_out, d_moments_out, flags, d_observations)
              : track_particles_t<float>(ctx, lat, lv, lat->batch, n_particles, d_energy_in, d_p_in, d_p_out,
                                         d_energy_out, d_moments_out, flags, d_observations);
+}
+
+int lynx_track_particles_new(lynx_ctx* ctx, lynx_lattice* lat, int64_t n_particles, const void* d_energy_in,
+                             const void* d_p_in, int flags, int32_t want_energy_out, void** d_out /* [4] */) {
+  if (!ctx || !lat || !d_out) return fail(ctx, LYNX_ERR_INVALID, "null argument");
+  for (int k = 0; k < 4; ++k) d_out[k] = nullptr;
+  if (n_particles <= 0) return fail(ctx, LYNX_ERR_INVALID, "n_particles must be > 0");
+  const size_t es = dtype_size(lat->dtype);
+  const bool moments = (flags & (LYNX_TRACK_MOMENTS | LYNX_TRACK_COVARIANCE)) != 0;
+  int rc = ctx_alloc(ctx, (size_t)lat->batch * (size_t)n_particles * 7 * es, &d_out[0]);
+  if (!rc && want_energy_out) rc = ctx_alloc(ctx, (size_t)lat->batch * es, &d_out[1]);
+  if (!rc && moments) rc = ctx_alloc(ctx, (size_t)lat->batch * LYNX_MOMENT_STRIDE * sizeof(double), &d_out[2]);
+  if (!rc && lat->n_observers > 0) rc = ctx_alloc(ctx, (size_t)lat->batch * lat->n_observers * 2 * sizeof(double), &d_out[3]);
+  if (!rc)
+    rc = lynx_track_particles(ctx, lat, n_particles, d_energy_in, d_p_in, d_out[0], d_out[1], (double*)d_out[2], flags,
+                              (double*)d_out[3]);
+  if (rc) {  // nothing was enqueued on these blocks (every check of lynx_track_particles comes before its first launch ...
+    const std::string why = ctx->err;
+    (void)hipStreamSynchronize(ctx->stream);  // ... but a failure halfway through a launch sequence may have: drain first)
+    for (int k = 0; k < 4; ++k) {
+      if (d_out[k]) (void)ctx_free(ctx, d_out[k]);
+      d_out[k] = nullptr;
+    }
+    ctx->err = why;
+  }
+  return rc;
 }
 
 // ---- reverse pass -----------------------------------------------------------------------
@@ -1686,7 +1764,7 @@ int lynx_track_particles_backward(lynx_ctx* ctx, lynx_lattice* lat, int64_t n_pa
   if (!ctx || !lat || !d_energy_in || !d_p_in || !d_moments_fwd || !d_grad_moments || !d_grad_params || !d_grad_energy_in)
     return fail(ctx, LYNX_ERR_INVALID, "null argument");
   if (n_particles <= 0 || lat->n_steps <= 0) return fail(ctx, LYNX_ERR_INVALID, "empty program or beam");
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, use_device(ctx));
   {
     const int rc = join_side(ctx);  // d_moments_fwd is what a reduction on the side stream writes
     if (rc) return rc;
@@ -1747,7 +1825,7 @@ int lynx_track_moments_backward(lynx_ctx* ctx, lynx_lattice* lat, const void* d_
     return fail(ctx, LYNX_ERR_INVALID, "null argument");
   if (lat->n_steps <= 0) return fail(ctx, LYNX_ERR_INVALID, "empty program");
   if (lat->batch > 0x7fffffffLL) return fail(ctx, LYNX_ERR_INVALID, "batch too large");
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, use_device(ctx));
   return lat->dtype == LYNX_F64
              ? moments_backward_t<double>(ctx, lat, d_energy_in, d_mu_in, d_cov_in, d_mu_bar, d_cov_bar, d_grad_params,
                                           d_grad_energy_in, d_grad_mu_in, d_grad_cov_in)
@@ -1759,7 +1837,7 @@ int lynx_moments(lynx_ctx* ctx, int dtype, int64_t batch, int64_t n_particles, c
                  double* d_moments_out, int32_t covariance) {
   if (!ctx || !d_p || !d_moments_out) return fail(ctx, LYNX_ERR_INVALID, "null argument");
   if (batch <= 0 || n_particles <= 0) return fail(ctx, LYNX_ERR_INVALID, "bad shape");
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, use_device(ctx));
   LatticeDev lv;
   memset(&lv, 0, sizeof(lv));
   lv.batch = batch;
@@ -1788,12 +1866,12 @@ static int launch_track_moments(lynx_ctx* ctx, lynx_lattice* lat, const void* d_
     HIP_TRY(ctx, hipGetLastError());
     return LYNX_OK;
   }
-  // one workgroup per sample: one wave for big batches, four for medium ones, sixteen (and chunks of up to
-  // 128 elements) when the batch leaves most of the GPU idle and the depth of the tree is what the call waits for
+  // one workgroup per sample: one wave for big batches, four otherwise -- with chunks of up to 128 elements when the
+  // batch leaves most of the GPU idle and the depth of the tree is what the call waits for (build_shape)
   const int64_t cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
-  const bool wide = lat->batch * 2 <= cus;
-  const unsigned threads = wide ? 1024u : (lat->batch <= 4096 ? 256u : 64u);
-  const int chunk = build_chunk(lat->n_elems, wide ? 128 : 64);
+  const bool deep = lat->batch * 2 <= cus;
+  const unsigned threads = lat->batch <= 4096 ? 256u : 64u;
+  const int chunk = build_chunk(lat->n_elems, deep ? 128 : 64);
   const size_t lds = build_scratch_bytes(chunk, sizeof(T)) +
                      ((size_t)lat->n_steps * LYNX_STEP_STRIDE + lat->n_steps + 1 + 8 + 49 + 49 + 16) * sizeof(T);
   rc = allow_lds(ctx, k_track_moments<T>, lds);
@@ -1811,7 +1889,7 @@ int lynx_track_moments(lynx_ctx* ctx, lynx_lattice* lat, const void* d_energy_in
   if (!ctx || !lat || !d_energy_in || !d_mu_in || !d_cov_in || !d_mu_out || !d_cov_out)
     return fail(ctx, LYNX_ERR_INVALID, "null argument");
   if (lat->batch > 0x7fffffffLL) return fail(ctx, LYNX_ERR_INVALID, "batch too large");
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, use_device(ctx));
   ctx->main_dirty = true;
   return lat->dtype == LYNX_F64
              ? launch_track_moments<double>(ctx, lat, d_energy_in, d_mu_in, d_cov_in, d_mu_out, d_cov_out, d_energy_out)
@@ -1824,7 +1902,7 @@ int lynx_histogram2d(lynx_ctx* ctx, int dtype, int64_t batch, int64_t n_particle
                      const void* d_xedges, const void* d_yedges, int32_t nx, int32_t ny, int32_t* d_image) {
   if (!ctx || !d_p || !d_xedges || !d_yedges || !d_image || batch <= 0 || n_particles <= 0 || nx <= 0 || ny <= 0)
     return fail(ctx, LYNX_ERR_INVALID, "bad argument");
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, use_device(ctx));
   const size_t es = dtype_size(dtype);
   const size_t lds = ((size_t)nx + ny + 2) * es;
   if (lds > 64 * 1024) return fail(ctx, LYNX_ERR_INVALID, "screen resolution too large for the edge table");
@@ -1846,7 +1924,7 @@ int lynx_histogram2d(lynx_ctx* ctx, int dtype, int64_t batch, int64_t n_particle
 
 int lynx_diag_phase_trig(lynx_ctx* ctx, int64_t n, const float* d_x, int32_t packed, float* d_sin, float* d_cos) {
   if (!ctx || !d_x || !d_sin || !d_cos || n <= 0) return fail(ctx, LYNX_ERR_INVALID, "bad argument");
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, use_device(ctx));
   const int64_t threads = (n + 1) / 2;
   hipLaunchKernelGGL(k_diag_phase_trig, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, d_x, n,
                      (int)packed, d_sin, d_cos);
@@ -1862,7 +1940,7 @@ int lynx_aperture_mask(lynx_ctx* ctx, int dtype, int64_t batch, int64_t n_partic
   if (!ctx || !d_p || !d_x_max || !d_y_max || !d_mask || !d_counts || !d_offsets || !d_totals || batch <= 0 ||
       n_particles <= 0 || (param_stride != 0 && param_stride != 1))
     return fail(ctx, LYNX_ERR_INVALID, "bad argument");
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, use_device(ctx));
   const int64_t chunks = (n_particles + kApertureChunk - 1) / kApertureChunk;
   if (batch * chunks > 0x7fffffffLL) return fail(ctx, LYNX_ERR_INVALID, "grid too large");
   if (dtype == LYNX_F64)
@@ -1884,7 +1962,7 @@ int lynx_aperture_compact(lynx_ctx* ctx, int dtype, int64_t n_particles, const v
                           const int64_t* d_offsets, void* d_kept, void* d_lost) {
   if (!ctx || !d_p || !d_mask || !d_offsets || !d_kept || !d_lost || n_particles <= 0)
     return fail(ctx, LYNX_ERR_INVALID, "bad argument");
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, use_device(ctx));
   const int64_t chunks = (n_particles + kApertureChunk - 1) / kApertureChunk;
   if (dtype == LYNX_F64)
     hipLaunchKernelGGL(k_aperture_compact<double>, dim3((unsigned)chunks), dim3(256), 0, ctx->stream, (const double*)d_p,
@@ -1900,7 +1978,7 @@ int lynx_gaussian_image(lynx_ctx* ctx, int dtype, int64_t batch, const void* d_m
                         const void* d_xs, const void* d_ys, int32_t nx, int32_t ny, void* d_image) {
   if (!ctx || !d_mu || !d_cov || !d_xs || !d_ys || !d_image || batch <= 0 || nx <= 0 || ny <= 0 || batch > 65535)
     return fail(ctx, LYNX_ERR_INVALID, "bad argument");
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, use_device(ctx));
   const unsigned gx = (unsigned)(((int64_t)nx * ny + 255) / 256);
   if (dtype == LYNX_F64)
     hipLaunchKernelGGL(k_gaussian_image<double>, dim3(gx, (unsigned)batch), dim3(256), 0, ctx->stream,
@@ -1920,7 +1998,7 @@ int lynx_fill_gaussian(lynx_ctx* ctx, int dtype, int64_t batch, int64_t n_partic
                        const double* sigma, uint64_t seed, void* d_p) {
   if (!ctx || !d_p || !mu || !sigma || batch <= 0 || n_particles <= 0)
     return fail(ctx, LYNX_ERR_INVALID, "bad argument");
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, use_device(ctx));
   GaussArgs g;
   for (int i = 0; i < 6; ++i) {
     g.mu[i] = mu[i];
@@ -1944,7 +2022,7 @@ int lynx_diag_copy(lynx_ctx* ctx, void* d_dst, const void* d_src, size_t bytes, 
   if (!ctx || !d_dst || !d_src || bytes % 16 || repeats <= 0 || vec_per_thread < 0 || per_thread > 64 ||
       (vec_per_thread >= 100 && per_thread == 0))
     return fail(ctx, LYNX_ERR_INVALID, "bad argument");
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, use_device(ctx));
   const int64_t n_vec = (int64_t)(bytes / 16);
   const int vpt = vec_per_thread;  // 0 = grid-stride
   const unsigned grid = per_thread > 0 ? (unsigned)((n_vec + 256LL * per_thread - 1) / (256LL * per_thread))
@@ -1977,7 +2055,7 @@ int lynx_comm_unique_id(char* id_out) {
 int lynx_comm_init(lynx_ctx* ctx, int n_ranks, int rank, const char* id) {
   if (!ctx || !id || n_ranks <= 0 || rank < 0 || rank >= n_ranks) return fail(ctx, LYNX_ERR_INVALID, "bad argument");
   if (ctx->comm) return fail(ctx, LYNX_ERR_INVALID, "communicator already initialised");
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, use_device(ctx));
   ncclUniqueId uid;
   memcpy(&uid, id, sizeof(uid));
   NCCL_TRY(ctx, ncclCommInitRank(&ctx->comm, n_ranks, uid, rank));
@@ -2016,7 +2094,7 @@ int lynx_comm_info(lynx_ctx* ctx, int32_t* rccl_version, int32_t* n_ranks, int32
 
 int lynx_gather_moments(lynx_ctx* ctx, const double* d_send, double* d_recv, int64_t count) {
   if (!ctx || !ctx->comm) return fail(ctx, LYNX_ERR_INVALID, "communicator not initialised");
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, use_device(ctx));
   // Default with more than one rank: the side stream.  With one rank (LYNX_FORCE_COMM rehearsals) the "gather" is
   // a copy; it follows the reduction wherever that ran.
   const bool produced_on_side = ctx->side_wrote && ctx->side_wrote == (const void*)d_send;

@@ -12,7 +12,6 @@ import atexit
 import ctypes as C
 import math
 import os
-import weakref
 
 import numpy as np
 
@@ -168,14 +167,39 @@ def get_runtime() -> Runtime:
 class DeviceArray:
     """A C-contiguous array in HBM.  `np.asarray(x)` copies it to the host."""
 
+    # (a plain finaliser instead of `weakref.finalize`: a tracking loop makes and drops three of these per call, and
+    # the registry entry of a `finalize` costs more than the allocation; `Runtime.closed` makes a late release a no-op)
+    __slots__ = ("rt", "shape", "dtype", "size", "nbytes", "ptr", "_base", "_owned", "__weakref__")
+
     def __init__(self, rt: Runtime, shape: tuple, dtype: np.dtype):
         self.rt = rt
         self.shape = shape
         self.dtype = dtype
         self.size = math.prod(shape)  # () -> 1; Python ints: no overflow
         self.nbytes = self.size * dtype.itemsize
+        self._base = None
+        self._owned = False
         self.ptr = rt.alloc(max(self.nbytes, 1))
-        self._finalizer = weakref.finalize(self, rt.free, self.ptr)
+        self._owned = True
+
+    @classmethod
+    def adopt(cls, rt: Runtime, ptr: int, shape: tuple, dtype: np.dtype) -> "DeviceArray":
+        """A block the library allocated for the caller (`lynx_track_particles_new`): this object now owns it."""
+        self = object.__new__(cls)
+        self.rt, self.shape, self.dtype, self.ptr = rt, shape, dtype, ptr
+        self.size = math.prod(shape)
+        self.nbytes = self.size * dtype.itemsize
+        self._base = None
+        self._owned = True
+        return self
+
+    def __del__(self):
+        try:
+            if self._owned:
+                self._owned = False
+                self.rt.free(self.ptr)
+        except Exception:  # interpreter teardown: attributes or modules may already be gone
+            pass
 
     @property
     def ndim(self) -> int:
@@ -207,7 +231,8 @@ class DeviceArray:
         view.size = int(np.prod(view.shape, dtype=np.int64)) if view.shape else 1
         assert view.size == self.size, "reshape must keep the number of elements"
         view.nbytes = self.nbytes
-        view._base = self  # keeps the owner (and its finalizer) alive
+        view._base = self  # keeps the owner alive
+        view._owned = False
         return view
 
     def copy(self) -> "DeviceArray":

@@ -18,9 +18,10 @@ from dataclasses import dataclass, field
 import numpy as np
 
 from . import _ffi, config
-from .device import Dual, dtype_code, get_runtime
+from .device import DeviceArray, Dual, dtype_code, get_runtime
 
 ELECTRON_MASS_EV = 510998.95069  # cavity.py:20
+_F64 = np.dtype(np.float64)
 
 _LATE = None
 
@@ -41,8 +42,10 @@ def _late():
         from .particles.parameter_beam import ParameterBeam
         from .particles.particle_beam import ParticleBeam
 
+        from .accelerator.segment import ElementList
+
         _LATE = SimpleNamespace(EPOCH=EPOCH, STRUCTURE=STRUCTURE, Segment=Segment, Beam=Beam,
-                                ParameterBeam=ParameterBeam, ParticleBeam=ParticleBeam)
+                                ParameterBeam=ParameterBeam, ParticleBeam=ParticleBeam, ElementList=ElementList)
     return _LATE
 
 
@@ -153,7 +156,9 @@ def plan(owner, elements, raw: bool, fuse_observers: bool = False) -> list:
             ids = (ids, tuple(identities(el.elements) for el in items if isinstance(el, Segment)))
         return ids
 
-    ids = identities(elements)
+    # a Segment's own list says when it is changed in place (ElementList bumps STRUCTURE, and so do the lists of nested
+    # segments): the list object itself stands for its contents; any other sequence is compared element by element
+    ids = id(elements) if type(elements) is late.ElementList else identities(elements)
     token = (STRUCTURE[0], raw, ids)
     remembered = owner.__dict__.setdefault("_plan", {}).get(fuse_observers)
     if remembered is not None and remembered[0] == token:
@@ -213,6 +218,7 @@ class PackedLattice:
         self.rt = None
         self._static = None
         self._has_cavity = False
+        self._ready_epoch = None
         self.versions = tuple(el._version for el in leaves)
 
     def _pack_element(self, el):
@@ -343,11 +349,17 @@ class LatticeCache:
 
 def _ready(cache: LatticeCache, program: Program, batch_shape, dtype, energy_host) -> PackedLattice:
     lat = cache.get(program, batch_shape, dtype)
+    # nothing an element holds has been written since this lattice's flags were last evaluated (EPOCH), and it has no
+    # cavity whose `assert Ei > 0` would have to look at THIS beam's energy: it is ready as it stands
+    epoch = _late().EPOCH[0]
+    if lat._ready_epoch == epoch and not lat._has_cavity and lat.handle is not None:
+        return lat
     elem_flags, step_flags = lat.evaluate_flags(energy_host)
     if lat.handle is None:
         lat.upload(get_runtime(), elem_flags, step_flags)
     else:
         lat.set_flags(elem_flags, step_flags)
+    lat._ready_epoch = epoch
     return lat
 
 
@@ -361,30 +373,38 @@ def _ptr(x):
 
 
 def run_program_particles(cache, program: Program, beam, moments: bool | None = None):
-    """One launch of the fused kernel: ParticleBeam -> ParticleBeam."""
+    """One pass of the streaming kernel: ParticleBeam -> ParticleBeam (`lynx_track_particles_new`)."""
     ParticleBeam = _late().ParticleBeam
     rt = get_runtime()
     dtype = beam.dtype
     batch_shape = beam.batch_shape
     lat = _ready(cache, program, batch_shape, dtype, beam._energy._host)  # no read-back: None if it lives in HBM only
     p_in = beam._particles.device(rt)  # (N, 7)-like storage when the beam is shared by the batch
-    p_out = rt.empty((*batch_shape, beam.num_particles, 7), dtype)
     e_in = beam._energy.broadcast_device(rt, batch_shape)
-    e_out = rt.empty(batch_shape, dtype) if lat.has_cavity_step else None
     want_moments = config.fused_moments if moments is None else moments
-    mom = rt.empty((*batch_shape, _ffi.MOMENT_STRIDE), np.float64) if want_moments else None
     flags = ((0 if not want_moments else _ffi.TRACK_COVARIANCE if config.fused_covariance else _ffi.TRACK_MOMENTS)
              | (_ffi.TRACK_TWO_KERNEL if config.two_kernel else 0)
              | (_ffi.TRACK_SHARED_INPUT if beam.is_shared else 0)
              | (0 if config.merge_steps else _ffi.TRACK_SEQUENTIAL_STEPS))
-    obs = rt.empty((lat.B, len(program.observers), 2), np.float64) if program.observers else None
-    rt.check(rt.lib.lynx_track_particles(rt.ctx, lat.handle, beam.num_particles, _ptr(e_in), _ptr(p_in),
-                                         _ptr(p_out), _ptr(e_out), _ptr(mom), flags, _ptr(obs)))
-    for k, (_, element) in enumerate(program.observers):
-        element._reading_from(obs, k, batch_shape, dtype)  # read back only if somebody looks at it
+    n = beam.num_particles
+    # the outgoing beam's blocks come from the library's pool inside the call: one crossing of the C boundary per
+    # `track` instead of one per array (a small call is bound by the host's enqueue rate)
+    blocks = (C.c_void_p * 4)()
+    status = rt.lib.lynx_track_particles_new(rt.ctx, lat.handle, n, e_in.ptr, p_in.ptr, flags,
+                                             1 if lat.has_cavity_step else 0, blocks)
+    if status:
+        rt.check(status)
+    adopt = DeviceArray.adopt
+    p_out = adopt(rt, blocks[0], (*batch_shape, n, 7), dtype)
+    e_out = adopt(rt, blocks[1], batch_shape, dtype) if blocks[1] else None
+    mom = adopt(rt, blocks[2], (*batch_shape, _ffi.MOMENT_STRIDE), _F64) if blocks[2] else None
+    if blocks[3]:
+        obs = adopt(rt, blocks[3], (lat.B, len(program.observers), 2), _F64)
+        for k, (_, element) in enumerate(program.observers):
+            element._reading_from(obs, k, batch_shape, dtype)  # read back only if somebody looks at it
     out = ParticleBeam.__new__(ParticleBeam)
     charges = beam._charges
-    if beam.is_shared and charges is not None:
+    if charges is not None and beam.is_shared:
         charges = np.ascontiguousarray(beam.particle_charges)
     out._init_raw(Dual(dev=p_out), Dual(dev=e_out) if e_out is not None else beam._energy,
                   charges, dtype, moments=Dual(dev=mom) if mom is not None else None)

@@ -187,22 +187,33 @@ def test_c2_ares_segment_particles(lx, n):
         _assert_moments(out, ref, np.float32)
 
 
-@pytest.mark.parametrize("dtype,n", [(np.float32, 100_000), (np.float64, 300_001)])
-def test_wide_reduction_matches_the_level_form(lx, dtype, n, monkeypatch):
+@pytest.mark.parametrize("dtype,n", [(np.float32, 100_000), (np.float64, 300_001), (np.float64, 1_000_000)])
+def test_the_three_forms_of_the_moment_reduction_agree(lx, dtype, n, monkeypatch):
     """
-    Beams of few samples: the workgroups' records are added up by ONE 1024-thread workgroup per sample (a few
-    hundred rows: BASELINE config 2's shape) instead of a level of groups and a final launch.  Both forms add the
-    same records, in a different association: the moment records agree to float64 rounding, and with the oracle.
+    Beams of few samples with hundreds to thousands of workgroup records (BASELINE configs 2 and 3): by default ONE
+    launch adds them up in two levels -- groups of rows, then the workgroup that draws the sample's last ticket adds the
+    group records in group order (k_reduce_moments_ticket).  The same records through two launches (a level, then the
+    final one: LYNX_REDUCE_TICKET=0) and through one 1024-thread workgroup per sample (LYNX_REDUCE_WIDE=1): a different
+    association of the same float64 sums -- the records agree to rounding, and with the oracle; and the default form
+    gives the same bits every time it runs (the last arrival decides who adds, not in which order).
     """
-    out, ref = _particle_case(lx, ARES, dtype, (1,), n, seed=5, sigma=[175e-9, 2e-7, 175e-9, 2e-7, 1e-6, 1e-6])
-    wide = out.moment_record().copy()
+    sigma = [175e-9, 2e-7, 175e-9, 2e-7, 1e-6, 1e-6]
+    out, ref = _particle_case(lx, ARES, dtype, (1,), n, seed=5, sigma=sigma)
+    ticket = out.moment_record().copy()
     _assert_moments(out, ref, dtype)
-    monkeypatch.setenv("LYNX_REDUCE_WIDE", "0")
-    level, _ = _particle_case(lx, ARES, dtype, (1,), n, seed=5, sigma=[175e-9, 2e-7, 175e-9, 2e-7, 1e-6, 1e-6])
-    rec = level.moment_record()
-    have = ~np.isnan(rec)
-    assert np.array_equal(np.isnan(wide), np.isnan(rec))
-    assert np.allclose(wide[have], rec[have], rtol=1e-11, atol=1e-300)
+    for _ in range(3):
+        again, _ = _particle_case(lx, ARES, dtype, (1,), n, seed=5, sigma=sigma)
+        assert np.array_equal(again.moment_record(), ticket, equal_nan=True)
+    have = ~np.isnan(ticket)
+    for knob in ({"LYNX_REDUCE_TICKET": "0"}, {"LYNX_REDUCE_WIDE": "1"}):
+        for key, value in knob.items():
+            monkeypatch.setenv(key, value)
+        other, _ = _particle_case(lx, ARES, dtype, (1,), n, seed=5, sigma=sigma)
+        rec = other.moment_record()
+        assert np.array_equal(np.isnan(ticket), np.isnan(rec)), knob
+        assert np.allclose(ticket[have], rec[have], rtol=1e-11, atol=1e-300), knob
+        for key in knob:
+            monkeypatch.delenv(key)
 
 
 @pytest.mark.parametrize("dtype,n", [(np.float32, 4096), (np.float32, 4099), (np.float64, 2048), (np.float64, 2047)])
