@@ -114,7 +114,10 @@ template <int CTRL, int BANK_MASK> __device__ __forceinline__ float dpp_take_ban
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL,
                                                                 0xF, BANK_MASK, false));
 }
-__device__ __forceinline__ float sum_eight_over_wave(const float (&v)[8], int lane) {
+// ... in two parts: sum_eight_over_8_lanes leaves lane l with the sum over its aligned group of 8 lanes of v[l & 7] (a
+// kernel that sums the same eight quantities tile after tile can add these up per lane and finish once),
+// finish_over_lane_groups adds the eight groups of the wave.
+__device__ __forceinline__ float sum_eight_over_8_lanes(const float (&v)[8], int lane) {
   const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0, b2 = (lane & 4) != 0;
   float a[4], g[4];
 #pragma unroll
@@ -136,10 +139,16 @@ __device__ __forceinline__ float sum_eight_over_wave(const float (&v)[8], int la
   float got = dpp_take_banks<0x104, 0x5>(0.f, give);   // row_shl:4 -> lanes with bit 2 clear read lane + 4
   got = dpp_take_banks<0x114, 0xA>(got, give);         // row_shr:4 -> lanes with bit 2 set read lane - 4
   one += got;
+  return one;
+}
+__device__ __forceinline__ float finish_over_lane_groups(float one) {
   one += dpp_take<0x128>(one);                          // bit 3: row_ror:8 = lane ^ 8 within the row of 16
   one += __shfl_xor(one, 16, 64);                       // bits 4, 5: the four rows
   one += __shfl_xor(one, 32, 64);
   return one;  // lanes with (lane & 7) == c hold the total of v[c]
+}
+__device__ __forceinline__ float sum_eight_over_wave(const float (&v)[8], int lane) {
+  return finish_over_lane_groups(sum_eight_over_8_lanes(v, lane));
 }
 
 template <typename T> __device__ __forceinline__ T sum_over_wave(T v) {

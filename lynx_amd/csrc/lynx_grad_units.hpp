@@ -1,21 +1,34 @@
 // Reverse pass of multi-step float32 programs whose units are all of class U (lynx_units.hpp): the structured twin of
 // k_track_bwd.  Included only by lynx_hip.hip, after lynx_grad.hpp and lynx_units.hpp.
 //
-// k_track_bwd treats every unit's map as a dense 7x7 three times over -- forward sweep, recomputation inside a group,
-// `M^T z_bar` -- and sums the full 7x7 outer product `z_bar (x) z_in` over the wave's particles through its exchange
-// buffer.  For a class-U unit (rows 0,1: columns {0,1,6}; rows 2,3: {2,3,6}; rows 4,5: {4,5}; row 6 = e6) only 16 of
-// those 49 cotangents can reach a parameter: every element of the unit is block-structured, so the cotangent of an
-// element map's in-pattern entry is built from in-pattern entries of the unit's alone (k_build_bwd multiplies by the
-// element maps, which have the same blocks), and `dM/dtheta` vanishes outside the pattern.  This kernel therefore
-//   * applies units with 16 packed multiply-adds (unit_linear<kClassU>) in both sweeps,
-//   * sums 16 (+ 4 for a merged pair's entry block) particle products per unit instead of 49 (+ 14): lane group g of 8
-//     lanes owns one row of cotangents and at most three rows of states,
-//   * forms `M^T z_bar` from 16 entries,
-// and reads the unit records (128 bytes) instead of the 256-byte step-table rows.  The partial sums land in the same
-// [B][chunks][S][64] layout k_track_bwd writes (zeros where nothing is summed), so k_reduce_tbar and k_build_bwd are
-// shared.  Which kernel takes a SAMPLE is decided from its unit records (k_pack_units / k_emit_steps checked the
-// numbers): all units class U -> this one, anything else -> k_track_bwd; both are launched, a workgroup of the other
-// kind leaves at once.  Same mathematics as the dense pass; sums over particles are associated differently.
+// A class-U unit (rows 0,1: columns {0,1,6}; rows 2,3: {2,3,6}; rows 4,5: {4,5}; row 6 = e6) moves the two transverse
+// planes by AFFINE 2x3 maps that see neither each other nor (s, delta), and (s, delta) by a 2x2 block plus the cavity's
+// kick, which sees s and delta only (cavity.py:141-161).  The reverse pass of a program of such units falls apart:
+//
+//   transverse planes   With X_u the x-block of unit u (homogeneous 3x3, last row e), the state entering unit u is
+//                       C_u (x0, x0', z6),  C_u = X_{u-1} ... X_0,  and the cotangent leaving it is  A_u^T (xbar_f, xbar'_f),
+//                       A_u = the linear 2x2 of X_{U-1} ... X_{u+1}.  So every unit's cotangent block
+//                         Tbar_x(u) = sum_n obar_n(u) (x) z_in,n(u) = A_u^T S_x C_u^T,   S_x = sum_n (xbar_f, xbar'_f)_n (x) (x0, x0', z6)_n
+//                       comes from ONE 2x3 sum over the particles -- 12 multiply-adds per particle for both planes and
+//                       the whole lattice, where walking the units costs 12 products, their sums over the wave and a 2x3
+//                       transposed application PER UNIT.  The per-unit blocks are formed afterwards, per sample, by
+//                       k_finish_tbar_units (float64).
+//   (s, delta)          stays a walk over the units, but of two components: forward with the kick, parking the (s, delta)
+//                       that enters every unit (16 registers per pair of particles for 8 units: nothing is recomputed,
+//                       nothing goes to scratch memory), backward with the kick's cotangents (lynx_grad.hpp:
+//                       kick_cotangents) and 4 (+ 4 for a merged pair's entry block) (+ 8 coefficient) sums per unit,
+//                       finished over the wave by halving butterflies (sum_eight_over_wave) -- no exchange buffer.
+//
+// Round 3's form of this kernel applied every unit in full three times over (forward, recomputation inside a group of
+// four, transposed) and summed 16 + 4 products per unit through a 14-row LDS exchange buffer: 2834 vector instructions
+// per wave and tile of 128 particles, 912 bytes of scratch per lane, 3 waves per SIMD, 2.37 ms on BASELINE config 5.
+//
+// The partial sums land in the [B][chunks][S][64] layout k_track_bwd writes, so k_reduce_tbar and k_build_bwd are
+// shared: the (s, delta) block, entry rows and coefficient cotangents of every unit where k_track_bwd puts them, S_x
+// and S_y in the transverse positions of unit 0's slot until k_finish_tbar_units has replaced them.  Which kernel takes
+// a SAMPLE is decided from its unit records (k_pack_units / k_emit_steps checked the numbers): all units class U -> this
+// one, anything else -> k_track_bwd; both are launched, a workgroup of the other kind leaves at once.  Same mathematics
+// as the dense pass; sums over particles are associated differently.
 #pragma once
 
 #include "lynx_grad.hpp"
@@ -23,9 +36,11 @@
 
 namespace lynx {
 
-// all units of the sample's program have class U (wave-uniform)
+constexpr int kBwdUnitsMax = 16;  // units whose entering (s, delta) a lane parks in registers (BASELINE config 5: 8)
+
+// all units of the sample's program have class U, and there are few enough of them (wave-uniform)
 __device__ __forceinline__ bool sample_is_class_u(const float* __restrict__ g_units, int U) {
-  bool all = true;
+  bool all = U <= kBwdUnitsMax;
   for (int u = 0; u < U; ++u) {
     const int bits = __float_as_int(uniform_value(g_units[u * kUnitStride + kUnitDesc]));
     all = all && ((bits >> kUnitClassShift) & 3) == kClassU;
@@ -33,60 +48,53 @@ __device__ __forceinline__ bool sample_is_class_u(const float* __restrict__ g_un
   return all;
 }
 
-// one class-U unit, forward: linear map, then the kick driven by what entered the cavity -- the run's (s, delta) block
-// `pre` applied to the unit's incoming state (merged pair), or that state's own s, delta
-__device__ __forceinline__ void bwd_unit_forward(const UnitHalf& kick, const UnitHalf& map, const float (&pre)[4],
-                                                 lynx_f32x2 (&z)[7]) {
-  const int bits = __builtin_amdgcn_readfirstlane(__float_as_int(kick.v[kUnitDesc]));
-  lynx_f32x2 s_in = z[4], d_in = z[5];
-  if (bits & kUnitPair) {
-    s_in = pk_fma(z[5], pre[1], z[4] * pre[0]);
-    d_in = pk_fma(z[5], pre[3], z[4] * pre[2]);
-  }
-  unit_linear<kClassU>(map, nullptr, z);
-  if (bits & kUnitKick) {
-    float coef[8];
+// what the (s, delta) walk needs of a unit: descriptor bits, the cavity's coefficients and sin(phi), the (s, delta) block
+// of the unit's map and -- merged pair -- of the run's (which gives the s and delta that enter the cavity)
+struct UnitSD {
+  int bits;
+  float coef[8], sphi, m44, m45, m54, m55, pre[4];
+};
+__device__ __forceinline__ void unit_sd_fetch(const float* __restrict__ g_units, const float* __restrict__ g_extras, int u,
+                                              UnitSD& r) {
+  const float* rec = g_units + u * kUnitStride;
+  r.bits = __builtin_amdgcn_readfirstlane(__float_as_int(uniform_value(rec[kUnitDesc])));
+  r.sphi = uniform_value(rec[kUnitSinPhi]);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) coef[k] = kick.v[kUnitCoef + k];
-    unit_kick(coef, s_in, d_in, z[4], z[5]);
-  }
+  for (int k = 0; k < 8; ++k) r.coef[k] = uniform_value(rec[kUnitCoef + k]);
+  r.m44 = uniform_value(rec[kUnitMap + 12]);
+  r.m45 = uniform_value(rec[kUnitMap + 13]);
+  r.m54 = uniform_value(rec[kUnitMap + 14]);
+  r.m55 = uniform_value(rec[kUnitMap + 15]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) r.pre[k] = uniform_value(g_extras[u * kUnitExtraStride + kUnitPre + k]);
 }
 
-__device__ __forceinline__ void bwd_unit_fetch(const float* __restrict__ g_units, const float* __restrict__ g_extras, int u,
-                                               UnitHalf& kick, UnitHalf& map, float (&pre)[4]) {
-  unit_fetch(g_units + u * kUnitStride, kick);
-  unit_fetch(g_units + u * kUnitStride + kUnitMap, map);
-#pragma unroll
-  for (int k = 0; k < 4; ++k) pre[k] = uniform_value(g_extras[u * kUnitExtraStride + kUnitPre + k]);
+// Where a sample's S_x / S_y live until k_finish_tbar_units has turned them into the units' transverse blocks: the
+// transverse positions of its first unit's slot -- [i][j] at i * 7 + j; i in {0, 1}: j in {0, 1, 6}; i in {2, 3}: j in {2, 3, 6}
+__host__ __device__ constexpr int transverse_slot(int k /* 0..11 */) {
+  constexpr int at[12] = {0 * 7 + 0, 0 * 7 + 1, 0 * 7 + 6, 1 * 7 + 0, 1 * 7 + 1, 1 * 7 + 6,
+                          2 * 7 + 2, 2 * 7 + 3, 2 * 7 + 6, 3 * 7 + 2, 3 * 7 + 3, 3 * 7 + 6};
+  return at[k];
 }
 
-constexpr int kBwdUnitsPitch = 160;  // scalars per exchange row (k_track_bwd_units)
-constexpr int kBwdUnitsRows = 14;  // exchange rows: 0..5 cotangents of the linear outputs, 6 the entering s', 7..13 the state
-
-__global__ __launch_bounds__(kTrackThreads) void k_track_bwd_units(
+// MAXU: how many units' entering (s, delta) a lane parks in registers -- 8 (BASELINE config 5: 32 registers, four waves
+// per SIMD without scratch) or kBwdUnitsMax
+// (three waves per SIMD: 168 registers and 32 bytes of scratch; compiled for four -- 128 registers -- it spills 192
+// bytes per lane into the tile loop and BASELINE config 5's forward + reverse step takes 3.05 ms instead of 2.46)
+#ifndef LYNX_BWD_UNITS_WAVES
+#define LYNX_BWD_UNITS_WAVES 3
+#endif
+template <int MAXU>
+__global__ __launch_bounds__(kTrackThreads, (MAXU <= 8 ? LYNX_BWD_UNITS_WAVES : 3)) void k_track_bwd_units(
     BwdArgs a, int32_t S, const float* __restrict__ p_in, const float* __restrict__ units, const float* __restrict__ extras,
     const double* __restrict__ moments_fwd, const double* __restrict__ grad_moments,
     float* __restrict__ partials /* [B][chunks][S][64] */, float* __restrict__ grad_p /* [B][N][7] or null */) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   using T = float;
   using Z = lynx_f32x2;
-  constexpr int K = kBwdGroup;
   constexpr int W = 2;
-  using Geo = ExGeom<T, W>;
-  using V = lynx_f32x4;
-  // Pitch and row order of the exchange buffer, chosen for ds_read_b128's lane groups on gfx950 ({0-3, 12-15, 20-27},
-  // {4-11, 16-19, 28-31} and the same + 32; banks (a / 4) mod 64): with 160 scalars per row even and odd rows sit 32
-  // banks apart, so the four row groups of a lane group read cotangent rows g .. g+3 without meeting, and with the
-  // state rows stored in the order 0, 2, 1, 3, 4, 5, 6 the two rows a lane group reads at once (0 | 2, then 1 | 3) do
-  // too.  (ExGeom's 132 with the rows in natural order: 108 LDS cycles per unit and wave where 64 are needed;
-  // SQ_LDS_BANK_CONFLICT 23 % of SQ_LDS_IDX_ACTIVE.)
-  constexpr int VW = Geo::kVW, P = kBwdUnitsPitch, NP = Geo::kPieces;
-  constexpr int kStateRow[7] = {7, 9, 8, 10, 11, 12, 13};
   const int U = a.n_units;
-  const int G = (U + K - 1) / K;
-  T* s_ex = reinterpret_cast<T*>(smem_raw);       // [4][kBwdUnitsRows][P]
-  T* s_acc = s_ex + 4 * kBwdUnitsRows * P;        // [4][S][64]
-  Z stack[kBwdMaxGroups * 7];                     // private: state entering unit g*K
+  T* s_acc = reinterpret_cast<T*>(smem_raw);  // [4][S][64]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t b = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / a.chunks));
@@ -96,25 +104,53 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_bwd_units(
   const float* g_extras = extras + b * (int64_t)U * kUnitExtraStride;
   if (!sample_is_class_u(g_units, U)) return;  // this sample belongs to k_track_bwd
 
-  T* ex = s_ex + wave * (kBwdUnitsRows * P);
   T* acc = s_acc + wave * (S * 64);
   for (int s = 0; s < S; ++s) acc[s * 64 + lane] = T(0);
+
+  // The transverse planes of the WHOLE program: (x, x') -> X (x, x', z6), (y, y') -> Y (y, y', z6), the product of the
+  // units' 2x3 blocks (wave-uniform arithmetic, once per workgroup)
+  T X[6] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f}, Y[6] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f};
+  for (int u = 0; u < U; ++u) {
+    T m[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) m[k] = uniform_value(g_units[u * kUnitStride + kUnitMap + k]);
+    const auto left = [](const T* q /* 2x3 of the unit */, T (&P)[6]) {  // P <- q . P (homogeneous)
+      const T p0 = P[0], p1 = P[1], p2 = P[2], p3 = P[3], p4 = P[4], p5 = P[5];
+      P[0] = fmaf(q[1], p3, q[0] * p0);
+      P[1] = fmaf(q[1], p4, q[0] * p1);
+      P[2] = fmaf(q[1], p5, fmaf(q[0], p2, q[2]));
+      P[3] = fmaf(q[4], p3, q[3] * p0);
+      P[4] = fmaf(q[4], p4, q[3] * p1);
+      P[5] = fmaf(q[4], p5, fmaf(q[3], p2, q[5]));
+    };
+    left(m, X);
+    left(m + 6, Y);
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    X[k] = uniform_value(X[k]);
+    Y[k] = uniform_value(Y[k]);
+  }
 
   const double* rec = moments_fwd + b * LYNX_MOMENT_STRIDE;
   const double* gm = grad_moments + b * LYNX_MOMENT_STRIDE;
   const T* src = p_in + b * N * 7;
   constexpr int64_t kTile = (int64_t)kTrackThreads * W;
-  // who sums what: lane group g = lane / 8 owns cotangent row g (0..5 the linear outputs' -- row 5 carries the
-  // entering delta's for a kicked pair --, 6 the entering s') and the state rows its pattern pairs it with
-  const int g = lane >> 3, kb = lane & 7;
-  const int zr0 = g < 2 ? 0 : (g < 4 ? 2 : 4);   // first state row
-  const int zr1 = zr0 + 1;                       // second
-  const bool third = g < 4;                      // rows 0..3 also meet the constant component (column 6)
+  Z sx[6], sy[6];  // this lane's share of S_x and S_y, over all its tiles
+#pragma unroll
+  for (int k = 0; k < 6; ++k) sx[k] = sy[k] = Z(T(0));
+  // ... and of the units' sums: per unit the eight of the (s, delta) block and entry rows, and the eight coefficient
+  // cotangents, each folded over the lane's group of eight after every tile (lane l keeps value l & 7) and finished over
+  // the wave once, behind the last tile -- the tile loop then touches neither LDS nor another lane group
+  T fold_sd[MAXU], fold_cc[MAXU];
+#pragma unroll
+  for (int u = 0; u < MAXU; ++u) fold_sd[u] = fold_cc[u] = T(0);
+
   for (int it = 0; it < a.tiles_per_wg; ++it) {
     const int64_t base = ((int64_t)chunk * a.tiles_per_wg + it) * kTile;
     if (base >= N) break;  // uniform
     bool live[W];
-    Z z[7];
+    Z z0[7];
 #pragma unroll
     for (int w = 0; w < W; ++w) {
       const int64_t i = base + (int64_t)w * kTrackThreads + tid;
@@ -122,19 +158,38 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_bwd_units(
       T zw[7];
       load_particle(src + (live[w] ? i : 0) * 7, zw);
 #pragma unroll
-      for (int c = 0; c < 7; ++c) zset(z[c], w, zw[c]);
+      for (int c = 0; c < 7; ++c) zset(z0[c], w, zw[c]);
     }
 
-    // forward sweep, parking the state that enters every K-th unit
-    for (int u = 0; u < U; ++u) {
-      if (u % K == 0) {
+    // the outgoing particle: transverse planes in one step, (s, delta) through the units; what enters every unit is kept
+    Z zf[6];
+    zf[0] = pk_fma(z0[6], X[2], pk_fma(z0[1], X[1], z0[0] * X[0]));
+    zf[1] = pk_fma(z0[6], X[5], pk_fma(z0[1], X[4], z0[0] * X[3]));
+    zf[2] = pk_fma(z0[6], Y[2], pk_fma(z0[3], Y[1], z0[2] * Y[0]));
+    zf[3] = pk_fma(z0[6], Y[5], pk_fma(z0[3], Y[4], z0[2] * Y[3]));
+    Z park[MAXU][2];
+    {
+      Z z4 = z0[4], z5 = z0[5];
 #pragma unroll
-        for (int c = 0; c < 7; ++c) stack[(u / K) * 7 + c] = z[c];
+      for (int u = 0; u < MAXU; ++u) {
+        if (u < U) {  // uniform
+          UnitSD r;
+          unit_sd_fetch(g_units, g_extras, u, r);
+          park[u][0] = z4;
+          park[u][1] = z5;
+          Z s_in = z4, d_in = z5;
+          if (r.bits & kUnitPair) {
+            s_in = pk_fma(z5, r.pre[1], z4 * r.pre[0]);
+            d_in = pk_fma(z5, r.pre[3], z4 * r.pre[2]);
+          }
+          const Z o4 = pk_fma(z5, r.m45, z4 * r.m44), o5 = pk_fma(z5, r.m55, z4 * r.m54);
+          z4 = o4;
+          z5 = o5;
+          if (r.bits & kUnitKick) unit_kick(r.coef, s_in, d_in, z4, z5);
+        }
       }
-      UnitHalf kick, map;
-      float pre[4];
-      bwd_unit_fetch(g_units, g_extras, u, kick, map, pre);
-      bwd_unit_forward(kick, map, pre, z);
+      zf[4] = z4;
+      zf[5] = z5;
     }
 
     // cotangent of the outgoing particle: (1/N) (mu_bar + G_hat (z - mean)), as in k_track_bwd
@@ -143,7 +198,7 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_bwd_units(
       const T inv_n = (T)(1.0 / rec[35]);
       Z d[6];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) d[k] = z[k] - (T)rec[k];
+      for (int k = 0; k < 6; ++k) d[k] = zf[k] - (T)rec[k];
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
         Z accv = Z((T)gm[k]);
@@ -162,136 +217,132 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_bwd_units(
         for (int c = 0; c < 7; ++c) zset(zb[c], w, live[w] ? zget(zb[c], w) : T(0));
     }
 
-    for (int grp = G - 1; grp >= 0; --grp) {
-      // states entering units grp*K .. grp*K + K-1
-      Z zz[K][7];
-#pragma unroll
-      for (int c = 0; c < 7; ++c) zz[0][c] = stack[grp * 7 + c];
-#pragma unroll
-      for (int j = 1; j < K; ++j) {
-        const int up = grp * K + j - 1;  // unit that produces zz[j]
-#pragma unroll
-        for (int c = 0; c < 7; ++c) zz[j][c] = zz[j - 1][c];
-        if (up + 1 < U) {
-          UnitHalf kick, map;
-          float pre[4];
-          bwd_unit_fetch(g_units, g_extras, up, kick, map, pre);
-          bwd_unit_forward(kick, map, pre, zz[j]);
-        }
-      }
+    // transverse planes: S_x += (xbar, xbar') (x) (x0, x0', z6), S_y likewise
+    sx[0] = zfma(zb[0], z0[0], sx[0]);
+    sx[1] = zfma(zb[0], z0[1], sx[1]);
+    sx[2] = zfma(zb[0], z0[6], sx[2]);
+    sx[3] = zfma(zb[1], z0[0], sx[3]);
+    sx[4] = zfma(zb[1], z0[1], sx[4]);
+    sx[5] = zfma(zb[1], z0[6], sx[5]);
+    sy[0] = zfma(zb[2], z0[2], sy[0]);
+    sy[1] = zfma(zb[2], z0[3], sy[1]);
+    sy[2] = zfma(zb[2], z0[6], sy[2]);
+    sy[3] = zfma(zb[3], z0[2], sy[3]);
+    sy[4] = zfma(zb[3], z0[3], sy[4]);
+    sy[5] = zfma(zb[3], z0[6], sy[5]);
 
-      for (int j = K - 1; j >= 0; --j) {
-        const int u = grp * K + j;
-        if (u >= U) continue;  // uniform
-        const int s = a.unit_slot[u];
-        Z zin[7];
+    // (s, delta) backwards through the units
+    Z b4 = zb[4], b5 = zb[5];
 #pragma unroll
-        for (int c = 0; c < 7; ++c) {
-          Z v = zz[0][c];
-#pragma unroll
-          for (int q = 1; q < K; ++q) v = (j == q) ? zz[q][c] : v;
-          zin[c] = v;
-        }
-        UnitHalf kickr, map;
-        float pre[4];
-        bwd_unit_fetch(g_units, g_extras, u, kickr, map, pre);
-        const int bits = __builtin_amdgcn_readfirstlane(__float_as_int(kickr.v[kUnitDesc]));
-        const bool paired = (bits & kUnitPair) != 0, kick = (bits & kUnitKick) != 0;
-        const bool entry_rows = paired && kick;  // cotangents of the run's (s, delta) block are due
-        Z s_in = zin[4], d_in = zin[5];
+    for (int u = MAXU - 1; u >= 0; --u) {
+      if (u < U) {  // uniform
+        UnitSD r;
+        unit_sd_fetch(g_units, g_extras, u, r);
+        const bool paired = (r.bits & kUnitPair) != 0, kick = (r.bits & kUnitKick) != 0;
+        const Z z4 = park[u][0], z5 = park[u][1];
+        Z s_in = z4, d_in = z5;
         if (paired) {
-          s_in = pk_fma(zin[5], pre[1], zin[4] * pre[0]);
-          d_in = pk_fma(zin[5], pre[3], zin[4] * pre[2]);
+          s_in = pk_fma(z5, r.pre[1], z4 * r.pre[0]);
+          d_in = pk_fma(z5, r.pre[3], z4 * r.pre[2]);
         }
-        Z olin[7], cc[8], dir4 = Z(T(0)), dir5 = Z(T(0));
-#pragma unroll
-        for (int c = 0; c < 7; ++c) olin[c] = zb[c];
+        Z o5 = b5, dir4 = Z(T(0)), dir5 = Z(T(0)), cc[8];
         if (kick) {
-          // o5' = z5 c0 + c1 (cos(a) - c4), a = -z4 c2 + c3 ; o4' = o4 + c5 z5^2 + c6 z4 z5 + c7 z4^2   (k_track_bwd)
-          const T* cf = kickr.v + kUnitCoef;
-          T sphi, cphi;
-          phase_of<T>(cf[LYNX_C_PHI], sphi, cphi);
-          kick_cotangents<T, Z>(cf, sphi, cphi, s_in, d_in, zb[4], zb[5], cc, dir4, dir5);
-          olin[5] = Z(T(0));  // the linear delta was overwritten
+          kick_cotangents<T, Z>(r.coef, r.sphi, r.coef[LYNX_C_COSPHI], s_in, d_in, b4, b5, cc, dir4, dir5);
+          o5 = Z(T(0));  // the linear delta was overwritten
         }
-
-        // sums over the wave's 128 particles: the rows go through the exchange buffer, lane (g, kb) reads one eighth
-        // of cotangent row g and of its two or three state rows, an 8-lane butterfly finishes each product
-        Z* exz = reinterpret_cast<Z*>(ex);
-#pragma unroll
-        for (int c = 0; c < 6; ++c) exz[(c * P) / W + lane] = (c == 5 && entry_rows) ? dir5 : olin[c];
-        exz[(6 * P) / W + lane] = dir4;
-#pragma unroll
-        for (int c = 0; c < 7; ++c) exz[(kStateRow[c] * P) / W + lane] = zin[c];
-        wave_lds_sync();
+        // sums over the wave's 128 particles, eight at a time in one halving butterfly: the unit's (s, delta) block, then
+        // the entry rows of s and of delta (merged pair: sums against the state that entered the RUN)
         {
-          const T* arow = ex + (g < 7 ? g : 1) * P + kb * VW;  // (group 7 has no row of its own: an odd one, see above)
-          V av[NP];
-#pragma unroll
-          for (int l = 0; l < NP; ++l) av[l] = *reinterpret_cast<const V*>(arow + l * 8 * VW);
-          const int zrows[3] = {zr0, zr1, 6};
-          T tot[3];
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            const T* zrow = ex + kStateRow[zrows[k]] * P + kb * VW;
-            V part = {T(0), T(0), T(0), T(0)};
-#pragma unroll
-            for (int l = 0; l < NP; ++l) part = __builtin_elementwise_fma(av[l], *reinterpret_cast<const V*>(zrow + l * 8 * VW), part);
-            tot[k] = sum_over_8_lanes((part[0] + part[1]) + (part[2] + part[3]));
-          }
-          // lane kb = k of the group books product k.  Where: unit's record rows 0..5 at [s][i * 7 + j]; a kicked pair's
-          // entry block in the RUN's slot, rows of s (at [0..6]) and of delta (at [7..13]) like k_track_bwd
-          if (kb < 3 && (kb < 2 || third)) {
-            const T mine = kb == 0 ? tot[0] : (kb == 1 ? tot[1] : tot[2]);
-            const int col = kb == 0 ? zr0 : (kb == 1 ? zr1 : 6);
-            if (g < 5 || (g == 5 && !entry_rows)) acc[s * 64 + g * 7 + col] += mine;
-            else if (g == 5) acc[(s - 1) * 64 + 7 + col] += mine;          // entry row of delta
-            else if (g == 6 && entry_rows) acc[(s - 1) * 64 + col] += mine;  // entry row of s
-          }
-          if (kick) {  // the eight coefficient cotangents: one halving butterfly over the wave
-            float each[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) each[c] = zhsum(cc[c]);
-            const T rest = sum_eight_over_wave(each, lane);
-            if (lane < 8) acc[s * 64 + 49 + lane] += rest;
-          }
+          float each[8];
+          each[0] = zhsum(b4 * z4);
+          each[1] = zhsum(b4 * z5);
+          each[2] = zhsum(o5 * z4);
+          each[3] = zhsum(o5 * z5);
+          each[4] = zhsum(dir4 * z4);
+          each[5] = zhsum(dir4 * z5);
+          each[6] = zhsum(dir5 * z4);
+          each[7] = zhsum(dir5 * z5);
+          fold_sd[u] += sum_eight_over_8_lanes(each, lane);
         }
-        wave_lds_sync();
-
-        // z_bar_in = M^T o_lin, 16 entries (+ the constant component's own), then through the entry block
-        {
-          const float* m = map.v;
-          const Z o0 = olin[0], o1 = olin[1], o2 = olin[2], o3 = olin[3], o4 = olin[4], o5 = olin[5];
-          zb[0] = pk_fma(o1, m[3], o0 * m[0]);
-          zb[1] = pk_fma(o1, m[4], o0 * m[1]);
-          zb[2] = pk_fma(o3, m[9], o2 * m[6]);
-          zb[3] = pk_fma(o3, m[10], o2 * m[7]);
-          zb[4] = pk_fma(o5, m[14], o4 * m[12]);
-          zb[5] = pk_fma(o5, m[15], o4 * m[13]);
-          zb[6] = pk_fma(o3, m[11], pk_fma(o2, m[8], pk_fma(o1, m[5], pk_fma(o0, m[2], olin[6]))));
+        if (kick) {  // uniform: the eight coefficient cotangents
+          float each[8];
+#pragma unroll
+          for (int c = 0; c < 8; ++c) each[c] = zhsum(cc[c]);
+          fold_cc[u] += sum_eight_over_8_lanes(each, lane);
         }
+        // through the unit's (s, delta) block (transposed), then the kick's direct terms -- through the entry block for
+        // a merged pair
+        const Z n4 = pk_fma(o5, r.m54, b4 * r.m44), n5 = pk_fma(o5, r.m55, b4 * r.m45);
+        b4 = n4;
+        b5 = n5;
         if (!paired) {
-          zb[4] += dir4;
-          zb[5] += dir5;
+          b4 += dir4;
+          b5 += dir5;
         } else if (kick) {
-          zb[4] = pk_fma(dir5, pre[2], pk_fma(dir4, pre[0], zb[4]));
-          zb[5] = pk_fma(dir5, pre[3], pk_fma(dir4, pre[1], zb[5]));
+          b4 = pk_fma(dir5, r.pre[2], pk_fma(dir4, r.pre[0], b4));
+          b5 = pk_fma(dir5, r.pre[3], pk_fma(dir4, r.pre[1], b5));
         }
       }
     }
-    // what is left after the last (= first) unit is dL/d(incoming particle)
+
+    // dL/d(incoming particle): the transverse cotangents through the whole program's blocks (transposed), s and delta
+    // from the walk, the constant component's from the affine columns
     if (grad_p != nullptr) {
+      Z g[7];
+      g[0] = pk_fma(zb[1], X[3], zb[0] * X[0]);
+      g[1] = pk_fma(zb[1], X[4], zb[0] * X[1]);
+      g[2] = pk_fma(zb[3], Y[3], zb[2] * Y[0]);
+      g[3] = pk_fma(zb[3], Y[4], zb[2] * Y[1]);
+      g[4] = b4;
+      g[5] = b5;
+      g[6] = pk_fma(zb[3], Y[5], pk_fma(zb[2], Y[2], pk_fma(zb[1], X[5], pk_fma(zb[0], X[2], zb[6]))));
 #pragma unroll
       for (int w = 0; w < W; ++w) {
         const int64_t i = base + (int64_t)w * kTrackThreads + tid;
         if (live[w]) {
           T zw[7];
 #pragma unroll
-          for (int c = 0; c < 7; ++c) zw[c] = zget(zb[c], w);
+          for (int c = 0; c < 7; ++c) zw[c] = zget(g[c], w);
           store_particle(grad_p + (b * N + i) * 7, zw);
         }
       }
     }
+  }
+
+  // the units' sums: finish over the wave; lane c < 8 books value c -- [4][4], [4][5], [5][4], [5][5] of the unit's
+  // slot; the entry rows in the RUN's slot, row of s at [0..6], of delta at [7..13] (where k_track_bwd puts them); the
+  // coefficient cotangents behind the unit's 49
+#pragma unroll
+  for (int u = 0; u < MAXU; ++u) {
+    if (u < U) {  // uniform
+      const int s = a.unit_slot[u];
+      const int bits = __builtin_amdgcn_readfirstlane(__float_as_int(uniform_value(g_units[u * kUnitStride + kUnitDesc])));
+      const bool entry_rows = (bits & kUnitPair) && (bits & kUnitKick);  // cotangents of the run's (s, delta) block are due
+      const T total = finish_over_lane_groups(fold_sd[u]);
+      if (lane < 4) acc[s * 64 + (lane < 2 ? 32 : 37) + lane] += total;                              // 32, 33, 39, 40
+      else if (lane < 8 && entry_rows) acc[(s - 1) * 64 + (lane < 6 ? 0 : 5) + lane] += total;  // 4, 5, 11, 12
+      if (bits & kUnitKick) {
+        const T coefs = finish_over_lane_groups(fold_cc[u]);
+        if (lane < 8) acc[s * 64 + 49 + lane] += coefs;
+      }
+    }
+  }
+  // the workgroup's S_x and S_y: lanes -> wave (two butterflies of eight, the last four slots idle), into unit 0's slot
+  {
+    const int s0 = a.unit_slot[0];
+    float each[8];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) each[k] = zhsum(sx[k]);
+    each[6] = zhsum(sy[0]);
+    each[7] = zhsum(sy[1]);
+    T total = sum_eight_over_wave(each, lane);
+    if (lane < 8) acc[s0 * 64 + transverse_slot(lane)] += total;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) each[k] = zhsum(sy[2 + k]);
+#pragma unroll
+    for (int k = 4; k < 8; ++k) each[k] = 0.f;
+    total = sum_eight_over_wave(each, lane);
+    if (lane < 4) acc[s0 * 64 + transverse_slot(8 + lane)] += total;
   }
 
   __syncthreads();
@@ -301,8 +352,73 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_bwd_units(
   }
 }
 
-inline size_t bwd_units_lds_bytes(int S) {
-  return ((size_t)4 * kBwdUnitsRows * kBwdUnitsPitch + (size_t)4 * S * 64) * sizeof(float);
+inline size_t bwd_units_lds_bytes(int S) { return (size_t)4 * S * 64 * sizeof(float); }
+
+// ---------------------------------------------------------------------------------------
+// k_finish_tbar_units: S_x, S_y of a class-U sample (k_track_bwd_units, reduced over the workgroups by k_reduce_tbar) ->
+// the transverse blocks of every unit's cotangent,  Tbar_x(u) = A_u^T S_x C_u^T  (see the top of this file), in float64.
+// One wave per sample, lane u = unit u: every lane reads S before any of them writes (unit 0's slot is where S sits).
+// A merged pair's entry rows have no transverse part; samples of other classes were walked densely and are left alone.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_finish_tbar_units(BwdArgs a, int32_t S, const float* __restrict__ units,
+                                                          float* __restrict__ tbar /* [B][S][64] */) {
+  const int64_t b = blockIdx.x;
+  const int U = a.n_units;
+  const int u = threadIdx.x;
+  const float* g_units = units + b * (int64_t)U * kUnitStride;
+  if (!sample_is_class_u(g_units, U)) return;  // uniform
+  float* row0 = tbar + (b * S + a.unit_slot[0]) * (int64_t)kGradStride;
+  double Sx[6], Sy[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    Sx[k] = (double)row0[transverse_slot(k)];
+    Sy[k] = (double)row0[transverse_slot(6 + k)];
+  }
+  double out[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) out[k] = 0.0;
+  if (u < U) {
+    for (int plane = 0; plane < 2; ++plane) {
+      const double* Sp = plane ? Sy : Sx;
+      // C = prefix (homogeneous 2x3) of the units in front of u, A = linear 2x2 of the units behind it
+      double C[6] = {1, 0, 0, 0, 1, 0}, A[4] = {1, 0, 0, 1};
+      for (int v = 0; v < U; ++v) {
+        if (v == u) continue;
+        const float* m = g_units + v * kUnitStride + kUnitMap + 6 * plane;
+        const double q0 = m[0], q1 = m[1], q2 = m[2], q3 = m[3], q4 = m[4], q5 = m[5];
+        if (v < u) {
+          const double c0 = C[0], c1 = C[1], c2 = C[2], c3 = C[3], c4 = C[4], c5 = C[5];
+          C[0] = q0 * c0 + q1 * c3;
+          C[1] = q0 * c1 + q1 * c4;
+          C[2] = q0 * c2 + q1 * c5 + q2;
+          C[3] = q3 * c0 + q4 * c3;
+          C[4] = q3 * c1 + q4 * c4;
+          C[5] = q3 * c2 + q4 * c5 + q5;
+        } else {
+          const double a0 = A[0], a1 = A[1], a2 = A[2], a3 = A[3];
+          A[0] = q0 * a0 + q1 * a2;
+          A[1] = q0 * a1 + q1 * a3;
+          A[2] = q3 * a0 + q4 * a2;
+          A[3] = q3 * a1 + q4 * a3;
+        }
+      }
+      // P = A^T S (2x3); Tbar = P Ct^T with Ct the homogeneous 3x3 of C (its last row picks the constant column)
+      const double P0 = A[0] * Sp[0] + A[2] * Sp[3], P1 = A[0] * Sp[1] + A[2] * Sp[4], P2 = A[0] * Sp[2] + A[2] * Sp[5];
+      const double P3 = A[1] * Sp[0] + A[3] * Sp[3], P4 = A[1] * Sp[1] + A[3] * Sp[4], P5 = A[1] * Sp[2] + A[3] * Sp[5];
+      out[6 * plane + 0] = P0 * C[0] + P1 * C[1] + P2 * C[2];
+      out[6 * plane + 1] = P0 * C[3] + P1 * C[4] + P2 * C[5];
+      out[6 * plane + 2] = P2;
+      out[6 * plane + 3] = P3 * C[0] + P4 * C[1] + P5 * C[2];
+      out[6 * plane + 4] = P3 * C[3] + P4 * C[4] + P5 * C[5];
+      out[6 * plane + 5] = P5;
+    }
+  }
+  __syncthreads();  // one wave: every lane has read S
+  if (u < U) {
+    float* row = tbar + (b * S + a.unit_slot[u]) * (int64_t)kGradStride;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) row[transverse_slot(k)] = (float)out[k];
+  }
 }
 
 }  // namespace lynx

@@ -1687,7 +1687,8 @@ static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const v
     if (ctx->knobs.bwd_units) {
       if ((rc = ensure_units_plan(ctx, lat, merged != 0))) return rc;
       const UnitPlan& up = lat->units[merged ? 1 : 0];
-      bool same = lat->units_ok[merged ? 1 : 0] && up.n_units == a.n_units;
+      // (the structured kernel parks the (s, delta) entering every unit in registers: up to kBwdUnitsMax units)
+      bool same = lat->units_ok[merged ? 1 : 0] && up.n_units == a.n_units && a.n_units <= kBwdUnitsMax;
       for (int u = 0; same && u < a.n_units; ++u) same = up.slot[u] == a.unit_slot[u];
       if (same) {
         const int64_t n = B * a.n_units;
@@ -1730,10 +1731,17 @@ static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const v
   if constexpr (W == 2) {
     if (d_units) {
       const size_t lds_u = bwd_units_lds_bytes(S);
-      if ((rc = allow_lds(ctx, k_track_bwd_units, lds_u))) return rc;
-      hipLaunchKernelGGL(k_track_bwd_units, dim3((unsigned)(B * chunks)), dim3(kTrackThreads), lds_u, ctx->stream, a, S,
-                         (const float*)d_p_in, (const float*)d_units, (const float*)d_extras, d_moments_fwd, d_grad_moments,
-                         (float*)ctx->scratch_grad[0], (float*)d_grad_p_in);
+      if (a.n_units <= 8) {
+        if ((rc = allow_lds(ctx, k_track_bwd_units<8>, lds_u))) return rc;
+        hipLaunchKernelGGL(k_track_bwd_units<8>, dim3((unsigned)(B * chunks)), dim3(kTrackThreads), lds_u, ctx->stream, a, S,
+                           (const float*)d_p_in, (const float*)d_units, (const float*)d_extras, d_moments_fwd, d_grad_moments,
+                           (float*)ctx->scratch_grad[0], (float*)d_grad_p_in);
+      } else {
+        if ((rc = allow_lds(ctx, k_track_bwd_units<kBwdUnitsMax>, lds_u))) return rc;
+        hipLaunchKernelGGL(k_track_bwd_units<kBwdUnitsMax>, dim3((unsigned)(B * chunks)), dim3(kTrackThreads), lds_u, ctx->stream,
+                           a, S, (const float*)d_p_in, (const float*)d_units, (const float*)d_extras, d_moments_fwd,
+                           d_grad_moments, (float*)ctx->scratch_grad[0], (float*)d_grad_p_in);
+      }
       HIP_TRY(ctx, hipGetLastError());
     }
   }
@@ -1744,6 +1752,13 @@ static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const v
   hipLaunchKernelGGL(k_reduce_tbar<T>, dim3((unsigned)(B * S)), dim3(64), 0, ctx->stream, (const T*)ctx->scratch_grad[0],
                      (int)chunks, (int)S, (T*)ctx->scratch_grad[1]);
   HIP_TRY(ctx, hipGetLastError());
+  if constexpr (W == 2) {
+    if (d_units) {  // class-U samples: the units' transverse blocks from the sample's S_x, S_y (lynx_grad_units.hpp)
+      hipLaunchKernelGGL(k_finish_tbar_units, dim3((unsigned)B), dim3(64), 0, ctx->stream, a, S, (const float*)d_units,
+                         (float*)ctx->scratch_grad[1]);
+      HIP_TRY(ctx, hipGetLastError());
+    }
+  }
   size_t lds2 = build_bwd_lds_fixed<T>(S, E);
   // maps + prefix products, then the kind-sorted task list and the elements' kinds (unsigned short each)
   const size_t maps_bytes = (size_t)(2 * E + S + 1) * 49 * sizeof(T) + ((size_t)bwd_task_capacity(E) + E) * sizeof(unsigned short);

@@ -507,12 +507,15 @@ def test_config_5_gradients_at_the_full_shape(lx, monkeypatch):
 
 # (float32 kernels against each other, float32 against the float64 pass): twice what the test above measured on MI355X,
 # over all 4096 environments (round 4):          structured - dense    structured - float64    dense - float64
-#                                  length              6.9e-06               6.3e-05               6.3e-05
-#                                  k1                  3.9e-06               4.9e-05               4.8e-05
-#                                  misalignment        7.1e-06               1.0e-04               1.0e-04
-#                                  voltage             3.8e-06               8.9e-04               8.9e-04
-#                                  phase               5.5e-06               2.0e-03               2.0e-03
-#                                  frequency           2.3e-05               8.5e-03               8.4e-03
-#                                  energy              1.6e-06               9.6e-05               9.6e-05
-TOL_C5_GRAD = {"length": (1.4e-5, 1.3e-4), "k1": (8e-6, 1e-4), "misalignment": (1.5e-5, 2e-4), "voltage": (8e-6, 1.8e-3),
-               "phase": (1.1e-5, 4e-3), "frequency": (5e-5, 1.7e-2), "energy": (4e-6, 2e-4)}
+#                                  length              2.7e-05               6.3e-05               6.3e-05
+#                                  k1                  5.5e-05               6.1e-05               4.8e-05
+#                                  misalignment        5.1e-05               9.9e-05               1.0e-04
+#                                  voltage             2.1e-05               8.9e-04               8.9e-04
+#                                  phase               1.9e-05               2.0e-03               2.0e-03
+#                                  frequency           2.6e-05               8.4e-03               8.4e-03
+#                                  energy              2.8e-06               9.6e-05               9.6e-05
+# (structured - dense: the structured kernel keeps a lane's share of the transverse sums S_x, S_y in float32 over all of
+# its tiles before the workgroup adds them up -- with round 3's exchange-buffer form, which added every tile's products
+# over the wave at once, that column read 4e-06 .. 2e-05)
+TOL_C5_GRAD = {"length": (6e-5, 1.3e-4), "k1": (1.1e-4, 1.3e-4), "misalignment": (1.1e-4, 2e-4), "voltage": (5e-5, 1.8e-3),
+               "phase": (4e-5, 4e-3), "frequency": (6e-5, 1.7e-2), "energy": (6e-6, 2e-4)}
