@@ -36,25 +36,50 @@ template <typename T> LYNX_HD bool operator!=(Dual<T> a, Dual<T> b) { return a.v
 template <typename T> LYNX_HD bool operator>(Dual<T> a, Dual<T> b) { return a.v > b.v; }
 template <typename T> LYNX_HD bool operator<(Dual<T> a, Dual<T> b) { return a.v < b.v; }
 
-// d/dx: sqrt -> 1/(2 sqrt x); sin -> cos; cos -> -sin; tan -> 1 + tan^2; sinh -> cosh;
-// cosh -> sinh; log -> 1/x
-#define LYNX_DUAL_FN(R, NAME, DERIV)                               \
-  template <> LYNX_FN Dual<R> NAME<Dual<R>>(Dual<R> x) {           \
-    const R f = NAME<R>(x.v);                                      \
-    return Dual<R>(f, (DERIV)*x.d);                                \
-  }
-#define LYNX_DUAL_ALL(R)                                           \
-  LYNX_DUAL_FN(R, t_sqrt, (R(0.5) / f))                            \
-  LYNX_DUAL_FN(R, t_sin, (t_cos<R>(x.v)))                          \
-  LYNX_DUAL_FN(R, t_cos, (-t_sin<R>(x.v)))                         \
-  LYNX_DUAL_FN(R, t_tan, (R(1) + f * f))                           \
-  LYNX_DUAL_FN(R, t_sinh, (t_cosh<R>(x.v)))                        \
-  LYNX_DUAL_FN(R, t_cosh, (t_sinh<R>(x.v)))                        \
-  LYNX_DUAL_FN(R, t_log, (R(1) / x.v))
+// d/dx: sqrt -> 1/(2 sqrt x); sin -> cos; cos -> -sin; tan -> 1 + tan^2; sinh -> cosh; cosh -> sinh; log -> 1/x.
+// INLINE, on the library functions themselves: the plain t_sin / t_cos / ... of lynx_maps.hpp are out-of-line on purpose
+// (the forward builders' code size), but a dual-number builder makes dozens of such calls, and every call on this
+// target saves and restores the caller's live registers through scratch memory -- that, not the arithmetic, was what
+// k_build_bwd's parameter-gradient phase spent its time on.
+LYNX_HD float dual_sin(float x) { return sinf(x); }
+LYNX_HD double dual_sin(double x) { return sin(x); }
+LYNX_HD float dual_cos(float x) { return cosf(x); }
+LYNX_HD double dual_cos(double x) { return cos(x); }
+LYNX_HD float dual_tan(float x) { return tanf(x); }
+LYNX_HD double dual_tan(double x) { return tan(x); }
+LYNX_HD float dual_sinh(float x) { return sinhf(x); }
+LYNX_HD double dual_sinh(double x) { return sinh(x); }
+LYNX_HD float dual_cosh(float x) { return coshf(x); }
+LYNX_HD double dual_cosh(double x) { return cosh(x); }
+LYNX_HD float dual_log(float x) { return logf(x); }
+LYNX_HD double dual_log(double x) { return log(x); }
+#define LYNX_DUAL_ALL(R)                                                                                                   \
+  template <> LYNX_HD Dual<R> t_sqrt<Dual<R>>(Dual<R> x) { const R f = t_sqrt<R>(x.v); return Dual<R>(f, (R(0.5) / f) * x.d); } \
+  template <> LYNX_HD Dual<R> t_sin<Dual<R>>(Dual<R> x) { return Dual<R>(dual_sin(x.v), dual_cos(x.v) * x.d); }             \
+  template <> LYNX_HD Dual<R> t_cos<Dual<R>>(Dual<R> x) { return Dual<R>(dual_cos(x.v), -dual_sin(x.v) * x.d); }            \
+  template <> LYNX_HD Dual<R> t_tan<Dual<R>>(Dual<R> x) { const R f = dual_tan(x.v); return Dual<R>(f, (R(1) + f * f) * x.d); } \
+  template <> LYNX_HD Dual<R> t_sinh<Dual<R>>(Dual<R> x) { return Dual<R>(dual_sinh(x.v), dual_cosh(x.v) * x.d); }          \
+  template <> LYNX_HD Dual<R> t_cosh<Dual<R>>(Dual<R> x) { return Dual<R>(dual_cosh(x.v), dual_sinh(x.v) * x.d); }          \
+  template <> LYNX_HD Dual<R> t_log<Dual<R>>(Dual<R> x) { return Dual<R>(dual_log(x.v), (R(1) / x.v) * x.d); }
 LYNX_DUAL_ALL(float)
 LYNX_DUAL_ALL(double)
 #undef LYNX_DUAL_ALL
-#undef LYNX_DUAL_FN
+
+// cs_of (lynx_maps.hpp) for dual numbers, inline for the same reason
+template <typename R> LYNX_HD void cs_of(Dual<R> k2, Dual<R> L, Dual<R> s_at_zero, Dual<R>& c, Dual<R>& s) {
+  if (k2.v > R(0)) {
+    const Dual<R> a = t_sqrt(k2), x = a * L;
+    c = t_cos(x);
+    s = t_sin(x) / a;
+  } else if (k2.v < R(0)) {
+    const Dual<R> a = t_sqrt(-k2), x = a * L;
+    c = t_cosh(x);
+    s = t_sinh(x) / a;
+  } else {
+    c = Dual<R>(R(1));
+    s = s_at_zero;
+  }
+}
 
 // cavity_r55_bracket (lynx_maps.hpp) without its cancellations: with a = 1/g0^2, b = 1/g1^2,
 //   beta0 beta1 - 1 = ((1 - a)(1 - b) - 1) / (beta0 beta1 + 1) = -(a + b - a b) / (1 + beta0 beta1)          =: -eps

@@ -24,13 +24,35 @@
 
 #include "lynx_device.hpp"
 #include "lynx_dual.hpp"
+#include "lynx_unit_record.hpp"
 
 namespace lynx {
 
 constexpr int kGradStride = 64;   // per (sample, step): 49 T_bar + 8 coef_bar + padding
 constexpr int kGradParams = 8;    // gradient slots per element (kinds with <= 8 parameters)
-// k_build_bwd's kind-sorted task list: every (element, parameter or energy) pair + one wave of padding per kind
-__host__ __device__ constexpr int bwd_task_capacity(int n_elems) { return n_elems * (kGradParams + 1) + 13 * 64; }
+// k_build_bwd's task list: every (element, parameter or energy) pair as element * 16 + (parameter | kGradParams for the
+// energy), 0xffff = padding.  The host lists them KIND BY KIND, each kind padded to whole waves (bwd_tasks_sorted), once
+// per lattice: a wave then runs ONE kind's builder on dual numbers, the kinds run side by side on different waves, and
+// slots of parameters a kind does not have do not exist (BASELINE config 5: 192 slots of 3 kinds instead of 288 over
+// mixed waves).  (Until round 4 thread 0 of every workgroup sorted the list itself, after the chains: 80 of the
+// kernel's 380 us.)
+__host__ __device__ inline int bwd_kind_params_dev(int kind) {
+  switch (kind) {
+    case LYNX_KIND_DRIFT: return 1;
+    case LYNX_KIND_QUADRUPOLE: return 5;
+    case LYNX_KIND_DIPOLE: return 8;
+    case LYNX_KIND_HCOR:
+    case LYNX_KIND_VCOR: return 2;
+    case LYNX_KIND_CAVITY: return 4;
+    case LYNX_KIND_BASE_RMATRIX: return 4;
+    case LYNX_KIND_ROTATION: return 1;
+    case LYNX_KIND_MISALIGNMENT: return 3;
+    case LYNX_KIND_SOLENOID: return 4;
+    case LYNX_KIND_UNDULATOR: return 1;
+    default: return 0;  // identity; custom maps carry no differentiable parameters here
+  }
+}
+inline int bwd_kind_params(int kind) { return bwd_kind_params_dev(kind); }
 
 constexpr int kBwdGroup = 4;
 constexpr int kBwdMaxGroups = 16;  // => at most 64 units
@@ -792,7 +814,7 @@ __global__ __launch_bounds__(256) void k_build_bwd(LatticeDev lat, const T* __re
                                                     T* tbar, T* __restrict__ scratch,
                                                     T* __restrict__ grad_params /* [B][E][8] */,
                                                     T* __restrict__ grad_energy /* [B] */, int merged_pairs,
-                                                    int maps_in_lds) {
+                                                    int maps_in_lds, const unsigned short* __restrict__ tasks, int n_tasks) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int E = lat.n_elems, S = lat.n_steps;
   T* s_energy = reinterpret_cast<T*>(smem_raw);  // [S+1]
@@ -953,62 +975,14 @@ __global__ __launch_bounds__(256) void k_build_bwd(LatticeDev lat, const T* __re
   //    tasks are therefore listed kind by kind, each kind padded to whole waves -- a wave then runs ONE builder,
   //    the kinds run side by side on different waves, and slots of parameters a kind does not have do not
   //    exist (BASELINE config 5: 120 tasks of 3 kinds instead of 288 slots over mixed waves).
-  const auto kind_params = [](int kind) {
-    switch (kind) {
-      case LYNX_KIND_DRIFT: return 1;
-      case LYNX_KIND_QUADRUPOLE: return 5;
-      case LYNX_KIND_DIPOLE: return 8;
-      case LYNX_KIND_HCOR:
-      case LYNX_KIND_VCOR: return 2;
-      case LYNX_KIND_CAVITY: return 4;
-      case LYNX_KIND_BASE_RMATRIX: return 4;
-      case LYNX_KIND_ROTATION: return 1;
-      case LYNX_KIND_MISALIGNMENT: return 3;
-      case LYNX_KIND_SOLENOID: return 4;
-      case LYNX_KIND_UNDULATOR: return 1;
-      default: return 0;  // identity; custom maps carry no differentiable parameters here
-    }
-  };
-  unsigned short* s_task = reinterpret_cast<unsigned short*>(g_pref + (int64_t)(E + S + 1) * 49);  // sorted list (maps_in_lds)
-  unsigned short* s_kind = s_task + bwd_task_capacity(E);                                            // [E]
-  __shared__ int s_ntasks;
-  int n_tasks = E * (kGradParams + 1);
-  if (maps_in_lds) {
-    for (int e = tid; e < E; e += blockDim.x) {
-      s_kind[e] = (unsigned short)lat.elems[e].kind;
-      s_econ[e] = T(0);
-    }
-    __syncthreads();
-    if (tid == 0) {
-      int n = 0;
-      for (int k = 1; k <= LYNX_KIND_UNDULATOR; ++k) {
-        const int np = kind_params(k);
-        if (np == 0) continue;
-        const int first = n;
-        for (int e = 0; e < E; ++e)
-          if (s_kind[e] == k)
-            for (int q = 0; q <= np; ++q) s_task[n++] = (unsigned short)(e * 16 + (q == np ? kGradParams : q));
-        if (n > first)
-          while (n & 63) s_task[n++] = 0xffffu;  // a wave never mixes kinds
-      }
-      s_ntasks = n;
-    }
-    __syncthreads();
-    n_tasks = s_ntasks;
-  }
+  for (int e = tid; e < E; e += blockDim.x) s_econ[e] = T(0);
+  __syncthreads();
   for (int task = tid; task < n_tasks; task += blockDim.x) {
-    int e, pidx;
-    if (maps_in_lds) {
-      const unsigned code = s_task[task];
-      if (code == 0xffffu) continue;
-      e = (int)(code >> 4);
-      pidx = (int)(code & 15u);
-    } else {
-      e = task / (kGradParams + 1);
-      pidx = task % (kGradParams + 1);
-    }
+    const unsigned code = tasks[task];
+    if (code == 0xffffu) continue;
+    const int e = (int)(code >> 4), pidx = (int)(code & 15u);
     lynx_elem el = lat.elems[e];
-    const int np = kind_params(el.kind);
+    const int np = bwd_kind_params_dev(el.kind);
     const bool energy_task = pidx == kGradParams;
     T g = T(0);
     if ((pidx < np || energy_task) && np > 0) {
@@ -1017,14 +991,28 @@ __global__ __launch_bounds__(256) void k_build_bwd(LatticeDev lat, const T* __re
       Dual<T> dp[8];
       for (int q = 0; q < 8; ++q) dp[q] = Dual<T>(q < np ? p[q] : T(0), (q == pidx) ? T(1) : T(0));
       const Dual<T> de(s_energy[s], energy_task ? T(1) : T(0));
-      Dual<T> dM[49], dC[8];
+      Dual<T> dC[8];
       const bool cav_step = lat.steps[s].kind == LYNX_STEP_CAVITY;
       for (int q = 0; q < 8; ++q) dC[q] = Dual<T>(T(0));
-      build_element<Dual<T>>(el.kind, el.flags, dp, de, dM, cav_step ? dC : nullptr);
       const T* mb = g_pref + (int64_t)(e + s + 1) * 49;
-      for (int q = 0; q < 49; ++q) {
-        const T w = mb[q];
-        if (w != T(0)) g = t_fma(w, dM[q].d, g);  // 0 * (inf or NaN derivative) must not poison the sum
+      // Kinds whose maps have the structure of class U (drifts, correctors, untilted quadrupoles, cavities: all of
+      // BASELINE config 5) are differentiated through their 16 entries in registers; a 49-entry array of dual numbers
+      // per lane lives in scratch memory (656 bytes), which is what this kernel used to wait for.  An entry outside
+      // the pattern has derivative zero, so leaving its term out is exact.
+      Dual<T> m16[16];
+      if (build_entries_u<Dual<T>>(el.kind, el.flags, dp, de, m16, cav_step ? dC : nullptr)) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const T w = mb[unit_entry_u(k)];
+          if (w != T(0)) g = t_fma(w, m16[k].d, g);  // 0 * (inf or NaN derivative) must not poison the sum
+        }
+      } else {
+        Dual<T> dM[49];
+        build_element<Dual<T>>(el.kind, el.flags, dp, de, dM, cav_step ? dC : nullptr);
+        for (int q = 0; q < 49; ++q) {
+          const T w = mb[q];
+          if (w != T(0)) g = t_fma(w, dM[q].d, g);
+        }
       }
       if (cav_step) {
         const T* cb = tbar + (b * S + s) * (int64_t)kGradStride + LYNX_COEF_OFFSET;

@@ -210,6 +210,9 @@ struct lynx_lattice {
   bool units_made[2] = {false, false};
   bool units_ok[2] = {false, false};
   int32_t* d_step_unit[2] = {nullptr, nullptr};
+  // the reverse pass's (element, parameter) tasks, kind by kind (lynx_grad.hpp: bwd_kind_params), made on first use
+  unsigned short* d_bwd_tasks = nullptr;
+  int32_t n_bwd_tasks = 0;
 };
 
 static thread_local std::string g_err;
@@ -870,6 +873,7 @@ int lynx_lattice_destroy(lynx_lattice* lat) {
   if (lat->d_cavs) ctx_free(ctx, lat->d_cavs);
   for (int32_t* p : lat->d_step_unit)
     if (p) ctx_free(ctx, p);
+  if (lat->d_bwd_tasks) ctx_free(ctx, lat->d_bwd_tasks);
   if (lat->d_pieces) ctx_free(ctx, lat->d_pieces);
   if (lat->d_tasks) ctx_free(ctx, lat->d_tasks);
   if (lat->d_step_slot) ctx_free(ctx, lat->d_step_slot);
@@ -1647,6 +1651,30 @@ int lynx_track_particles_new(lynx_ctx* ctx, lynx_lattice* lat, int64_t n_particl
 
 // ---- reverse pass -----------------------------------------------------------------------
 
+// k_build_bwd's task list for this lattice: (element, parameter | energy) pairs kind by kind, every kind padded to whole
+// waves of 64 (lynx_grad.hpp).  The kinds of a lattice never change: made once.
+static int ensure_bwd_tasks(lynx_ctx* ctx, lynx_lattice* lat) {
+  if (lat->d_bwd_tasks) return LYNX_OK;
+  std::vector<unsigned short> tasks;
+  if (lat->n_elems >= 4096) return fail(ctx, LYNX_ERR_INVALID, "reverse pass: at most 4095 elements per program");
+  for (int k = 1; k <= LYNX_KIND_UNDULATOR; ++k) {
+    const int np = bwd_kind_params(k);
+    if (np == 0) continue;
+    const size_t first = tasks.size();
+    for (int32_t e = 0; e < lat->n_elems; ++e)
+      if (lat->h_elems[e].kind == k)
+        for (int q = 0; q <= np; ++q) tasks.push_back((unsigned short)(e * 16 + (q == np ? kGradParams : q)));
+    if (tasks.size() > first)
+      while (tasks.size() & 63) tasks.push_back(0xffffu);  // a wave never mixes kinds
+  }
+  if (tasks.empty()) tasks.assign(64, 0xffffu);
+  int rc = ctx_alloc(ctx, tasks.size() * sizeof(unsigned short), (void**)&lat->d_bwd_tasks);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpy(lat->d_bwd_tasks, tasks.data(), tasks.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+  lat->n_bwd_tasks = (int32_t)tasks.size();
+  return LYNX_OK;
+}
+
 constexpr int kBwdWgsPerCu = 24;                     // workgroups per CU of the reverse streaming kernels
 constexpr size_t kBwdMapsLdsBytes = (size_t)40 << 10;  // k_build_bwd keeps maps and prefix products in LDS up to this
 
@@ -1761,14 +1789,15 @@ static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const v
   }
   size_t lds2 = build_bwd_lds_fixed<T>(S, E);
   // maps + prefix products, then the kind-sorted task list and the elements' kinds (unsigned short each)
-  const size_t maps_bytes = (size_t)(2 * E + S + 1) * 49 * sizeof(T) + ((size_t)bwd_task_capacity(E) + E) * sizeof(unsigned short);
-  const int maps_in_lds = E < 4096 && lds2 + maps_bytes <= kBwdMapsLdsBytes;
+  const size_t maps_bytes = (size_t)(2 * E + S + 1) * 49 * sizeof(T);
+  if ((rc = ensure_bwd_tasks(ctx, lat))) return rc;
+  const int maps_in_lds = lds2 + maps_bytes <= kBwdMapsLdsBytes;
   if (maps_in_lds) lds2 += maps_bytes;
   if ((rc = allow_lds(ctx, k_build_bwd<T>, lds2))) return rc;
   HIP_TRY(ctx, hipMemsetAsync(d_grad_params, 0, (size_t)B * E * kGradParams * sizeof(T), ctx->stream));
   hipLaunchKernelGGL(k_build_bwd<T>, dim3((unsigned)B), dim3(256), lds2, ctx->stream, lv, (const T*)d_energy_in,
                      (T*)ctx->scratch_grad[1], (T*)ctx->scratch_grad[2], (T*)d_grad_params, (T*)d_grad_energy_in, merged,
-                     maps_in_lds);
+                     maps_in_lds, lat->d_bwd_tasks, lat->n_bwd_tasks);
   HIP_TRY(ctx, hipGetLastError());
   return LYNX_OK;
 }
@@ -1819,14 +1848,15 @@ static int moments_backward_t(lynx_ctx* ctx, lynx_lattice* lat, const void* d_en
   HIP_TRY(ctx, hipGetLastError());
   size_t lds2 = build_bwd_lds_fixed<T>(S, E);
   // maps + prefix products, then the kind-sorted task list and the elements' kinds (unsigned short each)
-  const size_t maps_bytes = (size_t)(2 * E + S + 1) * 49 * sizeof(T) + ((size_t)bwd_task_capacity(E) + E) * sizeof(unsigned short);
-  const int maps_in_lds = E < 4096 && lds2 + maps_bytes <= kBwdMapsLdsBytes;
+  const size_t maps_bytes = (size_t)(2 * E + S + 1) * 49 * sizeof(T);
+  if ((rc = ensure_bwd_tasks(ctx, lat))) return rc;
+  const int maps_in_lds = lds2 + maps_bytes <= kBwdMapsLdsBytes;
   if (maps_in_lds) lds2 += maps_bytes;
   if ((rc = allow_lds(ctx, k_build_bwd<T>, lds2))) return rc;
   HIP_TRY(ctx, hipMemsetAsync(d_grad_params, 0, (size_t)B * E * kGradParams * sizeof(T), ctx->stream));
   hipLaunchKernelGGL(k_build_bwd<T>, dim3((unsigned)B), dim3(256), lds2, ctx->stream, lv, (const T*)d_energy_in,
                      (T*)ctx->scratch_grad[1], (T*)ctx->scratch_grad[2], (T*)d_grad_params, (T*)d_grad_energy_in, 0,
-                     maps_in_lds);
+                     maps_in_lds, lat->d_bwd_tasks, lat->n_bwd_tasks);
   HIP_TRY(ctx, hipGetLastError());
   return LYNX_OK;
 }

@@ -169,8 +169,12 @@ template <typename T> LYNX_FN void build_drift(T L, T energy, T* M) {
   M[4 * 7 + 5] = -L / (beta * beta) * igamma2;
 }
 
-// lynx/track_methods.py:37-99 without the tilt rotation (applied by the caller)
-template <typename T> LYNX_FN void build_base_rmatrix(T L, T k1, T hx, T energy, T* M) {
+// The scalars of lynx/track_methods.py:37-99 (`base_rmatrix` without the tilt rotation): what both the 7x7 builder below
+// and the 16-entry builder of structured maps (build_entries_u) put into their matrices.
+template <typename T> struct BaseScalars {
+  T cx, sx, cy, sy, dx, r56, kx2, ky2, beta;
+};
+template <typename T> LYNX_HD void base_rmatrix_scalars(T L, T k1, T hx, T energy, BaseScalars<T>& o) {
   T gamma = energy / T(LYNX_REST_ENERGY);
   T igamma2 = T(1);  // ones where gamma == 0 (track_methods.py:61)
   if (gamma != T(0)) igamma2 = T(1) / (gamma * gamma);
@@ -186,6 +190,14 @@ template <typename T> LYNX_FN void build_base_rmatrix(T L, T k1, T hx, T energy,
   T dx = hx / kx2 * (T(1) - cx);
   T r56 = hx * hx * (L - sx) / kx2 / (beta * beta);
   r56 = r56 - L / (beta * beta) * igamma2;
+  o.cx = cx; o.sx = sx; o.cy = cy; o.sy = sy; o.dx = dx; o.r56 = r56; o.kx2 = kx2; o.ky2 = ky2; o.beta = beta;
+}
+
+// lynx/track_methods.py:37-99 without the tilt rotation (applied by the caller)
+template <typename T> LYNX_FN void build_base_rmatrix(T L, T k1, T hx, T energy, T* M) {
+  BaseScalars<T> b;
+  base_rmatrix_scalars(L, k1, hx, energy, b);
+  const T cx = b.cx, sx = b.sx, cy = b.cy, sy = b.sy, dx = b.dx, r56 = b.r56, kx2 = b.kx2, ky2 = b.ky2, beta = b.beta;
 
   mat_identity(M);
   M[0 * 7 + 0] = cx;
@@ -300,7 +312,10 @@ template <typename T> LYNX_HD T cavity_r55_bracket(T g0, T g1, T beta0, T beta1)
 // lynx/accelerator/cavity.py:248-325 (`_cavity_rmatrix`) plus, when `coef` is non-null,
 // the per-sample coefficients of the non-linear step (cavity.py:97-246, `_track_beam`).
 // p = [L, V, phase_deg, f].  Returns the outgoing energy.
-template <typename T> LYNX_FN T build_cavity(const T* p, int flags, T energy, T* M, T* coef) {
+template <typename T> struct CavityScalars {
+  T r11, r12, r21, r22, r55_cor, r56, r65, r66;
+};
+template <typename T> LYNX_HD T cavity_scalars(const T* p, int flags, T energy, CavityScalars<T>& o, T* coef) {
   const T me = T(LYNX_ELECTRON_MASS_EV);
   T L = p[0], V = p[1], f = p[3];
   T phi = p[2] * T(LYNX_PI / 180.0);  // deg2rad
@@ -329,20 +344,7 @@ template <typename T> LYNX_FN T build_cavity(const T* p, int flags, T energy, T*
   }
   T r66 = Ei / Ef * beta0 / beta1;
   T r65 = k * sphi * V / (Ef * beta1 * me);
-
-  mat_identity(M);
-  M[0 * 7 + 0] = r11;
-  M[0 * 7 + 1] = r12;
-  M[1 * 7 + 0] = r21;
-  M[1 * 7 + 1] = r22;
-  M[2 * 7 + 2] = r11;
-  M[2 * 7 + 3] = r12;
-  M[3 * 7 + 2] = r21;
-  M[3 * 7 + 3] = r22;
-  M[4 * 7 + 4] = T(1) + r55_cor;
-  M[4 * 7 + 5] = r56;
-  M[5 * 7 + 4] = r65;
-  M[5 * 7 + 5] = r66;
+  o.r11 = r11; o.r12 = r12; o.r21 = r21; o.r22 = r22; o.r55_cor = r55_cor; o.r56 = r56; o.r65 = r65; o.r66 = r66;
 
   T energy_out = energy;
   if (coef) {
@@ -389,6 +391,24 @@ template <typename T> LYNX_FN T build_cavity(const T* p, int flags, T energy, T*
     coef[LYNX_C_T556] = gain ? T556 : T(0);
     coef[LYNX_C_T555] = gain ? T555 : T(0);
   }
+  return energy_out;
+}
+template <typename T> LYNX_FN T build_cavity(const T* p, int flags, T energy, T* M, T* coef) {
+  CavityScalars<T> c;
+  const T energy_out = cavity_scalars(p, flags, energy, c, coef);
+  mat_identity(M);
+  M[0 * 7 + 0] = c.r11;
+  M[0 * 7 + 1] = c.r12;
+  M[1 * 7 + 0] = c.r21;
+  M[1 * 7 + 1] = c.r22;
+  M[2 * 7 + 2] = c.r11;
+  M[2 * 7 + 3] = c.r12;
+  M[3 * 7 + 2] = c.r21;
+  M[3 * 7 + 3] = c.r22;
+  M[4 * 7 + 4] = T(1) + c.r55_cor;
+  M[4 * 7 + 5] = c.r56;
+  M[5 * 7 + 4] = c.r65;
+  M[5 * 7 + 5] = c.r66;
   return energy_out;
 }
 
@@ -451,6 +471,93 @@ template <typename T> LYNX_FN void build_undulator(T L, T energy, T* M) {
   M[0 * 7 + 1] = L;
   M[2 * 7 + 3] = L;
   M[4 * 7 + 5] = L * igamma2;
+}
+
+// The map of an element whose kind and whole-batch flags give it the structure of class U (lynx_unit_record.hpp: rows
+// 0, 1 <- columns {0, 1, 6}; rows 2, 3 <- {2, 3, 6}; rows 4, 5 <- {4, 5}; row 6 = e6) as its 16 entries, in the order of
+// unit_entry_u(), straight into registers -- no 7x7 in memory.  Same scalars, same operations as the builders above
+// (the misaligned quadrupole's sandwich, quadrupole.py:75-80, written out for the entries it can reach).  Returns false
+// for every other kind (dipoles, tilted quadrupoles, solenoids, custom maps, the helper kinds): those take
+// build_element.  Used where a map is needed per (element, parameter) and a 49-entry array per lane would live in
+// scratch memory: the dual-number evaluation of k_build_bwd.
+template <typename T>
+LYNX_HD bool build_entries_u(int kind, int flags, const T* p, T energy, T (&m)[16], T* coef) {
+#pragma unroll
+  for (int k = 0; k < 16; ++k) m[k] = T(0);
+  m[0] = T(1);   // [0][0]
+  m[4] = T(1);   // [1][1]
+  m[6] = T(1);   // [2][2]
+  m[10] = T(1);  // [3][3]
+  m[12] = T(1);  // [4][4]
+  m[15] = T(1);  // [5][5]
+  switch (kind) {
+    case LYNX_KIND_IDENTITY: return true;
+    case LYNX_KIND_DRIFT:
+    case LYNX_KIND_HCOR:
+    case LYNX_KIND_VCOR: {  // drift.py:44-62; *_corrector.py:52-67
+      const T L = p[0];
+      T gamma = energy / T(LYNX_REST_ENERGY);
+      T igamma2 = T(0);
+      if (gamma != T(0)) igamma2 = T(1) / (gamma * gamma);
+      T beta = t_sqrt(T(1) - igamma2);
+      m[1] = L;                                // [0][1]
+      m[7] = L;                                // [2][3]
+      m[13] = -L / (beta * beta) * igamma2;    // [4][5]
+      if (kind == LYNX_KIND_HCOR) m[5] = p[1];   // [1][6]
+      if (kind == LYNX_KIND_VCOR) m[11] = p[1];  // [3][6]
+      return true;
+    }
+    case LYNX_KIND_UNDULATOR: {  // undulator.py:48-60
+      const T L = p[0];
+      const T gamma = energy / T(LYNX_REST_ENERGY);
+      T igamma2 = T(0);
+      if (gamma != T(0)) igamma2 = T(1) / (gamma * gamma);
+      m[1] = L;
+      m[7] = L;
+      m[13] = L * igamma2;
+      return true;
+    }
+    case LYNX_KIND_QUADRUPOLE: {
+      if (flags & LYNX_FLAG_TILT) return false;
+      BaseScalars<T> b;
+      base_rmatrix_scalars(p[0], p[1], T(0), energy, b);
+      m[0] = b.cx;
+      m[1] = b.sx;
+      m[3] = -b.kx2 * b.sx;
+      m[4] = b.cx;
+      m[6] = b.cy;
+      m[7] = b.sy;
+      m[9] = -b.ky2 * b.sy;
+      m[10] = b.cy;
+      m[13] = b.r56;
+      if (flags & LYNX_FLAG_MISALIGNED) {  // R_exit . R . R_entry (quadrupole.py:75-80; track_methods.py:108-122)
+        const T mx = p[3], my = p[4];
+        m[2] = (m[0] * (-mx)) + mx;   // [0][6]
+        m[5] = (m[3] * (-mx));        // [1][6]
+        m[8] = (m[6] * (-my)) + my;   // [2][6]
+        m[11] = (m[9] * (-my));       // [3][6]
+      }
+      return true;
+    }
+    case LYNX_KIND_CAVITY: {
+      CavityScalars<T> c;
+      (void)cavity_scalars(p, flags, energy, c, coef);
+      m[0] = c.r11;
+      m[1] = c.r12;
+      m[3] = c.r21;
+      m[4] = c.r22;
+      m[6] = c.r11;
+      m[7] = c.r12;
+      m[9] = c.r21;
+      m[10] = c.r22;
+      m[12] = T(1) + c.r55_cor;
+      m[13] = c.r56;
+      m[14] = c.r65;
+      m[15] = c.r66;
+      return true;
+    }
+    default: return false;
+  }
 }
 
 // One element -> M (49 scalars).  `p` points at the element's parameter row of this

@@ -48,3 +48,17 @@ extern "C" void harness_build_dual_f32(int kind, int flags, const float* p, int 
   for (int q = 0; q < 49; ++q) { M[q] = dm[q].v; dM[q] = dm[q].d; }
   for (int q = 0; q < 8; ++q) { coef[q] = dc[q].v; dcoef[q] = dc[q].d; }
 }
+
+// The 16-entry builder of structured maps (lynx_maps.hpp: build_entries_u): returns 1 and the entries, or 0.
+extern "C" int harness_entries_u_f32(int kind, int flags, const float* p, float energy, float* m16, float* coef) {
+  float m[16];
+  const bool ok = lynx::build_entries_u<float>(kind, flags, p, energy, m, coef);
+  for (int k = 0; k < 16; ++k) m16[k] = m[k];
+  return ok ? 1 : 0;
+}
+extern "C" int harness_entries_u_f64(int kind, int flags, const double* p, double energy, double* m16, double* coef) {
+  double m[16];
+  const bool ok = lynx::build_entries_u<double>(kind, flags, p, energy, m, coef);
+  for (int k = 0; k < 16; ++k) m16[k] = m[k];
+  return ok ? 1 : 0;
+}

@@ -155,3 +155,50 @@ def test_solenoid_and_undulator(host_harness, dtype):
         _check(host_harness, _ffi.KIND_SOLENOID, flags, [L, k, mis[0], mis[1]], energy, spec, dtype)
     for L, energy in ((0.25, 1e8), (1.0, 6e6), (0.5, 0.0)):
         _check(host_harness, _ffi.KIND_UNDULATOR, 0, [L], energy, o.Undulator(a(L)), dtype)
+
+
+ENTRY_U = [0 * 7 + 0, 0 * 7 + 1, 0 * 7 + 6, 1 * 7 + 0, 1 * 7 + 1, 1 * 7 + 6, 2 * 7 + 2, 2 * 7 + 3, 2 * 7 + 6, 3 * 7 + 2, 3 * 7 + 3,
+           3 * 7 + 6, 4 * 7 + 4, 4 * 7 + 5, 5 * 7 + 4, 5 * 7 + 5]  # lynx_unit_record.hpp: unit_entry_u
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_the_16_entry_builder_of_structured_maps_equals_the_7x7_builder(host_harness, dtype):
+    """
+    lynx_maps.hpp: build_entries_u gives the maps of the kinds with class-U structure (drift, correctors, undulator,
+    untilted quadrupole with or without misalignment, cavity, identity) as 16 entries in registers; the reverse pass
+    differentiates through it (k_build_bwd).  Bit for bit the entries of build_element at the pattern's positions, the
+    rest of build_element's 7x7 exactly the identity's; every other kind is refused.
+    """
+    import ctypes as C
+
+    from lynx_amd import _ffi
+
+    ct = C.c_float if dtype == np.float32 else C.c_double
+    fn = host_harness.harness_entries_u_f32 if dtype == np.float32 else host_harness.harness_entries_u_f64
+    fn.argtypes = [C.c_int, C.c_int, C.c_void_p, ct, C.c_void_p, C.c_void_p]
+    fn.restype = C.c_int
+    cav = _ffi.FLAG_CAV_BETA | _ffi.FLAG_CAV_GAIN | _ffi.FLAG_CAV_T5XX
+    cases = [(_ffi.KIND_IDENTITY, 0, [], 1e8), (_ffi.KIND_DRIFT, 0, [0.7], 6e6), (_ffi.KIND_HCOR, 0, [0.3, 1e-3], 1e8),
+             (_ffi.KIND_VCOR, 0, [0.3, -2e-3], 6e6), (_ffi.KIND_UNDULATOR, 0, [0.8], 6e6),
+             (_ffi.KIND_QUADRUPOLE, 0, [0.2, 4.2, 0.0, 0.0, 0.0], 1e8), (_ffi.KIND_QUADRUPOLE, 0, [0.2, 0.0, 0.0, 0.0, 0.0], 1e8),
+             (_ffi.KIND_QUADRUPOLE, _ffi.FLAG_MISALIGNED, [0.1, -3.1, 0.0, 1e-3, -2e-3], 6e6),
+             (_ffi.KIND_CAVITY, cav, [1.0377, 1.8e7, 5.0, 1.3e9], 6e6), (_ffi.KIND_CAVITY, cav, [1.0377, 1.2e7, -7.0, 1.3e9], 9e7),
+             (_ffi.KIND_CAVITY, _ffi.FLAG_CAV_BETA, [1.0, 0.0, 3.0, 1.3e9], 1e8)]  # V = 0: NaN in r12, as the reference
+    for kind, flags, p, energy in cases:
+        want_coef = kind == _ffi.KIND_CAVITY
+        M, coef = harness_map(host_harness, kind, flags, p, energy, dtype, want_coef)
+        pp = np.ascontiguousarray(np.asarray(p if p else [0.0], dtype=dtype))
+        m16, c8 = np.zeros(16, dtype), np.zeros(8, dtype)
+        assert fn(kind, flags, pp.ctypes.data, ct(float(energy)), m16.ctypes.data, c8.ctypes.data if want_coef else None) == 1
+        flat = M.reshape(-1)
+        assert np.array_equal(m16, flat[ENTRY_U], equal_nan=True), (kind, flags, m16, flat[ENTRY_U])
+        rest = np.delete(flat, ENTRY_U)
+        assert np.array_equal(rest, np.delete(np.eye(7, dtype=dtype).reshape(-1), ENTRY_U)), (kind, flags)
+        if want_coef:
+            assert np.array_equal(c8, coef, equal_nan=True)
+    for kind, flags, p in [(_ffi.KIND_QUADRUPOLE, _ffi.FLAG_TILT, [0.2, 1.0, 0.3, 0.0, 0.0]),
+                           (_ffi.KIND_DIPOLE, _ffi.FLAG_THICK, [0.5, 0.1, 0, 0, 0, 0, 0, 0]), (_ffi.KIND_SOLENOID, 0, [0.5, 2.0, 0, 0]),
+                           (_ffi.KIND_ROTATION, 0, [0.3])]:
+        pp = np.ascontiguousarray(np.asarray(p, dtype=dtype))
+        m16 = np.zeros(16, dtype)
+        assert fn(kind, flags, pp.ctypes.data, ct(1e8), m16.ctypes.data, None) == 0
