@@ -237,12 +237,15 @@ int lynx_track_moments(lynx_ctx* ctx, lynx_lattice* lat, const void* d_energy_in
  *   d_grad_energy_in [B]            dL/d(incoming energy)
  *   d_grad_p_in    [B][N][7] or NULL dL/d(incoming particle coordinates) (the reference's
  *                                   tests/test_differentiable.py:75-91 differentiates through those)
+ *   d_grad_observations [B][n_observers][2] float64 or NULL: dL/d(reading) of the program's observer steps (active
+ *                                   BPMs, bpm.py:48-58: the reading is the mean x, y of the beam that enters the BPM)
  * Limit of this version: n_steps <= 64 (every 4th per-particle state is parked in a
  * fixed-size private array during the forward sweep).                                       */
 int lynx_track_particles_backward(lynx_ctx* ctx, lynx_lattice* lat, int64_t n_particles,
                                   const void* d_energy_in, const void* d_p_in,
                                   const double* d_moments_fwd, const double* d_grad_moments,
-                                  void* d_grad_params, void* d_grad_energy_in, void* d_grad_p_in);
+                                  void* d_grad_params, void* d_grad_energy_in, void* d_grad_p_in,
+                                  const double* d_grad_observations);
 
 /* Reverse pass of lynx_track_moments (ParameterBeam): gradient of a scalar function of the
  * outgoing (mu, cov) with respect to every element parameter, the incoming energy and the

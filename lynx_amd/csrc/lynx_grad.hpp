@@ -68,6 +68,11 @@ struct BwdArgs {
   // run's slot in front of it holds the two rows that give the s and delta entering the cavity and
   // carries LYNX_DESC_PAIR in its descriptor
   unsigned char unit_slot[kBwdGroup * kBwdMaxGroups];
+  // observer steps (active BPMs, LYNX_STEP_FLAG_OBSERVE): 0 = this unit is none, k + 1 = it is the program's k-th one.
+  // Its reading is the mean x and y of the beam that ENTERS it (bpm.py:48-54): linear in the particles, so a cotangent
+  // of the reading is one more term of every particle's cotangent at that point of the reverse sweep.
+  unsigned char unit_observer[kBwdGroup * kBwdMaxGroups];
+  int32_t n_observers;
 };
 
 // ---------------------------------------------------------------------------------------
@@ -362,7 +367,8 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
     T* __restrict__ partials /* [B][chunks][S][64] */, T* __restrict__ grad_p /* [B][N][7] or null */,
     const float* __restrict__ units_skip = nullptr /* unit records: samples whose units are all of class U belong to
                                                        k_track_bwd_units (lynx_grad_units.hpp) */,
-    int units_stride = 0, int units_class_shift = 0, int units_class_u = 0) {
+    int units_stride = 0, int units_class_shift = 0, int units_class_u = 0,
+    const double* __restrict__ grad_observations = nullptr /* [B][n_observers][2] or null: dL/d(reading) */) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int K = kBwdGroup;
   constexpr int W = LaneOf<Z>::W;
@@ -599,6 +605,17 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
 #pragma unroll
           for (int r = 1; r < 7; ++r) v = zfma(olin[r], m[r * 7 + jj], v);
           zb[jj] = v;
+        }
+        if (grad_observations != nullptr && a.unit_observer[u] != 0) {  // uniform: an active BPM read the beam entering this unit
+          const double* ob = grad_observations + (b * a.n_observers + (a.unit_observer[u] - 1)) * 2;
+          const T inv_n = (T)(1.0 / rec[35]), gx = (T)ob[0] * inv_n, gy = (T)ob[1] * inv_n;
+#pragma unroll
+          for (int w = 0; w < W; ++w) {
+            if (live[w]) {
+              zset(zb[0], w, zget(zb[0], w) + gx);
+              zset(zb[2], w, zget(zb[2], w) + gy);
+            }
+          }
         }
         if (!paired) {
           zb[4] += dir4;

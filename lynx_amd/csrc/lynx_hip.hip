@@ -1681,7 +1681,7 @@ constexpr size_t kBwdMapsLdsBytes = (size_t)40 << 10;  // k_build_bwd keeps maps
 template <typename T, typename Z = T>
 static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const void* d_energy_in, const void* d_p_in,
                             const double* d_moments_fwd, const double* d_grad_moments, void* d_grad_params,
-                            void* d_grad_energy_in, void* d_grad_p_in) {
+                            void* d_grad_energy_in, void* d_grad_p_in, const double* d_grad_observations) {
   const int64_t B = lat->batch;
   const int32_t S = lat->n_steps, E = lat->n_elems;
   int rc;
@@ -1695,6 +1695,7 @@ static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const v
       merged |= lat->h_steps[s].kind == LYNX_STEP_CAVITY && lat->h_steps[s - 1].kind == LYNX_STEP_RUN &&
                 !(lat->h_steps[s - 1].flags & LYNX_STEP_FLAG_OBSERVE);
   a.n_units = 0;
+  a.n_observers = 0;
   for (int32_t s = 0; s < S; ++s) {
     const bool pair = merged && s + 1 < S && lat->h_steps[s].kind == LYNX_STEP_RUN &&
                       lat->h_steps[s + 1].kind == LYNX_STEP_CAVITY && !(lat->h_steps[s].flags & LYNX_STEP_FLAG_OBSERVE);
@@ -1703,9 +1704,11 @@ static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const v
       return fail(ctx, LYNX_ERR_INVALID,
                   "lynx_track_particles_backward: " + std::to_string(S) + " steps; this version parks at most " +
                       std::to_string(kBwdGroup * kBwdMaxGroups) + " (merge skippable elements or split the lattice)");
+    a.unit_observer[a.n_units] = 0;
+    if (lat->h_steps[s].flags & LYNX_STEP_FLAG_OBSERVE) a.unit_observer[a.n_units] = (unsigned char)(++a.n_observers);
     a.unit_slot[a.n_units++] = (unsigned char)s;
   }
-  for (int u = a.n_units; u < kBwdGroup * kBwdMaxGroups; ++u) a.unit_slot[u] = 0;
+  for (int u = a.n_units; u < kBwdGroup * kBwdMaxGroups; ++u) a.unit_slot[u] = a.unit_observer[u] = 0;
   const size_t steps_bytes = (size_t)B * S * LYNX_STEP_STRIDE * sizeof(T);
   if ((rc = ensure_scratch(ctx, &ctx->scratch_steps[lynx_ctx::kTableBwd], &ctx->scratch_steps_bytes[lynx_ctx::kTableBwd], steps_bytes))) return rc;
   // float32 packed pairs: samples whose units all have class U take the structured reverse kernel (lynx_grad_units.hpp)
@@ -1775,7 +1778,8 @@ static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const v
   }
   hipLaunchKernelGGL((k_track_bwd<T, Z>), dim3((unsigned)(B * chunks)), dim3(kTrackThreads), lds, ctx->stream, lv, a,
                      (const T*)d_p_in, (const T*)ctx->scratch_steps[lynx_ctx::kTableBwd], d_moments_fwd, d_grad_moments,
-                     (T*)ctx->scratch_grad[0], (T*)d_grad_p_in, (const float*)d_units, kUnitStride, kUnitClassShift, (int)kClassU);
+                     (T*)ctx->scratch_grad[0], (T*)d_grad_p_in, (const float*)d_units, kUnitStride, kUnitClassShift, (int)kClassU,
+                     d_grad_observations);
   HIP_TRY(ctx, hipGetLastError());
   hipLaunchKernelGGL(k_reduce_tbar<T>, dim3((unsigned)(B * S)), dim3(64), 0, ctx->stream, (const T*)ctx->scratch_grad[0],
                      (int)chunks, (int)S, (T*)ctx->scratch_grad[1]);
@@ -1804,10 +1808,13 @@ static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const v
 
 int lynx_track_particles_backward(lynx_ctx* ctx, lynx_lattice* lat, int64_t n_particles, const void* d_energy_in,
                                   const void* d_p_in, const double* d_moments_fwd, const double* d_grad_moments,
-                                  void* d_grad_params, void* d_grad_energy_in, void* d_grad_p_in) {
+                                  void* d_grad_params, void* d_grad_energy_in, void* d_grad_p_in,
+                                  const double* d_grad_observations) {
   if (!ctx || !lat || !d_energy_in || !d_p_in || !d_moments_fwd || !d_grad_moments || !d_grad_params || !d_grad_energy_in)
     return fail(ctx, LYNX_ERR_INVALID, "null argument");
   if (n_particles <= 0 || lat->n_steps <= 0) return fail(ctx, LYNX_ERR_INVALID, "empty program or beam");
+  if (d_grad_observations && lat->n_observers == 0)
+    return fail(ctx, LYNX_ERR_INVALID, "d_grad_observations given, but the program has no observer step");
   HIP_TRY(ctx, use_device(ctx));
   {
     const int rc = join_side(ctx);  // d_moments_fwd is what a reduction on the side stream writes
@@ -1815,12 +1822,13 @@ int lynx_track_particles_backward(lynx_ctx* ctx, lynx_lattice* lat, int64_t n_pa
   }
   return lat->dtype == LYNX_F64
              ? track_backward_t<double>(ctx, lat, n_particles, d_energy_in, d_p_in, d_moments_fwd, d_grad_moments,
-                                        d_grad_params, d_grad_energy_in, d_grad_p_in)
+                                        d_grad_params, d_grad_energy_in, d_grad_p_in, d_grad_observations)
          : ctx->knobs.bwd_pairs
              ? track_backward_t<float, lynx_f32x2>(ctx, lat, n_particles, d_energy_in, d_p_in, d_moments_fwd,
-                                                   d_grad_moments, d_grad_params, d_grad_energy_in, d_grad_p_in)
+                                                   d_grad_moments, d_grad_params, d_grad_energy_in, d_grad_p_in,
+                                                   d_grad_observations)
              : track_backward_t<float>(ctx, lat, n_particles, d_energy_in, d_p_in, d_moments_fwd, d_grad_moments,
-                                       d_grad_params, d_grad_energy_in, d_grad_p_in);
+                                       d_grad_params, d_grad_energy_in, d_grad_p_in, d_grad_observations);
 }
 
 template <typename T>

@@ -149,20 +149,48 @@ def property_cotangents(outgoing: ParticleBeam, named: dict):
     return mu_bar, cov_bar
 
 
+def _reading_cotangents(program, readings: dict, batch_shape) -> np.ndarray | None:
+    """
+    `{bpm: cotangent of bpm.reading}` -> [B][observers][2] float64 in the order the program reads them.  A BPM's reading
+    is `stack([mu_x, mu_y])` of the beam that enters it (bpm.py:48-54), shape (2, *batch): so is its cotangent.
+    """
+    if not readings:
+        return None
+    B = int(np.prod(batch_shape, dtype=np.int64))
+    out = np.zeros((B, len(program.observers), 2), dtype=np.float64)
+    known = {id(element): k for k, (_, element) in enumerate(program.observers)}
+    for element, bar in readings.items():
+        if id(element) not in known:
+            raise KeyError(f"{element!r} is not an active BPM of this lattice")
+        bar = np.broadcast_to(np.asarray(bar, dtype=np.float64), (2, *batch_shape))
+        out[:, known[id(element)], 0] += bar[0].reshape(B)
+        out[:, known[id(element)], 1] += bar[1].reshape(B)
+    return out
+
+
 class TrackVJP:
     def __init__(self, segment, beam: ParticleBeam):
         if not isinstance(beam, ParticleBeam):
             raise TypeError("track_vjp needs a ParticleBeam")
-        items = engine.partition(segment.elements if hasattr(segment, "elements") else [segment])
+        # active BPMs are read inside the streaming pass (observer steps); their readings are differentiable outputs
+        items = engine.partition(segment.elements if hasattr(segment, "elements") else [segment], fuse_observers=True)
         if len(items) != 1 or not isinstance(items[0], engine.Program):
-            raise NotImplementedError("track_vjp: lattices with active BPMs are not supported yet")
+            raise NotImplementedError(
+                f"track_vjp: a lattice with an active Screen or Aperture, or with more than {_ffi.MAX_OBSERVERS} active "
+                "BPMs, is tracked in several passes -- differentiate the stretches one by one")
         self.program = items[0]
         beam = beam.materialized()  # the reverse pass indexes the incoming particles per sample
         self.beam = beam
         self.cache = segment.__dict__.setdefault("_lattice_cache", engine.LatticeCache())
         self.outgoing = engine.run_program_particles(self.cache, self.program, beam, moments=True)
 
-    def __call__(self, mu_bar=None, cov_bar=None, wrt_particles: bool = False, **properties) -> Gradients:
+    def __call__(self, mu_bar=None, cov_bar=None, wrt_particles: bool = False, readings: dict | None = None,
+                 **properties) -> Gradients:
+        """
+        Cotangents of the outgoing beam's mean (`mu_bar`, (*batch, 6)) and covariance (`cov_bar`, (*batch, 6, 6)), of named
+        beam properties (`sigma_x=...`), and -- `readings={bpm: bar}` -- of the readings of the lattice's active BPMs
+        (`bar` shaped like `bpm.reading`: (2, *batch)).
+        """
         rt = get_runtime()
         beam, program = self.beam, self.program
         batch_shape, dtype = beam.batch_shape, beam.dtype
@@ -189,24 +217,76 @@ class TrackVJP:
         g_p = rt.empty((*batch_shape, beam.num_particles, 7), dtype) if wrt_particles else None
         fwd = self.outgoing._moments.device(rt)
         e_in = beam._energy.broadcast_device(rt, batch_shape)
+        obs_bar = _reading_cotangents(program, readings, batch_shape)
+        g_obs = None if obs_bar is None else rt.to_device(obs_bar)  # (named: alive until the call has been enqueued)
         rt.check(rt.lib.lynx_track_particles_backward(
             rt.ctx, lat.handle, beam.num_particles, C.c_void_p(e_in.ptr), C.c_void_p(beam._particles.device(rt).ptr),
             C.c_void_p(fwd.ptr), C.c_void_p(g_rec.ptr), C.c_void_p(g_par.ptr), C.c_void_p(g_en.ptr),
-            None if g_p is None else C.c_void_p(g_p.ptr)))
+            None if g_p is None else C.c_void_p(g_p.ptr), None if g_obs is None else C.c_void_p(g_obs.ptr)))
         return Gradients(program, g_par, g_en, batch_shape, np.asarray(beam.energy).shape, g_p)
 
 
+class ChainedGradients:
+    """Gradients of a lattice that was differentiated stretch by stretch (a ParameterBeam through active BPMs)."""
+
+    def __init__(self, parts: list):
+        self._parts = parts  # in lattice order
+
+    @property
+    def energy(self) -> np.ndarray:
+        return sum(part.energy for part in self._parts)
+
+    @property
+    def mu(self) -> np.ndarray:
+        return self._parts[0].mu
+
+    @property
+    def cov(self) -> np.ndarray:
+        return self._parts[0].cov
+
+    def __contains__(self, element) -> bool:
+        return any(element in part for part in self._parts)
+
+    def __getitem__(self, element) -> dict:
+        total = None
+        for part in self._parts:
+            if element in part:
+                got = part[element]
+                total = got if total is None else {n: total[n] + got[n] for n in got}
+        if total is None:
+            raise KeyError(f"{element!r} has no differentiable parameters in this lattice")
+        return total
+
+
 class MomentsVJP:
-    """Vector-Jacobian product of `Segment.track` on a `ParameterBeam` (lynx_track_moments_backward)."""
+    """
+    Vector-Jacobian product of `Segment.track` on a `ParameterBeam` (lynx_track_moments_backward).  An active BPM cuts
+    the lattice in stretches (it is a host-side step of `track`, bpm.py:48-58): each stretch is differentiated by the
+    kernel, and (mu_bar, cov_bar) -- plus the cotangent of the BPM's reading, which is (mu_x, mu_y) of the beam at that
+    point -- is handed from a stretch to the one in front of it.
+    """
 
     def __init__(self, segment, beam):
         items = engine.partition(segment.elements if hasattr(segment, "elements") else [segment])
-        if len(items) != 1 or not isinstance(items[0], engine.Program):
-            raise NotImplementedError("track_vjp: lattices with active BPMs are not supported yet")
-        self.program = items[0]
-        self.beam = beam
+        for item in items:
+            if not isinstance(item, engine.Program) and not getattr(item, "_fusable_observer", False):
+                raise NotImplementedError("track_vjp: lattices with an active Screen or Aperture are not differentiated")
         self.cache = segment.__dict__.setdefault("_lattice_cache", engine.LatticeCache())
-        self.outgoing = engine.run_program_parameters(self.cache, self.program, beam)
+        self.stretches = []  # (Program, beam entering it) / (BPM, None), in lattice order
+        for k, item in enumerate(items):
+            if isinstance(item, engine.Program):
+                if any(el._kind == _ffi.KIND_CAVITY for el in item.leaves) and any(isinstance(i, engine.Program) for i in items[k + 1:]):
+                    raise NotImplementedError(
+                        "track_vjp: a cavity in front of an active BPM (the energy cotangent does not cross stretches yet)")
+                self.stretches.append((item, beam))
+                beam = engine.run_program_parameters(self.cache, item, beam)
+            else:
+                item._observe(beam)
+                self.stretches.append((item, None))
+                beam = beam._shallow_copy()
+        self.program = items[0] if len(items) == 1 else None
+        self.beam = self.stretches[0][1] if self.stretches else beam
+        self.outgoing = beam
 
     def _property_cotangents(self, named: dict):
         """`mu_<c>`: mu[c]; `sigma_<c>` = sqrt(max(cov_cc, 1e-20)) (parameter_beam.py:371-417); `sigma_xxp/yyp`: cov_01, cov_23."""
@@ -229,24 +309,10 @@ class MomentsVJP:
                 raise KeyError(f"no cotangent rule for beam property {name!r}")
         return mu_bar, cov_bar
 
-    def __call__(self, mu_bar=None, cov_bar=None, **properties) -> Gradients:
-        """`mu_bar` (*batch, <=7), `cov_bar` (*batch, 6|7, 6|7): cotangents entry by entry."""
+    def _stretch(self, program, beam, mb, cb) -> Gradients:
         rt = get_runtime()
-        beam, program = self.beam, self.program
         batch_shape, dtype = beam.batch_shape, beam.dtype
         B = int(np.prod(batch_shape, dtype=np.int64))
-        mb, cb = np.zeros((B, 7)), np.zeros((B, 7, 7))
-        if properties:
-            pm, pc = self._property_cotangents(properties)
-            mb += pm.reshape(B, 7)
-            cb += pc.reshape(B, 7, 7)
-        if mu_bar is not None:
-            mu_bar = np.asarray(mu_bar, dtype=np.float64).reshape(B, -1)
-            mb[:, : mu_bar.shape[1]] += mu_bar
-        if cov_bar is not None:
-            cov_bar = np.asarray(cov_bar, dtype=np.float64)
-            k = cov_bar.shape[-1]
-            cb[:, :k, :k] += cov_bar.reshape(B, k, k)
         lat = engine._ready(self.cache, program, batch_shape, dtype, beam._energy._host)
         g_par = rt.empty((B, max(lat.E, 1), 8), dtype)
         g_en = rt.empty((B,), dtype)
@@ -260,6 +326,46 @@ class MomentsVJP:
             rt.ctx, lat.handle, p(e_in), p(beam._mu_d.device(rt)), p(beam._cov_d.device(rt)),
             p(mb_dev), p(cb_dev), p(g_par), p(g_en), p(g_mu), p(g_cov)))
         return Gradients(program, g_par, g_en, batch_shape, np.asarray(beam.energy).shape, mu_dev=g_mu, cov_dev=g_cov)
+
+    def __call__(self, mu_bar=None, cov_bar=None, readings: dict | None = None, **properties):
+        """
+        `mu_bar` (*batch, <=7), `cov_bar` (*batch, 6|7, 6|7): cotangents entry by entry; `readings={bpm: bar}`: cotangents
+        of the readings of active BPMs, shaped like `bpm.reading` -- (2, *batch).
+        """
+        batch_shape = self.outgoing.batch_shape
+        B = int(np.prod(batch_shape, dtype=np.int64))
+        mb, cb = np.zeros((B, 7)), np.zeros((B, 7, 7))
+        if properties:
+            pm, pc = self._property_cotangents(properties)
+            mb += pm.reshape(B, 7)
+            cb += pc.reshape(B, 7, 7)
+        if mu_bar is not None:
+            mu_bar = np.asarray(mu_bar, dtype=np.float64).reshape(B, -1)
+            mb[:, : mu_bar.shape[1]] += mu_bar
+        if cov_bar is not None:
+            cov_bar = np.asarray(cov_bar, dtype=np.float64)
+            k = cov_bar.shape[-1]
+            cb[:, :k, :k] += cov_bar.reshape(B, k, k)
+        readings = dict(readings or {})
+        known = {id(item): item for item, beam in self.stretches if beam is None}
+        for element in readings:
+            if id(element) not in known:
+                raise KeyError(f"{element!r} is not an active BPM of this lattice")
+        parts = []
+        for item, beam in reversed(self.stretches):
+            if beam is None:  # an active BPM: its reading is (mu_x, mu_y) of the beam passing here
+                for element, bar in readings.items():
+                    if element is item:
+                        bar = np.broadcast_to(np.asarray(bar, dtype=np.float64), (2, *batch_shape))
+                        mb[:, 0] += bar[0].reshape(B)
+                        mb[:, 2] += bar[1].reshape(B)
+                continue
+            part = self._stretch(item, beam, mb, cb)
+            parts.insert(0, part)
+            mb, cb = np.asarray(part.mu, dtype=np.float64).reshape(B, 7), np.asarray(part.cov, dtype=np.float64).reshape(B, 7, 7)
+        if not parts:
+            raise ValueError("track_vjp: the lattice has no element to differentiate")
+        return parts[0] if len(parts) == 1 else ChainedGradients(parts)
 
 
 def track_vjp(segment, beam):

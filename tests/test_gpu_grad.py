@@ -519,3 +519,85 @@ def test_config_5_gradients_at_the_full_shape(lx, monkeypatch):
 # over the wave at once, that column read 4e-06 .. 2e-05)
 TOL_C5_GRAD = {"length": (6e-5, 1.3e-4), "k1": (1.1e-4, 1.3e-4), "misalignment": (1.1e-4, 2e-4), "voltage": (5e-5, 1.8e-3),
                "phase": (4e-5, 4e-3), "frequency": (6e-5, 1.7e-2), "energy": (6e-6, 2e-4)}
+
+
+def _ares_with_active_bpms(ns, dtype, values, active=True):
+    """The README's ARES segment (BASELINE configs 1 and 2) with its second and last BPM switched on."""
+    a = lambda v: np.array([v], dtype=dtype)  # noqa: E731
+    bpm = (lambda on: ns.BPM(is_active=on)) if ns is not o else (lambda on: o.BPM(is_active=on))
+    return [bpm(False), ns.Drift(a(values["d1"])), bpm(active), ns.Drift(a(1.0)),
+            ns.VerticalCorrector(a(0.3), angle=a(values["v7"])), ns.Drift(a(0.2)),
+            ns.HorizontalCorrector(a(values["lh"]), angle=a(values["h10"])), ns.Drift(a(7.0)),
+            ns.HorizontalCorrector(a(0.3), angle=a(values["h12"])), ns.Drift(a(0.05)), bpm(active)]
+
+
+@pytest.mark.parametrize("beam_type", ["particles-fp64", "particles-fp32", "parameters-fp64"])
+def test_gradients_through_active_bpms(lx, beam_type):
+    """
+    BASELINE config 2's lattice with two ACTIVE BPMs (bpm.py:48-58: an active BPM is a step of `Segment.track` of its
+    own and records `stack([mu_x, mu_y])` of the beam that enters it).  The loss sees the outgoing beam's moments AND
+    both readings; its gradient w.r.t. corrector angles and lengths against central finite differences of the oracle
+    (float64), for a ParticleBeam -- the BPMs are observer steps inside the one streaming pass, the cotangent of a
+    reading is one more term of every particle's cotangent at that point of the reverse sweep -- and for a
+    ParameterBeam, where `track` cuts the lattice at the BPMs and the reverse pass is chained stretch by stretch.
+    """
+    dtype = np.float32 if beam_type.endswith("fp32") else np.float64
+    values = dict(d1=1.0, v7=3.142e-3, lh=0.3, h10=1e-4, h12=-1e-4)
+    rng = np.random.default_rng(5)
+    w_mu = rng.normal(size=(1, 6))
+    w_cov = np.zeros((1, 6, 6))
+    w_cov[0, :4, :4] = rng.normal(size=(4, 4)) * 1e3
+    r_a, r_b = rng.normal(size=(2, 1)), rng.normal(size=(2, 1))
+    N = 4000
+    P = o.gaussian_particles((1,), N, seed=21, dtype=np.float64, sigma=[1e-4, 2e-5, 1e-4, 2e-5, 1e-5, 1e-3],
+                             mu=[2e-4, 3e-5, -1e-4, 2e-5, 0.0, 0.0])
+    energy = np.array([1e8])
+    if beam_type.startswith("parameters"):
+        Q = P[0, :, :6]
+        mu0 = np.concatenate([Q.mean(axis=0), [1.0]])[None]
+        cov0 = np.zeros((1, 7, 7))
+        cov0[0, :6, :6] = np.cov(Q.T, bias=True)
+
+    def loss(v):
+        readings = []
+        specs = _ares_with_active_bpms(o, np.float64, v)
+        if beam_type.startswith("parameters"):
+            out = o.segment_track(specs, o.parameter_beam(mu0, cov0, energy, np.float64), np.float64, bpm_readings=readings)
+            mu, cov = out["mu"][..., :6], out["cov"][..., :6, :6]
+        else:
+            out = o.segment_track(specs, o.particle_beam(P, energy, np.float64), np.float64, bpm_readings=readings)
+            Q = out["particles"][..., :6]
+            mu = Q.mean(axis=-2)
+            d = Q - mu[..., None, :]
+            cov = np.einsum("...ni,...nj->...ij", d, d) / N
+        (_, ra), (_, rb) = readings  # in lattice order (the oracle finds an element's index by equality: both BPMs "at 2")
+        return float(np.sum(w_mu * mu) + np.sum(w_cov * cov) + np.sum(r_a * ra) + np.sum(r_b * rb))
+
+    elements = _ares_with_active_bpms(lx, dtype, values)
+    segment = lx.Segment(elements)
+    if beam_type.startswith("parameters"):
+        beam = lx.ParameterBeam(mu0, cov0, energy, dtype=dtype)
+    else:
+        beam = lx.ParticleBeam(P.astype(dtype), energy.astype(dtype), dtype=dtype)
+    vjp = lx.grad.track_vjp(segment, beam)
+    # the forward pass recorded the readings the loss is written in
+    readings = []
+    o.segment_track(_ares_with_active_bpms(o, np.float64, values), o.particle_beam(P, energy, np.float64), np.float64, bpm_readings=readings)
+    tol_read = 1e-4 if dtype == np.float32 else 1e-7
+    assert np.allclose(elements[2].reading, readings[0][1], rtol=tol_read, atol=1e-12)
+    assert np.allclose(elements[10].reading, readings[1][1], rtol=tol_read, atol=1e-12)
+    wc7 = np.zeros((1, 7, 7))
+    wc7[:, :6, :6] = w_cov
+    g = vjp(mu_bar=w_mu, cov_bar=wc7 if beam_type.startswith("parameters") else w_cov, readings={elements[2]: r_a, elements[10]: r_b})
+    rtol = 2e-3 if dtype == np.float32 else 2e-5
+    for key, index, name in (("d1", 1, "length"), ("v7", 4, "angle"), ("lh", 6, "length"), ("h10", 6, "angle"), ("h12", 8, "angle")):
+        h = 1e-5 * max(abs(values[key]), 1e-2)
+        ref = (loss({**values, key: values[key] + h}) - loss({**values, key: values[key] - h})) / (2 * h)
+        got = float(np.asarray(g[elements[index]][name]).reshape(-1)[0])
+        assert abs(got - ref) <= rtol * abs(ref) + 1e-9, (key, got, ref)
+    # without the readings' cotangents the gradient is a different one: the BPM terms did go in
+    plain = vjp(mu_bar=w_mu, cov_bar=wc7 if beam_type.startswith("parameters") else w_cov)
+    assert not np.isclose(float(np.asarray(plain[elements[1]]["length"]).reshape(-1)[0]),
+                          float(np.asarray(g[elements[1]]["length"]).reshape(-1)[0]), rtol=1e-3)
+    with pytest.raises(KeyError):
+        vjp(mu_bar=w_mu, readings={elements[0]: r_a})  # an inactive BPM reads nothing
