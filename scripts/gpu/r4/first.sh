@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 4, first GPU call: the whole GPU suite (new full-size parity tests included), then one bench line per workload.
-# Usage (from the repo root, on the GPU box): bash scripts/gpu/r4_first.sh <tag>
+# Usage (from the repo root, on the GPU box): bash scripts/gpu/r4/first.sh <tag>
 set -o pipefail
 TAG=${1:-r4a}
 OUT=gpurun_out/$TAG

@@ -1,5 +1,5 @@
 #!/bin/bash
-# the GPU suite only.  Usage: bash scripts/gpu/r4_tests.sh <tag> [pytest args]
+# the GPU suite only.  Usage: bash scripts/gpu/r4/tests.sh <tag> [pytest args]
 set -o pipefail
 TAG=${1:-r4t}; shift
 OUT=gpurun_out/$TAG

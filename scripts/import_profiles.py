@@ -13,7 +13,7 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 series = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r04"
 src = ROOT / "gpurun_out" / f"prof_r{int(rnd[1:])}_{series}"
 dst = ROOT / "profiles"
 copied = []
@@ -25,12 +25,12 @@ def put(path, name):
         copied.append(name)
 
 
-for w in ("c4", "c3", "c3big", "c5", "c2", "c5grad"):
+for w in ("c4", "c4a", "c3", "c3big", "c5", "c2", "c5grad"):
     stats = sorted(glob.glob(str(src / f"trace_{w}" / "*" / "*kernel_stats.csv")))
     if stats:
         put(stats[-1], f"{w}_kernel_stats.csv")
     put(src / f"trace_{w}.json", f"{w}_bench_under_rocprof.json")
-for w in ("c4", "c3big"):
+for w in ("c4", "c4a", "c3big"):
     put(src / f"{w}_pmc_traffic.json", f"{w}_pmc_traffic.json")
 put(src / "default.json", "c4_bench_default.json")
 put(src / "rccl_world1.json", "c4_bench_rccl_world1.json")
@@ -48,4 +48,9 @@ put(src / "c5_default.json", "c5_bench_default.json")
 put(src / "c5grad.json", "c5grad_bench.json")
 put(src / "steady_c3big.json", "c3big_bench_steady.json")
 put(src / "pmc_c5" / "c5_pmc_sq.json", "c5_pmc_sq.json")
+# round 4: the corrector-angle variant of config 4, the reverse pass's counters, the dense reverse pass, kernel timelines
+put(src / "c4a_default.json", "c4a_bench_default.json")
+put(src / "pmc_c5" / "c5grad_pmc_sq.json", "c5grad_pmc_sq.json")
+put(src / "c5grad_dense.json", "c5grad_bench_dense_reverse.json")
+put(src / "timeline.txt", "small_configs_kernel_timeline.txt")
 print(f"{len(copied)} files -> profiles/{rnd}_{series}_*:", ", ".join(copied))
