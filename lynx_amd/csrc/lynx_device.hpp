@@ -160,6 +160,7 @@ __device__ void build_compose_sample(const LatticeDev& lat, int64_t b, T energy_
   // where the builders write: straight into bufA for float64, into the staging area for float32
   T* built = sizeof(T) == 8 ? reinterpret_cast<T*>(bufA) : reinterpret_cast<T*>(tmp + 49);
   const int per_round = blockDim.x / 7;  // products per round, 7 row-lanes each
+  const int per_round49 = blockDim.x / 49;  // ... or 49 entry-lanes each
   const int my_prod = tid / 7, my_row = tid - my_prod * 7;
   const int waves = blockDim.x >> 6;
 
@@ -217,9 +218,17 @@ __device__ void build_compose_sample(const LatticeDev& lat, int64_t b, T energy_
       while (count > 1) {
         double* dst = (level & 1) ? bufC : bufB;
         const int half = count >> 1;
-        if (my_prod < per_round)
+        // Few products in the level: one lane per ENTRY (seven multiply-adds behind fourteen LDS reads, ~0.15 us) -- the
+        // row form (one lane per output row: 56 reads and 49 multiply-adds in a lane, ~0.8 us whatever the count) pays
+        // only when there are enough products to fill the workgroup with rows.  Same multiply-adds in the same order.
+        if (half <= 2 * per_round49) {
+          if (tid < per_round49 * 49)
+            for (int pr = tid / 49; pr < half; pr += per_round49)
+              dst[pr * 49 + tid % 49] = mat_product_entry<double>(src + (2 * pr + 1) * 49, src + (2 * pr) * 49, tid % 49);
+        } else if (my_prod < per_round) {
           for (int pr = my_prod; pr < half; pr += per_round)
             mat_product_row(src + (2 * pr + 1) * 49, src + (2 * pr) * 49, dst + pr * 49, my_row);
+        }
         if ((count & 1) && tid >= blockDim.x - 49) {
           const int q = tid - (blockDim.x - 49);
           dst[half * 49 + q] = src[(count - 1) * 49 + q];
@@ -237,7 +246,7 @@ __device__ void build_compose_sample(const LatticeDev& lat, int64_t b, T energy_
           if (tid < 49) carry[tid] = (tid % 8 == 0) ? 1.0 : 0.0;
           __syncthreads();
         }
-        if (tid < 7) mat_product_row(src, carry, tmp, tid);
+        if (tid < 49) tmp[tid] = mat_product_entry<double>(src, carry, tid);
         __syncthreads();
         if (tid < 49) carry[tid] = tmp[tid];
       }
