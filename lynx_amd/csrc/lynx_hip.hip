@@ -94,6 +94,10 @@ struct lynx_ctx {
   bool streamed_valid[kTableSlots] = {};
   unsigned seq = 0;
   bool main_dirty = false;            // unsynchronised device writes on the main stream (any buffer)
+  // Nothing enqueued on the main stream since the host last waited for it.  Kept by the library itself (set by
+  // sync_main, cleared by every entry point that enqueues): asking the runtime -- hipStreamQuery -- puts a marker
+  // packet into the queue whose release costs the next kernel ~5 us behind a kernel that left dirty lines in L2.
+  bool main_idle = true;
   const void* main_wrote = nullptr;   // energy buffer the last streaming kernel published on the main stream
   std::mutex mu;                      // allocator maps: finalizers may run on other threads
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
@@ -247,6 +251,12 @@ static hipError_t use_device(lynx_ctx* ctx) {
   return hipSetDevice(ctx->device);
 }
 
+static hipError_t sync_main(lynx_ctx* ctx) {
+  const hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) ctx->main_idle = true;
+  return e;
+}
+
 static size_t dtype_size(int dtype) { return dtype == LYNX_F64 ? 8 : 4; }
 
 static size_t size_class(size_t bytes) {
@@ -335,7 +345,7 @@ static int ensure_scratch(lynx_ctx* ctx, void** buf, size_t* have, size_t need) 
   if (*have >= need) return LYNX_OK;
   if (*buf) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->s_build));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, sync_main(ctx));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->s_side));
     HIP_TRY(ctx, hipFree(*buf));
     *buf = nullptr;
@@ -428,7 +438,7 @@ int lynx_ctx_destroy(lynx_ctx* ctx) {
   if (!ctx) return LYNX_OK;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->s_build);
-  (void)hipStreamSynchronize(ctx->stream);
+  (void)sync_main(ctx);
   (void)hipStreamSynchronize(ctx->s_side);
   if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
   {
@@ -559,12 +569,13 @@ static int join_side(lynx_ctx* ctx) {
 
 int lynx_sync(lynx_ctx* ctx) {
   HIP_TRY(ctx, use_device(ctx));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, sync_main(ctx));
   const int rc = wait_for_side(ctx);
   return rc ? rc : check_status(ctx);
 }
 
 int lynx_timer_start(lynx_ctx* ctx) {
+  ctx->main_idle = false;  // (something is about to be enqueued on the main stream)
   HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
   return LYNX_OK;
 }
@@ -572,6 +583,7 @@ int lynx_timer_start(lynx_ctx* ctx) {
 int lynx_timer_stop(lynx_ctx* ctx, float* elapsed_ms) {
   HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
   HIP_TRY(ctx, hipEventSynchronize(ctx->ev_stop));
+  ctx->main_idle = true;
   HIP_TRY(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev_start, ctx->ev_stop));
   return LYNX_OK;
 }
@@ -581,7 +593,7 @@ int lynx_profile_begin(lynx_ctx* ctx) {
   // wait on them once they are destroyed
   if (!ctx->prof_events.empty()) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->s_build));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, sync_main(ctx));
     for (bool& v : ctx->streamed_valid) v = false;
     ctx->last_stream_stop = nullptr;
   }
@@ -601,7 +613,7 @@ int lynx_profile_begin(lynx_ctx* ctx) {
 
 int lynx_profile_end(lynx_ctx* ctx, double* total_ms, int64_t* launches) {
   ctx->profiling = false;
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, sync_main(ctx));
   // every build is followed by its streaming kernel on the main stream, so both streams are idle now;
   // the per-launch stop events stood in for the step-table slots' "streamed" events and go away here
   for (bool& v : ctx->streamed_valid) v = false;
@@ -666,7 +678,7 @@ int lynx_buf_free(lynx_ctx* ctx, void* d_ptr) { return ctx_free(ctx, d_ptr); }
 int lynx_buf_h2d(lynx_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
   if (bytes == 0) return LYNX_OK;
   HIP_TRY(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // h_src is pageable and may be freed
+  HIP_TRY(ctx, sync_main(ctx));  // h_src is pageable and may be freed
   return LYNX_OK;
 }
 
@@ -677,11 +689,12 @@ int lynx_buf_d2h(lynx_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
     if (rc) return rc;
   }
   HIP_TRY(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, sync_main(ctx));
   return check_status(ctx);  // what came back may be the result of a program that met a cavity with energy <= 0
 }
 
 int lynx_buf_d2d(lynx_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) {
+  ctx->main_idle = false;  // (something is about to be enqueued on the main stream)
   if (bytes == 0) return LYNX_OK;
   {
     const int rc = join_side(ctx);  // the source may be a moment record the side stream is still reducing
@@ -693,6 +706,7 @@ int lynx_buf_d2d(lynx_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) {
 }
 
 int lynx_buf_memset(lynx_ctx* ctx, void* d_dst, int value, size_t bytes) {
+  ctx->main_idle = false;  // (something is about to be enqueued on the main stream)
   if (bytes == 0) return LYNX_OK;
   {
     const int rc = join_side(ctx);
@@ -705,7 +719,7 @@ int lynx_buf_memset(lynx_ctx* ctx, void* d_dst, int value, size_t bytes) {
 
 int lynx_pool_trim(lynx_ctx* ctx) {
   HIP_TRY(ctx, hipStreamSynchronize(ctx->s_build));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, sync_main(ctx));
   {
     const int rc = wait_for_side(ctx);
     if (rc) return rc;
@@ -830,9 +844,9 @@ int lynx_lattice_create(lynx_ctx* ctx, int dtype, int64_t batch, int32_t n_elems
       return rc;
     }
     HIP_TRY(ctx, hipMemcpyAsync(lat->d_cavs, cavs.data(), cavs.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // `cavs` goes out of scope
+    HIP_TRY(ctx, sync_main(ctx));  // `cavs` goes out of scope
   }
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, sync_main(ctx));
   *out = lat;
   return LYNX_OK;
 }
@@ -843,7 +857,7 @@ int lynx_lattice_update_params(lynx_lattice* lat, int64_t offset, int64_t count,
     return fail(ctx, LYNX_ERR_INVALID, "lynx_lattice_update_params: range outside the pool");
   const size_t es = dtype_size(lat->dtype);
   HIP_TRY(ctx, hipMemcpyAsync((char*)lat->d_pool + offset * es, host, count * es, hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, sync_main(ctx));
   return LYNX_OK;
 }
 
@@ -858,7 +872,7 @@ int lynx_lattice_set_flags(lynx_lattice* lat, const int32_t* elem_flags, const i
   }
   HIP_TRY(ctx, hipMemcpyAsync(lat->d_elems, lat->h_elems.data(), lat->n_elems * sizeof(lynx_elem), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(lat->d_steps, lat->h_steps.data(), lat->n_steps * sizeof(lynx_step), hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, sync_main(ctx));
   return LYNX_OK;
 }
 
@@ -1083,6 +1097,7 @@ static int launch_build(lynx_ctx* ctx, lynx_lattice* lat, hipStream_t stream, co
 
 int lynx_build_compose(lynx_ctx* ctx, lynx_lattice* lat, const void* d_energy_in, void* d_steps_out,
                        void* d_energy_out) {
+  ctx->main_idle = false;  // (something is about to be enqueued on the main stream)
   if (!ctx || !lat || !d_energy_in || !d_steps_out) return fail(ctx, LYNX_ERR_INVALID, "null argument");
   if (lat->batch > 0x7fffffffLL) return fail(ctx, LYNX_ERR_INVALID, "batch too large");
   HIP_TRY(ctx, use_device(ctx));
@@ -1104,9 +1119,6 @@ struct TrackPlan {
   unsigned grid;
 };
 
-// Tuning knobs (environment, read per call; defaults are the measured best):
-//   LYNX_XPOSE=0|1   LYNX_UNROLL=1|2|4   LYNX_MOM=1|2|3   LYNX_MIN_TILES_PER_WG=<n>
-//   LYNX_WGS_PER_CU=<n>      workgroups per CU over the whole launch
 template <typename T>
 static TrackPlan plan_track(lynx_ctx* ctx, const lynx_lattice* lat, int64_t B, int64_t N, int32_t S, bool fused,
                             bool moments, bool full_cov) {
@@ -1301,7 +1313,7 @@ static int ensure_units_plan(lynx_ctx* ctx, lynx_lattice* lat, bool merged) {
   if (!lat->d_step_unit[m] && (rc = ctx_alloc(ctx, code.size() * sizeof(int32_t), (void**)&lat->d_step_unit[m]))) return rc;
   // rare (new lattice, or its flags changed): nothing may still be reading the old table
   HIP_TRY(ctx, hipStreamSynchronize(ctx->s_build));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, sync_main(ctx));
   HIP_TRY(ctx, hipMemcpy(lat->d_step_unit[m], code.data(), code.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   return LYNX_OK;
 }
@@ -1403,8 +1415,7 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
     short_call = half_million && (size_t)B * N * 7 * sizeof(T) < ((size_t)128 << 20) && !lat->has_cavity;
     bool inline_all = false;
     if (short_call && ctx->knobs.async_build < 0)
-      inline_all = knob(ctx->knobs.small_inline, hipStreamQuery(ctx->stream) == hipSuccess ? 1 : 0) != 0;
-    (void)hipGetLastError();  // hipErrorNotReady of the query is an answer, not an error
+      inline_all = knob(ctx->knobs.small_inline, ctx->main_idle ? 1 : 0) != 0;
     const bool async = knob(ctx->knobs.async_build, half_million && !inline_all ? 1 : 0) != 0;
     async_build = async;
     hipStream_t bs = async ? ctx->s_build : ctx->stream;
@@ -1616,11 +1627,13 @@ int lynx_track_particles(lynx_ctx* ctx, lynx_lattice* lat, int64_t n_particles, 
     return fail(ctx, LYNX_ERR_INVALID, "a shared incoming beam cannot be tracked in place");
   HIP_TRY(ctx, use_device(ctx));
   LatticeDev lv = dev_view(lat);
-  return lat->dtype == LYNX_F64
-             ? track_particles_t<double>(ctx, lat, lv, lat->batch, n_particles, d_energy_in, d_p_in, d_p_out,
-                                         d_energy_out, d_moments_out, flags, d_observations)
-             : track_particles_t<float>(ctx, lat, lv, lat->batch, n_particles, d_energy_in, d_p_in, d_p_out,
-                                        d_energy_out, d_moments_out, flags, d_observations);
+  const int rc = lat->dtype == LYNX_F64
+                     ? track_particles_t<double>(ctx, lat, lv, lat->batch, n_particles, d_energy_in, d_p_in, d_p_out,
+                                                 d_energy_out, d_moments_out, flags, d_observations)
+                     : track_particles_t<float>(ctx, lat, lv, lat->batch, n_particles, d_energy_in, d_p_in, d_p_out,
+                                                d_energy_out, d_moments_out, flags, d_observations);
+  ctx->main_idle = false;  // (whatever allocation inside may have waited for the stream: work follows it now)
+  return rc;
 }
 
 int lynx_track_particles_new(lynx_ctx* ctx, lynx_lattice* lat, int64_t n_particles, const void* d_energy_in,
@@ -1639,7 +1652,7 @@ int lynx_track_particles_new(lynx_ctx* ctx, lynx_lattice* lat, int64_t n_particl
                               (double*)d_out[3]);
   if (rc) {  // nothing was enqueued on these blocks (every check of lynx_track_particles comes before its first launch ...
     const std::string why = ctx->err;
-    (void)hipStreamSynchronize(ctx->stream);  // ... but a failure halfway through a launch sequence may have: drain first)
+    (void)sync_main(ctx);  // ... but a failure halfway through a launch sequence may have: drain first)
     for (int k = 0; k < 4; ++k) {
       if (d_out[k]) (void)ctx_free(ctx, d_out[k]);
       d_out[k] = nullptr;
@@ -1810,6 +1823,7 @@ int lynx_track_particles_backward(lynx_ctx* ctx, lynx_lattice* lat, int64_t n_pa
                                   const void* d_p_in, const double* d_moments_fwd, const double* d_grad_moments,
                                   void* d_grad_params, void* d_grad_energy_in, void* d_grad_p_in,
                                   const double* d_grad_observations) {
+  ctx->main_idle = false;  // (something is about to be enqueued on the main stream)
   if (!ctx || !lat || !d_energy_in || !d_p_in || !d_moments_fwd || !d_grad_moments || !d_grad_params || !d_grad_energy_in)
     return fail(ctx, LYNX_ERR_INVALID, "null argument");
   if (n_particles <= 0 || lat->n_steps <= 0) return fail(ctx, LYNX_ERR_INVALID, "empty program or beam");
@@ -1873,6 +1887,7 @@ int lynx_track_moments_backward(lynx_ctx* ctx, lynx_lattice* lat, const void* d_
                                 const void* d_cov_in, const void* d_mu_bar, const void* d_cov_bar,
                                 void* d_grad_params, void* d_grad_energy_in, void* d_grad_mu_in,
                                 void* d_grad_cov_in) {
+  ctx->main_idle = false;  // (something is about to be enqueued on the main stream)
   if (!ctx || !lat || !d_energy_in || !d_mu_in || !d_cov_in || !d_mu_bar || !d_cov_bar || !d_grad_params ||
       !d_grad_energy_in || !d_grad_mu_in || !d_grad_cov_in)
     return fail(ctx, LYNX_ERR_INVALID, "null argument");
@@ -1888,6 +1903,7 @@ int lynx_track_moments_backward(lynx_ctx* ctx, lynx_lattice* lat, const void* d_
 
 int lynx_moments(lynx_ctx* ctx, int dtype, int64_t batch, int64_t n_particles, const void* d_p,
                  double* d_moments_out, int32_t covariance) {
+  ctx->main_idle = false;  // (something is about to be enqueued on the main stream)
   if (!ctx || !d_p || !d_moments_out) return fail(ctx, LYNX_ERR_INVALID, "null argument");
   if (batch <= 0 || n_particles <= 0) return fail(ctx, LYNX_ERR_INVALID, "bad shape");
   HIP_TRY(ctx, use_device(ctx));
@@ -1939,6 +1955,7 @@ static int launch_track_moments(lynx_ctx* ctx, lynx_lattice* lat, const void* d_
 
 int lynx_track_moments(lynx_ctx* ctx, lynx_lattice* lat, const void* d_energy_in, const void* d_mu_in,
                        const void* d_cov_in, void* d_mu_out, void* d_cov_out, void* d_energy_out) {
+  ctx->main_idle = false;  // (something is about to be enqueued on the main stream)
   if (!ctx || !lat || !d_energy_in || !d_mu_in || !d_cov_in || !d_mu_out || !d_cov_out)
     return fail(ctx, LYNX_ERR_INVALID, "null argument");
   if (lat->batch > 0x7fffffffLL) return fail(ctx, LYNX_ERR_INVALID, "batch too large");
@@ -1953,6 +1970,7 @@ int lynx_track_moments(lynx_ctx* ctx, lynx_lattice* lat, const void* d_energy_in
 
 int lynx_histogram2d(lynx_ctx* ctx, int dtype, int64_t batch, int64_t n_particles, const void* d_p,
                      const void* d_xedges, const void* d_yedges, int32_t nx, int32_t ny, int32_t* d_image) {
+  ctx->main_idle = false;  // (something is about to be enqueued on the main stream)
   if (!ctx || !d_p || !d_xedges || !d_yedges || !d_image || batch <= 0 || n_particles <= 0 || nx <= 0 || ny <= 0)
     return fail(ctx, LYNX_ERR_INVALID, "bad argument");
   HIP_TRY(ctx, use_device(ctx));
@@ -1976,6 +1994,7 @@ int lynx_histogram2d(lynx_ctx* ctx, int dtype, int64_t batch, int64_t n_particle
 }
 
 int lynx_diag_phase_trig(lynx_ctx* ctx, int64_t n, const float* d_x, int32_t packed, float* d_sin, float* d_cos) {
+  ctx->main_idle = false;  // (something is about to be enqueued on the main stream)
   if (!ctx || !d_x || !d_sin || !d_cos || n <= 0) return fail(ctx, LYNX_ERR_INVALID, "bad argument");
   HIP_TRY(ctx, use_device(ctx));
   const int64_t threads = (n + 1) / 2;
@@ -1990,6 +2009,7 @@ int lynx_diag_phase_trig(lynx_ctx* ctx, int64_t n, const float* d_x, int32_t pac
 int lynx_aperture_mask(lynx_ctx* ctx, int dtype, int64_t batch, int64_t n_particles, const void* d_p,
                        const void* d_x_max, const void* d_y_max, int32_t param_stride, int32_t elliptical,
                        unsigned char* d_mask, int32_t* d_counts, int64_t* d_offsets, int64_t* d_totals) {
+  ctx->main_idle = false;  // (something is about to be enqueued on the main stream)
   if (!ctx || !d_p || !d_x_max || !d_y_max || !d_mask || !d_counts || !d_offsets || !d_totals || batch <= 0 ||
       n_particles <= 0 || (param_stride != 0 && param_stride != 1))
     return fail(ctx, LYNX_ERR_INVALID, "bad argument");
@@ -2013,6 +2033,7 @@ int lynx_aperture_mask(lynx_ctx* ctx, int dtype, int64_t batch, int64_t n_partic
 
 int lynx_aperture_compact(lynx_ctx* ctx, int dtype, int64_t n_particles, const void* d_p, const unsigned char* d_mask,
                           const int64_t* d_offsets, void* d_kept, void* d_lost) {
+  ctx->main_idle = false;  // (something is about to be enqueued on the main stream)
   if (!ctx || !d_p || !d_mask || !d_offsets || !d_kept || !d_lost || n_particles <= 0)
     return fail(ctx, LYNX_ERR_INVALID, "bad argument");
   HIP_TRY(ctx, use_device(ctx));
@@ -2029,6 +2050,7 @@ int lynx_aperture_compact(lynx_ctx* ctx, int dtype, int64_t n_particles, const v
 
 int lynx_gaussian_image(lynx_ctx* ctx, int dtype, int64_t batch, const void* d_mu, const void* d_cov,
                         const void* d_xs, const void* d_ys, int32_t nx, int32_t ny, void* d_image) {
+  ctx->main_idle = false;  // (something is about to be enqueued on the main stream)
   if (!ctx || !d_mu || !d_cov || !d_xs || !d_ys || !d_image || batch <= 0 || nx <= 0 || ny <= 0 || batch > 65535)
     return fail(ctx, LYNX_ERR_INVALID, "bad argument");
   HIP_TRY(ctx, use_device(ctx));
@@ -2049,6 +2071,7 @@ int lynx_gaussian_image(lynx_ctx* ctx, int dtype, int64_t batch, const void* d_m
 
 int lynx_fill_gaussian(lynx_ctx* ctx, int dtype, int64_t batch, int64_t n_particles, const double* mu,
                        const double* sigma, uint64_t seed, void* d_p) {
+  ctx->main_idle = false;  // (something is about to be enqueued on the main stream)
   if (!ctx || !d_p || !mu || !sigma || batch <= 0 || n_particles <= 0)
     return fail(ctx, LYNX_ERR_INVALID, "bad argument");
   HIP_TRY(ctx, use_device(ctx));
@@ -2071,6 +2094,7 @@ int lynx_fill_gaussian(lynx_ctx* ctx, int dtype, int64_t batch, int64_t n_partic
 
 int lynx_diag_copy(lynx_ctx* ctx, void* d_dst, const void* d_src, size_t bytes, int repeats, int vec_per_thread,
                    float* avg_ms) {
+  ctx->main_idle = false;  // (something is about to be enqueued on the main stream)
   const int per_thread = vec_per_thread >= 100 ? vec_per_thread - 100 : vec_per_thread;  // >= 100: non-temporal stores
   if (!ctx || !d_dst || !d_src || bytes % 16 || repeats <= 0 || vec_per_thread < 0 || per_thread > 64 ||
       (vec_per_thread >= 100 && per_thread == 0))
@@ -2118,7 +2142,7 @@ int lynx_comm_init(lynx_ctx* ctx, int n_ranks, int rank, const char* id) {
 
 int lynx_comm_destroy(lynx_ctx* ctx) {
   if (ctx && ctx->comm) {
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, sync_main(ctx));
     int rc = wait_for_side(ctx);
     if (rc) return rc;
     NCCL_TRY(ctx, ncclCommDestroy(ctx->comm));
@@ -2146,6 +2170,7 @@ int lynx_comm_info(lynx_ctx* ctx, int32_t* rccl_version, int32_t* n_ranks, int32
 }
 
 int lynx_gather_moments(lynx_ctx* ctx, const double* d_send, double* d_recv, int64_t count) {
+  ctx->main_idle = false;  // (something is about to be enqueued on the main stream)
   if (!ctx || !ctx->comm) return fail(ctx, LYNX_ERR_INVALID, "communicator not initialised");
   HIP_TRY(ctx, use_device(ctx));
   // Default with more than one rank: the side stream.  With one rank (LYNX_FORCE_COMM rehearsals) the "gather" is
