@@ -251,6 +251,16 @@ static hipError_t use_device(lynx_ctx* ctx) {
   return hipSetDevice(ctx->device);
 }
 
+// Events between the context's own streams, and the time stamps around a profiled launch, are recorded WITHOUT the
+// system-scope fence HIP puts behind an event by default: that fence writes back and invalidates for the benefit of
+// the host and of other devices, which nothing that waits on these events needs -- a kernel's own end-of-kernel release
+// is what makes its results visible to the other queues of this device, host read-backs go through a copy and a stream
+// synchronisation of their own, and RCCL fences what it sends.  Same box, alternating (scripts/gpu/r4/evscope.sh):
+// BASELINE config 3 49.7-50.7 -> 47.0 us/step, the 128-sample shard of config 4 139.8-140.8 -> 135.8-136.2, config 3
+// at 8 M particles 170.8-174.8 -> 168.5; hipEventReleaseToDevice instead: no change.
+static unsigned sync_event_flags() { return hipEventDisableTiming | hipEventDisableSystemFence; }
+static unsigned timing_event_flags() { return hipEventDefault | hipEventDisableSystemFence; }
+
 static hipError_t sync_main(lynx_ctx* ctx) {
   const hipError_t e = hipStreamSynchronize(ctx->stream);
   if (e == hipSuccess) ctx->main_idle = true;
@@ -404,17 +414,17 @@ int lynx_ctx_create(int device, lynx_ctx** out) {
     HIP_TRY(nullptr, hipStreamCreateWithPriority(&ctx->s_build, hipStreamNonBlocking, prio_high));
     HIP_TRY(nullptr, hipStreamCreateWithPriority(&ctx->s_side, hipStreamNonBlocking, prio_high));
   }
-  HIP_TRY(nullptr, hipEventCreateWithFlags(&ctx->ev_side_in, hipEventDisableTiming));
-  HIP_TRY(nullptr, hipEventCreateWithFlags(&ctx->ev_main_mark, hipEventDisableTiming));
+  HIP_TRY(nullptr, hipEventCreateWithFlags(&ctx->ev_side_in, sync_event_flags()));
+  HIP_TRY(nullptr, hipEventCreateWithFlags(&ctx->ev_main_mark, sync_event_flags()));
   for (auto& slot : ctx->partial_ring) {
-    HIP_TRY(nullptr, hipEventCreateWithFlags(&slot.track_done, hipEventDisableTiming));
-    HIP_TRY(nullptr, hipEventCreateWithFlags(&slot.reduced, hipEventDisableTiming));
+    HIP_TRY(nullptr, hipEventCreateWithFlags(&slot.track_done, sync_event_flags()));
+    HIP_TRY(nullptr, hipEventCreateWithFlags(&slot.reduced, sync_event_flags()));
   }
   for (int i = 0; i < lynx_ctx::kTableSlots; ++i) {
-    HIP_TRY(nullptr, hipEventCreateWithFlags(&ctx->ev_built[i], hipEventDisableTiming));
-    HIP_TRY(nullptr, hipEventCreateWithFlags(&ctx->ev_streamed_own[i], hipEventDisableTiming));
+    HIP_TRY(nullptr, hipEventCreateWithFlags(&ctx->ev_built[i], sync_event_flags()));
+    HIP_TRY(nullptr, hipEventCreateWithFlags(&ctx->ev_streamed_own[i], sync_event_flags()));
   }
-  HIP_TRY(nullptr, hipEventCreateWithFlags(&ctx->ev_mark, hipEventDisableTiming));
+  HIP_TRY(nullptr, hipEventCreateWithFlags(&ctx->ev_mark, sync_event_flags()));
   HIP_TRY(nullptr, hipEventCreate(&ctx->ev_start));
   HIP_TRY(nullptr, hipEventCreate(&ctx->ev_stop));
   HIP_TRY(nullptr, hipHostMalloc((void**)&ctx->h_status, 2 * sizeof(int32_t), hipHostMallocMapped));
@@ -533,7 +543,7 @@ static int side_event(lynx_ctx* ctx, hipEvent_t* out) {
       ctx->side_events.pop_back();
     }
   }
-  if (!*out) HIP_TRY(ctx, hipEventCreateWithFlags(out, hipEventDisableTiming));
+  if (!*out) HIP_TRY(ctx, hipEventCreateWithFlags(out, sync_event_flags()));
   return LYNX_OK;
 }
 
@@ -1201,8 +1211,8 @@ static int launch_direct_inst(lynx_ctx* ctx, const TrackPlan& p, const LatticeDe
   // kernel's duration.
   hipEvent_t e0 = nullptr, e1 = p.done;
   if (ctx->profiling) {  // every profiled launch needs time stamps of its own
-    HIP_TRY(ctx, hipEventCreate(&e0));
-    HIP_TRY(ctx, hipEventCreate(&e1));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&e0, timing_event_flags()));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&e1, timing_event_flags()));
   }
   hipExtLaunchKernelGGL((k_track_direct<T, MOM, FULL, UNROLL, FUSED, XPOSE>), dim3(p.grid), dim3(kTrackThreads),
                         (std::uint32_t)p.lds, ctx->stream, e0, e1, 0u, lv, p.a, (const T*)d_energy_in, (const T*)d_p_in,
@@ -1327,8 +1337,8 @@ static int launch_units_inst(lynx_ctx* ctx, const TrackPlan& p, int32_t U, int32
   if (rc) return rc;
   hipEvent_t e0 = nullptr, e1 = p.done;
   if (ctx->profiling) {  // every profiled launch needs time stamps of its own
-    HIP_TRY(ctx, hipEventCreate(&e0));
-    HIP_TRY(ctx, hipEventCreate(&e1));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&e0, timing_event_flags()));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&e1, timing_event_flags()));
   }
   hipExtLaunchKernelGGL((k_track_units<MOM, FULL, PAIRS>), dim3(p.grid), dim3(kTrackThreads), (std::uint32_t)lds, ctx->stream, e0, e1,
                         0u, p.a, U, S, (const float*)d_p_in, (float*)d_p_out, (float*)d_energy_out, (const float*)d_steps,
@@ -2181,8 +2191,8 @@ int lynx_gather_moments(lynx_ctx* ctx, const double* d_send, double* d_recv, int
     if (rc) return rc;
     hipEvent_t g0 = nullptr, g1 = nullptr;
     if (ctx->profiling) {
-      HIP_TRY(ctx, hipEventCreate(&g0));
-      HIP_TRY(ctx, hipEventCreate(&g1));
+      HIP_TRY(ctx, hipEventCreateWithFlags(&g0, timing_event_flags()));
+      HIP_TRY(ctx, hipEventCreateWithFlags(&g1, timing_event_flags()));
       HIP_TRY(ctx, hipEventRecord(g0, ctx->stream));
     }
     NCCL_TRY(ctx, ncclAllGather(d_send, d_recv, (size_t)count, ncclDouble, ctx->comm, ctx->stream));
@@ -2210,8 +2220,8 @@ int lynx_gather_moments(lynx_ctx* ctx, const double* d_send, double* d_recv, int
   if (rc) return rc;
   hipEvent_t g0 = nullptr, g1 = nullptr;
   if (ctx->profiling) {  // the gather's own duration on its stream (bench.py at N > 1: how long a rank waits for the others)
-    HIP_TRY(ctx, hipEventCreate(&g0));
-    HIP_TRY(ctx, hipEventCreate(&g1));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&g0, timing_event_flags()));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&g1, timing_event_flags()));
     HIP_TRY(ctx, hipEventRecord(g0, ctx->s_side));
   }
   NCCL_TRY(ctx, ncclAllGather(d_send, d_recv, (size_t)count, ncclDouble, ctx->comm, ctx->s_side));
