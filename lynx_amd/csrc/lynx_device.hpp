@@ -44,6 +44,26 @@ struct LatticeDev {
   int32_t n_steps;
 };
 
+// The parameter pool of a SMALL lattice inside the kernel arguments: a parameter write (`quad.k1 = ...` between two
+// `track` calls -- the optimisation loop) then is a memcpy on the host instead of a copy to HBM the stream has to be
+// waited for (BASELINE config 2 with a setting changed before every call: 38.6 -> 23.8 us per call), and the pool in
+// HBM follows when a kernel that reads it from there is next launched (lynx_hip.hip: sync_pool).
+// Two sizes, because argument bytes cost latency: with the tables in there as well (3.5 KB) a call that is waited for
+// took 4 us longer, and nothing was gained on the build's chain of dependent accesses (NOTES.md).
+// The pool is the kernel's FIRST parameter and is read where it lies, at offset 0 of the kernel-argument segment:
+// naming the parameter makes the compiler copy all of it into every lane's scratch as soon as a pointer into it
+// reaches a function that is not inlined.
+template <int BYTES>
+struct InlinePool {
+  uint4 q[BYTES / 16];
+};
+constexpr int kInlinePoolSmall = 256, kInlinePoolLarge = 1024;
+__device__ __forceinline__ LatticeDev inline_pool_view(const LatticeDev& lat) {
+  LatticeDev v = lat;
+  v.pool = (const void*)__builtin_amdgcn_kernarg_segment_ptr();
+  return v;
+}
+
 // a run directly in front of an active cavity can be applied together with it -- unless it is an
 // observer (its step must stay visible to the streaming kernel)
 __device__ __forceinline__ bool steps_pair_up(const lynx_step& run, const lynx_step& cav) {
@@ -1022,9 +1042,9 @@ __device__ __forceinline__ void merged_pair_entry(const float* pre /*14*/, const
 // kernel to publish; `energy_out` is only used by the synchronous lynx_build_compose entry.
 // ---------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void k_build(LatticeDev lat, const T* __restrict__ energy_in,
-                                                T* __restrict__ steps_out, T* __restrict__ energy_out,
-                                                int chunk, int merge_pairs) {
+__device__ __forceinline__ void build_to_table(const LatticeDev& lat, const T* __restrict__ energy_in,
+                                               T* __restrict__ steps_out, T* __restrict__ energy_out,
+                                               int chunk, int merge_pairs) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* s_steps = reinterpret_cast<T*>(smem_raw + build_scratch_bytes(chunk, sizeof(T)));
   T* s_energy = s_steps + (size_t)lat.n_steps * LYNX_STEP_STRIDE;
@@ -1073,6 +1093,21 @@ __global__ __launch_bounds__(256) void k_build(LatticeDev lat, const T* __restri
   T* dst = steps_out + b * (int64_t)lat.n_steps * LYNX_STEP_STRIDE;
   for (int i = threadIdx.x; i < lat.n_steps * LYNX_STEP_STRIDE; i += blockDim.x) dst[i] = s_steps[i];
   if (energy_out && threadIdx.x == 0) energy_out[b] = s_energy[lat.n_steps];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_build(LatticeDev lat, const T* __restrict__ energy_in,
+                                                T* __restrict__ steps_out, T* __restrict__ energy_out,
+                                                int chunk, int merge_pairs) {
+  build_to_table<T>(lat, energy_in, steps_out, energy_out, chunk, merge_pairs);
+}
+
+// ... of a small lattice, whose parameters come with the arguments (InlinePool)
+template <typename T, int BYTES>
+__global__ __launch_bounds__(256) void k_build_inline(InlinePool<BYTES> /* read in place: inline_pool_view */, LatticeDev lat,
+                                                       const T* __restrict__ energy_in, T* __restrict__ steps_out,
+                                                       T* __restrict__ energy_out, int chunk, int merge_pairs) {
+  build_to_table<T>(inline_pool_view(lat), energy_in, steps_out, energy_out, chunk, merge_pairs);
 }
 
 
@@ -2100,9 +2135,9 @@ __global__ __launch_bounds__(64) void k_reduce_observers(const double* __restric
 // parallelises over elements.  The moment propagation itself uses 49 lanes.
 // ---------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void k_track_moments(LatticeDev lat, const T* __restrict__ energy_in,
-                                                        const T* mu_in, const T* cov_in, T* mu_out,
-                                                        T* cov_out, T* __restrict__ energy_out, int chunk) {
+__device__ __forceinline__ void track_moments_sample(const LatticeDev& lat, const T* __restrict__ energy_in,
+                                                     const T* mu_in, const T* cov_in, T* mu_out,
+                                                     T* cov_out, T* __restrict__ energy_out, int chunk) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* s_steps = reinterpret_cast<T*>(smem_raw + build_scratch_bytes(chunk, sizeof(T)));
   T* s_energy = s_steps + (size_t)lat.n_steps * LYNX_STEP_STRIDE;
@@ -2170,6 +2205,22 @@ __global__ __launch_bounds__(256) void k_track_moments(LatticeDev lat, const T* 
   if (lane < 7) mu_out[b * 7 + lane] = s_mu[lane];
   if (lane < 49) cov_out[b * 49 + lane] = s_cov[lane];
   if (energy_out && lane == 0) energy_out[b] = s_energy[lat.n_steps];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_track_moments(LatticeDev lat, const T* __restrict__ energy_in,
+                                                        const T* mu_in, const T* cov_in, T* mu_out,
+                                                        T* cov_out, T* __restrict__ energy_out, int chunk) {
+  track_moments_sample<T>(lat, energy_in, mu_in, cov_in, mu_out, cov_out, energy_out, chunk);
+}
+
+// ... of a small lattice, whose parameters come with the arguments (InlinePool)
+template <typename T, int BYTES>
+__global__ __launch_bounds__(256) void k_track_moments_inline(InlinePool<BYTES> /* read in place: inline_pool_view */, LatticeDev lat,
+                                                               const T* __restrict__ energy_in, const T* mu_in,
+                                                               const T* cov_in, T* mu_out, T* cov_out,
+                                                               T* __restrict__ energy_out, int chunk) {
+  track_moments_sample<T>(inline_pool_view(lat), energy_in, mu_in, cov_in, mu_out, cov_out, energy_out, chunk);
 }
 
 // ---------------------------------------------------------------------------------------

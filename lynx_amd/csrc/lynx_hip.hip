@@ -51,6 +51,7 @@ struct Knobs {
   int bwd_pairs = 1;          // LYNX_BWD_PAIRS         two particles per lane in the float32 reverse pass
   int build_in_tail = 1;      // LYNX_BUILD_IN_TAIL     start the next build in the tail of the streaming kernel
   int small_inline = -1;      // LYNX_SMALL_INLINE      short calls: build, stream and reduce back to back on ONE stream, no events
+  int inline_pool = 1;        // LYNX_INLINE_POOL       small lattices: the parameters by value in the kernel arguments (0: always from memory)
 };
 
 static void load_knobs(Knobs* k) {
@@ -64,7 +65,7 @@ static void load_knobs(Knobs* k) {
       {"LYNX_FUSE_MAX_CHUNKS", &k->fuse_max_chunks}, {"LYNX_MERGE_STEPS", &k->merge_steps},
       {"LYNX_REDUCE_WIDE", &k->reduce_wide}, {"LYNX_REDUCE_TICKET", &k->reduce_ticket}, {"LYNX_TRACK_UNITS", &k->track_units}, {"LYNX_BWD_UNITS", &k->bwd_units},
       {"LYNX_BWD_MERGE", &k->bwd_merge}, {"LYNX_BWD_PAIRS", &k->bwd_pairs}, {"LYNX_BUILD_IN_TAIL", &k->build_in_tail},
-      {"LYNX_SMALL_INLINE", &k->small_inline}};
+      {"LYNX_SMALL_INLINE", &k->small_inline}, {"LYNX_INLINE_POOL", &k->inline_pool}};
   for (const auto& t : table) {
     const char* v = getenv(t.name);
     if (v && *v) *t.value = atoi(v);
@@ -217,6 +218,12 @@ struct lynx_lattice {
   // the reverse pass's (element, parameter) tasks, kind by kind (lynx_grad.hpp: bwd_kind_params), made on first use
   unsigned short* d_bwd_tasks = nullptr;
   int32_t n_bwd_tasks = 0;
+  // Small lattices without cavities: the parameter pool travels by value in the arguments of the one-workgroup-per-
+  // sample kernels (InlinePool, lynx_device.hpp).  A parameter write is a memcpy on the host; d_pool is brought up to
+  // date when a kernel that reads it is next launched (sync_pool).
+  bool prog_pool = false;
+  bool pool_stale = false;
+  InlinePool<kInlinePoolLarge> h_pool;
 };
 
 static thread_local std::string g_err;
@@ -776,6 +783,15 @@ static int params_of_kind(int kind) {
   }
 }
 
+// d_pool as current as the pool that travels in the kernel arguments: before any kernel that reads the parameters from memory
+static int sync_pool(lynx_ctx* ctx, lynx_lattice* lat) {
+  if (!lat->pool_stale) return LYNX_OK;
+  HIP_TRY(ctx, hipMemcpyAsync(lat->d_pool, lat->h_pool.q, (size_t)lat->pool_count * dtype_size(lat->dtype), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, sync_main(ctx));
+  lat->pool_stale = false;
+  return LYNX_OK;
+}
+
 int lynx_lattice_create(lynx_ctx* ctx, int dtype, int64_t batch, int32_t n_elems,
                         const lynx_elem* elems, int32_t n_steps, const lynx_step* steps,
                         const void* pool, int64_t pool_count, lynx_lattice** out) {
@@ -857,6 +873,9 @@ int lynx_lattice_create(lynx_ctx* ctx, int dtype, int64_t batch, int32_t n_elems
     HIP_TRY(ctx, sync_main(ctx));  // `cavs` goes out of scope
   }
   HIP_TRY(ctx, sync_main(ctx));
+  memset(&lat->h_pool, 0, sizeof(lat->h_pool));
+  lat->prog_pool = !lat->has_cavity && n_steps > 0 && (size_t)pool_count * es <= sizeof(lat->h_pool);  // (a cavity's predicates are evaluated by kernels of their own)
+  if (lat->prog_pool) memcpy(lat->h_pool.q, pool, (size_t)pool_count * es);
   *out = lat;
   return LYNX_OK;
 }
@@ -866,6 +885,11 @@ int lynx_lattice_update_params(lynx_lattice* lat, int64_t offset, int64_t count,
   if (offset < 0 || count < 0 || offset + count > lat->pool_count)
     return fail(ctx, LYNX_ERR_INVALID, "lynx_lattice_update_params: range outside the pool");
   const size_t es = dtype_size(lat->dtype);
+  if (lat->prog_pool) {  // the kernels of a small lattice read the parameters in their arguments: d_pool follows when it is needed
+    memcpy(reinterpret_cast<unsigned char*>(lat->h_pool.q) + offset * es, host, count * es);
+    lat->pool_stale = true;
+    return LYNX_OK;
+  }
   HIP_TRY(ctx, hipMemcpyAsync((char*)lat->d_pool + offset * es, host, count * es, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, sync_main(ctx));
   return LYNX_OK;
@@ -1082,16 +1106,31 @@ static int launch_build(lynx_ctx* ctx, lynx_lattice* lat, hipStream_t stream, co
   }
   // large batches: lanes = samples (an order of magnitude fewer wave-instructions); small ones: one
   // workgroup per sample, whose tree is shallower than a chain of launches
-  if (lat->n_steps > 0 && lat->batch >= ctx->knobs.lanes_build_min_batch)
-    return launch_build_lanes<T>(ctx, lat, stream, d_energy_in, d_steps_out, d_energy_out, merge_pairs, d_units, d_extras);
+  if (lat->n_steps > 0 && lat->batch >= ctx->knobs.lanes_build_min_batch) {
+    const int rc = sync_pool(ctx, lat);
+    return rc ? rc : launch_build_lanes<T>(ctx, lat, stream, d_energy_in, d_steps_out, d_energy_out, merge_pairs, d_units, d_extras);
+  }
   int threads, chunk;
   build_shape<T>(ctx, lat, underneath, &threads, &chunk);
   const size_t lds = build_scratch_bytes(chunk, sizeof(T)) +
                      ((size_t)lat->n_steps * LYNX_STEP_STRIDE + lat->n_steps + 1) * sizeof(T);
-  int rc = allow_lds(ctx, k_build<T>, lds);
-  if (rc) return rc;
-  hipLaunchKernelGGL(k_build<T>, dim3((unsigned)lat->batch), dim3((unsigned)threads), lds, stream, dev_view(lat),
-                     (const T*)d_energy_in, (T*)d_steps_out, (T*)d_energy_out, chunk, merge_pairs);
+  int rc;
+  if (lat->prog_pool && ctx->knobs.inline_pool) {
+    if ((size_t)lat->pool_count * sizeof(T) <= (size_t)kInlinePoolSmall) {
+      if ((rc = allow_lds(ctx, k_build_inline<T, kInlinePoolSmall>, lds))) return rc;
+      hipLaunchKernelGGL((k_build_inline<T, kInlinePoolSmall>), dim3((unsigned)lat->batch), dim3((unsigned)threads), lds, stream,
+                         *reinterpret_cast<const InlinePool<kInlinePoolSmall>*>(&lat->h_pool), dev_view(lat),
+                         (const T*)d_energy_in, (T*)d_steps_out, (T*)d_energy_out, chunk, merge_pairs);
+    } else {
+      if ((rc = allow_lds(ctx, k_build_inline<T, kInlinePoolLarge>, lds))) return rc;
+      hipLaunchKernelGGL((k_build_inline<T, kInlinePoolLarge>), dim3((unsigned)lat->batch), dim3((unsigned)threads), lds, stream,
+                         lat->h_pool, dev_view(lat), (const T*)d_energy_in, (T*)d_steps_out, (T*)d_energy_out, chunk, merge_pairs);
+    }
+  } else {
+    if ((rc = sync_pool(ctx, lat)) || (rc = allow_lds(ctx, k_build<T>, lds))) return rc;
+    hipLaunchKernelGGL(k_build<T>, dim3((unsigned)lat->batch), dim3((unsigned)threads), lds, stream, dev_view(lat),
+                       (const T*)d_energy_in, (T*)d_steps_out, (T*)d_energy_out, chunk, merge_pairs);
+  }
   HIP_TRY(ctx, hipGetLastError());
   if constexpr (sizeof(T) == 4) {
     if (d_units) {
@@ -1491,6 +1530,7 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
     d_steps = ctx->scratch_steps[slot];
   }
   if (fused && lat) {
+    if ((rc = sync_pool(ctx, lat))) return rc;  // (the prologue reads the parameters from memory)
     if ((rc = launch_cavity_flags<T>(ctx, lat, ctx->stream, d_energy_in))) return rc;
     ctx->main_dirty = true;  // it rewrote the lattice's flags on the main stream: a later build on s_build waits
   }
@@ -1530,6 +1570,12 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
     p.a.tail_wg = (int32_t)std::max<int64_t>(0, (int64_t)p.grid - 4 * cus);
   }
   p.done = (slot >= 0 && async_build) ? ctx->ev_streamed_own[slot] : nullptr;
+  // A short call whose reduction follows in line marks "this table slot has been read" BEHIND the reduction instead
+  // of on the streaming kernel's dispatch: a completion signal between two kernels of a queue costs the second one
+  // ~5 us (kernel timeline of BASELINE config 3), behind the call's last kernel it shares the hand-over the next call
+  // pays anyway.
+  const bool late_mark = p.done && short_call && moments && !side && !ctx->profiling;
+  if (late_mark) p.done = nullptr;
   if (side && !p.done) p.done = ring->track_done;  // the side stream's reduction starts behind it
   if (use_units) rc = launch_units(ctx, p, n_units, S, d_p_in, d_p_out, d_energy_out, d_steps, d_units, d_extras, d_partials, moments);
   else rc = launch_direct<T>(ctx, p, lv, d_energy_in, d_p_in, d_p_out, d_energy_out, d_steps, d_partials, d_obs, moments);
@@ -1622,6 +1668,11 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
       ctx->side_wrote = d_moments_out;
     }
   }
+  if (late_mark) {
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_streamed_own[slot], ctx->stream));
+    ctx->ev_streamed[slot] = ctx->ev_streamed_own[slot];
+    ctx->streamed_valid[slot] = true;
+  }
   return LYNX_OK;
 }
 
@@ -1708,6 +1759,7 @@ static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const v
   const int64_t B = lat->batch;
   const int32_t S = lat->n_steps, E = lat->n_elems;
   int rc;
+  if ((rc = sync_pool(ctx, lat))) return rc;  // (k_build_bwd reads the parameters from memory)
   // forward step tables; packed float32 pairs walk [run, cavity] pairs in the merged form of the forward
   // kernel (LYNX_BWD_MERGE=0: every step on its own), k_build_bwd takes the cotangents apart again
   constexpr int W = LaneOf<Z>::W;
@@ -1862,6 +1914,7 @@ static int moments_backward_t(lynx_ctx* ctx, lynx_lattice* lat, const void* d_en
   const int64_t B = lat->batch;
   const int32_t S = lat->n_steps, E = lat->n_elems;
   int rc;
+  if ((rc = sync_pool(ctx, lat))) return rc;  // (k_moments_bwd reads the parameters from memory)
   if ((rc = ensure_scratch(ctx, &ctx->scratch_steps[lynx_ctx::kTableBwd], &ctx->scratch_steps_bytes[lynx_ctx::kTableBwd], (size_t)B * S * LYNX_STEP_STRIDE * sizeof(T))))
     return rc;
   if ((rc = launch_build<T>(ctx, lat, ctx->stream, d_energy_in, ctx->scratch_steps[lynx_ctx::kTableBwd], nullptr))) return rc;
@@ -1953,8 +2006,22 @@ static int launch_track_moments(lynx_ctx* ctx, lynx_lattice* lat, const void* d_
   const int chunk = build_chunk(lat->n_elems, deep ? 128 : 64);
   const size_t lds = build_scratch_bytes(chunk, sizeof(T)) +
                      ((size_t)lat->n_steps * LYNX_STEP_STRIDE + lat->n_steps + 1 + 8 + 49 + 49 + 16) * sizeof(T);
-  rc = allow_lds(ctx, k_track_moments<T>, lds);
-  if (rc) return rc;
+  if (lat->prog_pool && ctx->knobs.inline_pool) {  // (no cavities: no flags to evaluate)
+    if ((size_t)lat->pool_count * sizeof(T) <= (size_t)kInlinePoolSmall) {
+      if ((rc = allow_lds(ctx, k_track_moments_inline<T, kInlinePoolSmall>, lds))) return rc;
+      hipLaunchKernelGGL((k_track_moments_inline<T, kInlinePoolSmall>), dim3((unsigned)lat->batch), dim3(threads), lds, ctx->stream,
+                         *reinterpret_cast<const InlinePool<kInlinePoolSmall>*>(&lat->h_pool), dev_view(lat), (const T*)d_energy_in,
+                         (const T*)d_mu_in, (const T*)d_cov_in, (T*)d_mu_out, (T*)d_cov_out, (T*)d_energy_out, chunk);
+    } else {
+      if ((rc = allow_lds(ctx, k_track_moments_inline<T, kInlinePoolLarge>, lds))) return rc;
+      hipLaunchKernelGGL((k_track_moments_inline<T, kInlinePoolLarge>), dim3((unsigned)lat->batch), dim3(threads), lds, ctx->stream,
+                         lat->h_pool, dev_view(lat), (const T*)d_energy_in, (const T*)d_mu_in, (const T*)d_cov_in, (T*)d_mu_out,
+                         (T*)d_cov_out, (T*)d_energy_out, chunk);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return LYNX_OK;
+  }
+  if ((rc = sync_pool(ctx, lat)) || (rc = allow_lds(ctx, k_track_moments<T>, lds))) return rc;
   if ((rc = launch_cavity_flags<T>(ctx, lat, ctx->stream, d_energy_in))) return rc;
   hipLaunchKernelGGL(k_track_moments<T>, dim3((unsigned)lat->batch), dim3(threads), lds, ctx->stream, dev_view(lat),
                      (const T*)d_energy_in, (const T*)d_mu_in, (const T*)d_cov_in, (T*)d_mu_out, (T*)d_cov_out,

@@ -1798,6 +1798,79 @@ def test_device_phase_trig_accuracy(lx, packed):
     assert err.max() < 1.35e-7, err.max()
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("batch,cells", [(1, 3), (3, 3), (1, 40)])
+def test_the_parameters_of_small_lattices_travel_in_the_kernel_arguments(lx, dtype, batch, cells, monkeypatch):
+    """
+    InlinePool (lynx_device.hpp): the parameter pool of a small lattice without cavities (up to 256 bytes, or up to
+    1 KB) is passed to the one-workgroup-per-sample kernels by value; a parameter write then is a memcpy on the host,
+    and the pool in HBM follows when a kernel that reads it from there is next launched.
+    (batch, cells) = (1, 3): the small size; (3, 3): the large one; (1, 40): 160 elements, too many -- from memory.
+    Same arithmetic as from memory (LYNX_INLINE_POOL=0): the same bits, for a ParticleBeam and a ParameterBeam; a
+    parameter written between two calls reaches both forms, and the reverse pass -- which reads the parameters from
+    HBM -- right behind a write.
+    """
+    import lynx_amd.grad as grad
+
+    B = batch
+    f = lambda v: np.full(B, v, dtype=dtype)  # noqa: E731
+    rng = np.random.default_rng(31)
+    k1 = rng.uniform(-4, 4, (cells, B)).astype(dtype)
+    k1_new = rng.uniform(-4, 4, B).astype(dtype)
+
+    def segment(first_k1):
+        els = []
+        for c in range(cells):
+            els += [lx.Drift(f(0.3), dtype=dtype), lx.Quadrupole(f(0.2), k1=first_k1 if c == 0 else k1[c], dtype=dtype, name=f"Q{c}"),
+                    lx.HorizontalCorrector(f(0.1), angle=f(1e-4), dtype=dtype), lx.Marker(name=f"M{c}")]
+        return lx.Segment(els)
+
+    P = o.gaussian_particles((B,), 3001, seed=7, dtype=dtype, sigma=[1e-4, 1e-5, 1e-4, 1e-5, 1e-5, 1e-3])
+    energy = f(1e8)
+    pbeam = lx.ParameterBeam.from_parameters(energy=energy, dtype=dtype) if B == 1 else None
+
+    def results(seg):
+        out = seg.track(lx.ParticleBeam(P, energy, dtype=dtype))
+        res = [np.asarray(out.particles), out.moment_record().copy()]
+        if pbeam is not None:
+            pb = seg.track(pbeam)
+            res += [np.asarray(pb._mu), np.asarray(pb._cov)]
+        return res
+
+    def same(a, b):
+        return all(np.array_equal(x, y, equal_nan=True) for x, y in zip(a, b))
+
+    seg = segment(k1[0])
+    first = results(seg)
+    seg.Q0.k1 = k1_new  # a write between two calls ...
+    second = results(seg)
+    assert not np.array_equal(first[0], second[0])
+    assert same(second, results(segment(k1_new)))  # ... is what a new segment with that value gives
+    vjp = grad.track_vjp(seg, lx.ParticleBeam(P, energy, dtype=dtype))  # the reverse pass right behind a write
+    g = vjp(cov_bar=np.broadcast_to(np.eye(6), (B, 6, 6)).copy())
+    seg.Q0.k1 = k1[0]
+    seg.Q0.k1 = k1_new  # (two writes, none of them followed by a forward call)
+    fresh = segment(k1_new)
+    g_fresh = grad.track_vjp(fresh, lx.ParticleBeam(P, energy, dtype=dtype))(cov_bar=np.broadcast_to(np.eye(6), (B, 6, 6)).copy())
+    assert np.array_equal(np.asarray(g[seg.Q0]["k1"]), np.asarray(g_fresh[fresh.Q0]["k1"]))
+    g_again = grad.track_vjp(seg, lx.ParticleBeam(P, energy, dtype=dtype))(cov_bar=np.broadcast_to(np.eye(6), (B, 6, 6)).copy())
+    assert np.array_equal(np.asarray(g[seg.Q0]["k1"]), np.asarray(g_again[seg.Q0]["k1"]))
+    monkeypatch.setenv("LYNX_INLINE_POOL", "0")  # everything from memory: the same bits
+    seg_mem = segment(k1[0])
+    assert same(first, results(seg_mem))
+    seg_mem.Q0.k1 = k1_new
+    assert same(second, results(seg_mem))
+    g_mem = grad.track_vjp(seg_mem, lx.ParticleBeam(P, energy, dtype=dtype))(cov_bar=np.broadcast_to(np.eye(6), (B, 6, 6)).copy())
+    assert np.array_equal(np.asarray(g[seg.Q0]["k1"]), np.asarray(g_mem[seg_mem.Q0]["k1"]))
+    # and against the oracle
+    specs = []
+    for c in range(cells):
+        specs += [o.Drift(f(0.3)), o.Quadrupole(f(0.2), k1=k1_new if c == 0 else k1[c]), o.HorizontalCorrector(f(0.1), angle=f(1e-4)), o.Marker()]
+    ref = o.segment_track(specs, o.particle_beam(P, energy, dtype), dtype)
+    for c in range(7):
+        assert rel_err(second[0][..., c], ref["particles"][..., c]) < TOL_P[np.dtype(dtype).type], c
+
+
 def test_attribute_writes_between_tracks_take_effect(lx):
     """
     README.md:60 pattern (`segment.AREAMQZM2.k1 = ...`): values, whole-batch predicates (tilt,
