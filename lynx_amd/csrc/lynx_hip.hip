@@ -1570,12 +1570,6 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
     p.a.tail_wg = (int32_t)std::max<int64_t>(0, (int64_t)p.grid - 4 * cus);
   }
   p.done = (slot >= 0 && async_build) ? ctx->ev_streamed_own[slot] : nullptr;
-  // A short call whose reduction follows in line marks "this table slot has been read" BEHIND the reduction instead
-  // of on the streaming kernel's dispatch: a completion signal between two kernels of a queue costs the second one
-  // ~5 us (kernel timeline of BASELINE config 3), behind the call's last kernel it shares the hand-over the next call
-  // pays anyway.
-  const bool late_mark = p.done && short_call && moments && !side && !ctx->profiling;
-  if (late_mark) p.done = nullptr;
   if (side && !p.done) p.done = ring->track_done;  // the side stream's reduction starts behind it
   if (use_units) rc = launch_units(ctx, p, n_units, S, d_p_in, d_p_out, d_energy_out, d_steps, d_units, d_extras, d_partials, moments);
   else rc = launch_direct<T>(ctx, p, lv, d_energy_in, d_p_in, d_p_out, d_energy_out, d_steps, d_partials, d_obs, moments);
@@ -1667,11 +1661,6 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
       side_op_issued(ctx, ring->reduced, d_moments_out, nullptr, false);
       ctx->side_wrote = d_moments_out;
     }
-  }
-  if (late_mark) {
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_streamed_own[slot], ctx->stream));
-    ctx->ev_streamed[slot] = ctx->ev_streamed_own[slot];
-    ctx->streamed_valid[slot] = true;
   }
   return LYNX_OK;
 }
