@@ -51,6 +51,7 @@ struct Knobs {
   int bwd_pairs = 1;          // LYNX_BWD_PAIRS         two particles per lane in the float32 reverse pass
   int build_in_tail = 1;      // LYNX_BUILD_IN_TAIL     start the next build in the tail of the streaming kernel
   int small_inline = -1;      // LYNX_SMALL_INLINE      short calls: build, stream and reduce back to back on ONE stream, no events
+  int bwd_reuse_table = 1;    // LYNX_BWD_REUSE_TABLE   the reverse pass reads the step table the forward call just built (0: builds its own)
   int inline_pool = 1;        // LYNX_INLINE_POOL       small lattices: the parameters by value in the kernel arguments (0: always from memory)
 };
 
@@ -65,7 +66,7 @@ static void load_knobs(Knobs* k) {
       {"LYNX_FUSE_MAX_CHUNKS", &k->fuse_max_chunks}, {"LYNX_MERGE_STEPS", &k->merge_steps},
       {"LYNX_REDUCE_WIDE", &k->reduce_wide}, {"LYNX_REDUCE_TICKET", &k->reduce_ticket}, {"LYNX_TRACK_UNITS", &k->track_units}, {"LYNX_BWD_UNITS", &k->bwd_units},
       {"LYNX_BWD_MERGE", &k->bwd_merge}, {"LYNX_BWD_PAIRS", &k->bwd_pairs}, {"LYNX_BUILD_IN_TAIL", &k->build_in_tail},
-      {"LYNX_SMALL_INLINE", &k->small_inline}, {"LYNX_INLINE_POOL", &k->inline_pool}};
+      {"LYNX_SMALL_INLINE", &k->small_inline}, {"LYNX_INLINE_POOL", &k->inline_pool}, {"LYNX_BWD_REUSE_TABLE", &k->bwd_reuse_table}};
   for (const auto& t : table) {
     const char* v = getenv(t.name);
     if (v && *v) *t.value = atoi(v);
@@ -99,6 +100,26 @@ struct lynx_ctx {
   // sync_main, cleared by every entry point that enqueues): asking the runtime -- hipStreamQuery -- puts a marker
   // packet into the queue whose release costs the next kernel ~5 us behind a kernel that left dirty lines in L2.
   bool main_idle = true;
+  // The step table (and unit records) the latest forward call built, for a reverse pass that follows it directly on the
+  // same lattice, incoming energy and merge form: it reads them instead of building its own (BASELINE config 5: 80 us
+  // of 2.27 ms).  Good while no later call has taken a table slot (`seq`), the lattice has not been written to
+  // (`version`) and no entry point that writes device memory on the caller's behalf has run since.
+  struct FwdTable {
+    const lynx_lattice* lat = nullptr;
+    uint64_t version = 0;
+    const void* energy = nullptr;
+    int slot = -1;
+    int merged = 0;
+    bool units = false;
+    size_t energy_bytes = 0;
+    unsigned seq = 0;
+    bool valid = false;
+    // device memory [dst, dst + bytes) is about to be written on the caller's behalf
+    void written(const void* dst, size_t bytes) {
+      const char *a = (const char*)dst, *e = (const char*)energy;
+      if (valid && a < e + energy_bytes && a + bytes > e) valid = false;
+    }
+  } fwd_table;
   const void* main_wrote = nullptr;   // energy buffer the last streaming kernel published on the main stream
   std::mutex mu;                      // allocator maps: finalizers may run on other threads
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
@@ -221,6 +242,7 @@ struct lynx_lattice {
   // Small lattices without cavities: the parameter pool travels by value in the arguments of the one-workgroup-per-
   // sample kernels (InlinePool, lynx_device.hpp).  A parameter write is a memcpy on the host; d_pool is brought up to
   // date when a kernel that reads it is next launched (sync_pool).
+  uint64_t version = 0;  // parameter and flag writes so far
   bool prog_pool = false;
   bool pool_stale = false;
   InlinePool<kInlinePoolLarge> h_pool;
@@ -690,10 +712,14 @@ int lynx_buf_alloc(lynx_ctx* ctx, size_t bytes, void** d_out) {
   return ctx_alloc(ctx, bytes, d_out);
 }
 
-int lynx_buf_free(lynx_ctx* ctx, void* d_ptr) { return ctx_free(ctx, d_ptr); }
+int lynx_buf_free(lynx_ctx* ctx, void* d_ptr) {
+  if (ctx && d_ptr) ctx->fwd_table.written(d_ptr, 1);  // (a freed energy block may come back with other contents)
+  return ctx_free(ctx, d_ptr);
+}
 
 int lynx_buf_h2d(lynx_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
   if (bytes == 0) return LYNX_OK;
+  ctx->fwd_table.written(d_dst, bytes);
   HIP_TRY(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, sync_main(ctx));  // h_src is pageable and may be freed
   return LYNX_OK;
@@ -717,6 +743,7 @@ int lynx_buf_d2d(lynx_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) {
     const int rc = join_side(ctx);  // the source may be a moment record the side stream is still reducing
     if (rc) return rc;
   }
+  ctx->fwd_table.written(d_dst, bytes);
   HIP_TRY(ctx, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
   ctx->main_dirty = true;
   return LYNX_OK;
@@ -729,6 +756,7 @@ int lynx_buf_memset(lynx_ctx* ctx, void* d_dst, int value, size_t bytes) {
     const int rc = join_side(ctx);
     if (rc) return rc;
   }
+  ctx->fwd_table.written(d_dst, bytes);
   HIP_TRY(ctx, hipMemsetAsync(d_dst, value, bytes, ctx->stream));
   ctx->main_dirty = true;
   return LYNX_OK;
@@ -885,6 +913,7 @@ int lynx_lattice_update_params(lynx_lattice* lat, int64_t offset, int64_t count,
   if (offset < 0 || count < 0 || offset + count > lat->pool_count)
     return fail(ctx, LYNX_ERR_INVALID, "lynx_lattice_update_params: range outside the pool");
   const size_t es = dtype_size(lat->dtype);
+  ++lat->version;
   if (lat->prog_pool) {  // the kernels of a small lattice read the parameters in their arguments: d_pool follows when it is needed
     memcpy(reinterpret_cast<unsigned char*>(lat->h_pool.q) + offset * es, host, count * es);
     lat->pool_stale = true;
@@ -900,6 +929,7 @@ int lynx_lattice_set_flags(lynx_lattice* lat, const int32_t* elem_flags, const i
   for (int32_t e = 0; e < lat->n_elems; ++e) lat->h_elems[e].flags = elem_flags[e];
   for (int32_t s = 0; s < lat->n_steps; ++s) lat->h_steps[s].flags = step_flags[s];
   lat->units_made[0] = lat->units_made[1] = false;  // the proposed classes depend on the elements' flags
+  ++lat->version;
   {
     const int rc = count_observers(ctx, lat);
     if (rc) return rc;
@@ -1528,6 +1558,15 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
       else HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_built[slot], 0));
     }
     d_steps = ctx->scratch_steps[slot];
+    ctx->fwd_table.lat = lat;
+    ctx->fwd_table.version = lat->version;
+    ctx->fwd_table.energy = d_energy_in;
+    ctx->fwd_table.energy_bytes = (size_t)B * sizeof(T);
+    ctx->fwd_table.slot = slot;
+    ctx->fwd_table.merged = p.a.merged_pairs;
+    ctx->fwd_table.units = use_units;
+    ctx->fwd_table.seq = ctx->seq;
+    ctx->fwd_table.valid = d_energy_out != d_energy_in;  // (a call that overwrites its own incoming energy leaves nothing to come back to)
   }
   if (fused && lat) {
     if ((rc = sync_pool(ctx, lat))) return rc;  // (the prologue reads the parameters from memory)
@@ -1795,9 +1834,23 @@ static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const v
       }
     }
   }
-  if ((rc = launch_build<T>(ctx, lat, ctx->stream, d_energy_in, ctx->scratch_steps[lynx_ctx::kTableBwd], nullptr, merged, false,
-                            d_units, d_extras)))
+  // the forward call this reverse pass belongs to has built exactly this table (and these unit records) a moment ago:
+  // read them where they are -- and make the slot's next build wait for this reverse pass too
+  const lynx_ctx::FwdTable& ft = ctx->fwd_table;
+  const bool reuse = ctx->knobs.bwd_reuse_table && ft.valid && ft.lat == lat && ft.version == lat->version &&
+                     ft.energy == d_energy_in && ft.seq == ctx->seq && ft.merged == merged && (!d_units || ft.units) &&
+                     ctx->scratch_steps_bytes[ft.slot] >= steps_bytes;
+  const void* d_table = ctx->scratch_steps[lynx_ctx::kTableBwd];
+  if (reuse) {
+    d_table = ctx->scratch_steps[ft.slot];
+    if (d_units) {
+      d_units = (float*)ctx->scratch_units[ft.slot];
+      d_extras = (float*)ctx->scratch_units[lynx_ctx::kTableSlots + ft.slot];
+    }
+  } else if ((rc = launch_build<T>(ctx, lat, ctx->stream, d_energy_in, ctx->scratch_steps[lynx_ctx::kTableBwd], nullptr, merged, false,
+                                   d_units, d_extras))) {
     return rc;
+  }
   ctx->main_dirty = true;
 
   // Z: what a lane carries -- one particle, or (float32) two as a packed pair
@@ -1841,7 +1894,7 @@ static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const v
     }
   }
   hipLaunchKernelGGL((k_track_bwd<T, Z>), dim3((unsigned)(B * chunks)), dim3(kTrackThreads), lds, ctx->stream, lv, a,
-                     (const T*)d_p_in, (const T*)ctx->scratch_steps[lynx_ctx::kTableBwd], d_moments_fwd, d_grad_moments,
+                     (const T*)d_p_in, (const T*)d_table, d_moments_fwd, d_grad_moments,
                      (T*)ctx->scratch_grad[0], (T*)d_grad_p_in, (const float*)d_units, kUnitStride, kUnitClassShift, (int)kClassU,
                      d_grad_observations);
   HIP_TRY(ctx, hipGetLastError());
@@ -1854,6 +1907,11 @@ static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const v
                          (float*)ctx->scratch_grad[1]);
       HIP_TRY(ctx, hipGetLastError());
     }
+  }
+  if (reuse) {  // the forward call's table slot has been read up to here: its next build waits for this, too
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_streamed_own[ft.slot], ctx->stream));
+    ctx->ev_streamed[ft.slot] = ctx->ev_streamed_own[ft.slot];
+    ctx->streamed_valid[ft.slot] = true;
   }
   size_t lds2 = build_bwd_lds_fixed<T>(S, E);
   // maps + prefix products, then the kind-sorted task list and the elements' kinds (unsigned short each)
@@ -2022,6 +2080,7 @@ static int launch_track_moments(lynx_ctx* ctx, lynx_lattice* lat, const void* d_
 int lynx_track_moments(lynx_ctx* ctx, lynx_lattice* lat, const void* d_energy_in, const void* d_mu_in,
                        const void* d_cov_in, void* d_mu_out, void* d_cov_out, void* d_energy_out) {
   ctx->main_idle = false;  // (something is about to be enqueued on the main stream)
+  if (ctx && d_energy_out) ctx->fwd_table.written(d_energy_out, 1);
   if (!ctx || !lat || !d_energy_in || !d_mu_in || !d_cov_in || !d_mu_out || !d_cov_out)
     return fail(ctx, LYNX_ERR_INVALID, "null argument");
   if (lat->batch > 0x7fffffffLL) return fail(ctx, LYNX_ERR_INVALID, "batch too large");

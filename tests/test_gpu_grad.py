@@ -214,6 +214,71 @@ def test_structured_reverse_pass_fp32(lx, monkeypatch, B, N):
             assert any(np.any(structured[key] != dense[key]) for key in g64)
 
 
+@pytest.mark.parametrize("dtype,B,N", [(np.float32, 3, 4000), (np.float32, 300, 512), (np.float64, 2, 3000)],
+                         ids=["fp32-workgroup-build", "fp32-lanes-build", "fp64"])
+def test_the_reverse_pass_reads_the_table_of_its_forward_call(lx, monkeypatch, dtype, B, N):
+    """
+    A reverse pass that directly follows its forward call (same lattice, incoming energy, merge form; nothing written
+    in between) reads the step table and unit records that call built instead of building its own
+    (lynx_ctx::FwdTable; LYNX_BWD_REUSE_TABLE=0: always its own).  The same numbers go into the same kernels: every
+    gradient bit for bit.  What must break the hand-over does: another forward call in between (the slots move on), a
+    parameter written in between (the gradient is the one at the NEW value, as it always was), and -- many steps in a
+    row, each of them a forward and a reverse pass -- the table slot's next build waits for the reverse pass that
+    still reads it.
+    """
+    rng = np.random.default_rng(47)
+    f = lambda v: np.full(B, v)  # noqa: E731
+    desc = []
+    for cell in range(3):
+        desc += [("drift", dict(length=f(0.3))),
+                 ("quadrupole", dict(length=f(0.1), k1=rng.uniform(-5, 5, B), misalignment=rng.normal(0, 1e-3, (B, 2)))),
+                 ("hcor", dict(length=f(0.1), angle=rng.normal(0, 1e-3, B))), ("drift", dict(length=f(0.3))),
+                 ("cavity", dict(length=f(1.0377), voltage=rng.uniform(5e6, 2e7, B), phase=rng.uniform(-10, 10, B), frequency=f(1.3e9)))]
+    P = o.gaussian_particles((B,), N, seed=9, dtype=np.float64, sigma=[1e-3, 1e-4, 1e-3, 1e-4, 1e-3, 1e-3]).astype(dtype)
+    energy = rng.uniform(6e6, 8e6, B).astype(dtype)
+    w_cov = rng.normal(size=(B, 6, 6)) * 1e3
+
+    def flat(g, elements):
+        out = [np.asarray(g.energy)]
+        for e, (kind, _) in enumerate(desc):
+            out += [np.asarray(g[elements[e]][name]) for name in PARAMS_TO_CHECK.get(kind, []) if getattr(elements[e], name, None) is not None]
+        return out
+
+    def same(a, b):
+        return all(np.array_equal(x, y, equal_nan=True) for x, y in zip(a, b))
+
+    elements, _ = make_lattice(desc, dtype, lx)
+    seg = lx.Segment(elements)
+    beam = lx.ParticleBeam(P, energy, dtype=dtype)
+    handed_over = flat(lx.grad.track_vjp(seg, beam)(cov_bar=w_cov), elements)
+    monkeypatch.setenv("LYNX_BWD_REUSE_TABLE", "0")
+    own_table = flat(lx.grad.track_vjp(seg, beam)(cov_bar=w_cov), elements)
+    monkeypatch.delenv("LYNX_BWD_REUSE_TABLE")
+    assert same(handed_over, own_table)
+    # another forward call between the two halves
+    vjp = lx.grad.track_vjp(seg, beam)
+    other, _ = make_lattice(desc[:5], dtype, lx)
+    lx.Segment(other).track(beam)
+    assert same(flat(vjp(cov_bar=w_cov), elements), own_table)
+    # a parameter written between the two halves: the reverse pass builds at the new value
+    quad = elements[1]
+    k1_old, k1_new = np.asarray(quad.k1).copy(), (np.asarray(quad.k1) * 0.5).astype(dtype)
+    vjp = lx.grad.track_vjp(seg, beam)
+    quad.k1 = k1_new
+    moved = flat(vjp(cov_bar=w_cov), elements)
+    monkeypatch.setenv("LYNX_BWD_REUSE_TABLE", "0")
+    quad.k1 = k1_old
+    vjp2 = lx.grad.track_vjp(seg, beam)
+    quad.k1 = k1_new
+    assert same(moved, flat(vjp2(cov_bar=w_cov), elements))
+    monkeypatch.delenv("LYNX_BWD_REUSE_TABLE")
+    quad.k1 = k1_old
+    # many steps in a row without a wait in between
+    runs = [lx.grad.track_vjp(seg, beam)(cov_bar=w_cov) for _ in range(8)]
+    for g in runs:
+        assert same(flat(g, elements), own_table)
+
+
 def test_gradient_of_linear_lattice_and_broadcast_parameters(lx):
     """All-skippable lattice (one composed map), fp32; a parameter shared by the whole batch
     receives the sum of the per-sample gradients."""
