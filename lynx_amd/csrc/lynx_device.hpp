@@ -329,12 +329,16 @@ __device__ __forceinline__ T cavity_look(const T* pool, const lynx_elem& el, boo
 // the host once per lattice, so that neither kernel has to walk the step and element tables to find them
 template <typename T>
 __global__ __launch_bounds__(256) void k_cavity_flags_spec(LatticeDev lat, const int2* __restrict__ cavs, int n_cavs,
-                                                           const T* __restrict__ energy_in, int32_t* __restrict__ words) {
+                                                           const T* __restrict__ energy_in, int32_t* __restrict__ words,
+                                                           T* __restrict__ e_steps /* or null */, int64_t Bp) {
   const T* pool = static_cast<const T*>(lat.pool);
   const int64_t b_raw = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = b_raw < lat.batch;
   const int64_t b = live ? b_raw : lat.batch - 1;
   T energy = energy_in[b];
+  // the sample's energy behind 0, 1, 2, ... step cavities, for the lanes build (StepEnergies): what this walk computes anyway
+  int k = 0;
+  if (e_steps && live) e_steps[b] = energy;
   for (int c = 0; c < n_cavs; ++c) {
     const int2 cv = cavs[c];
     const lynx_elem el = lat.elems[cv.x];
@@ -348,7 +352,11 @@ __global__ __launch_bounds__(256) void k_cavity_flags_spec(LatticeDev lat, const
     if (__builtin_amdgcn_ballot_w64((mine & LYNX_FLAG_CAV_T5XX) != 0)) bits |= LYNX_FLAG_CAV_T5XX;
     if (__builtin_amdgcn_ballot_w64((mine & kBadEnergy) != 0)) bits |= kBadEnergy;
     if ((threadIdx.x & 63) == 0 && bits) atomicOr(&words[c], bits);
-    if (is_step) energy = energy + d_energy;  // the assumption: this cavity's batch gains energy (cavity.py:128-130)
+    if (is_step) {
+      energy = energy + d_energy;  // the assumption: this cavity's batch gains energy (cavity.py:128-130)
+      ++k;
+      if (e_steps && live) e_steps[(int64_t)k * Bp + b] = energy;
+    }
   }
 }
 
@@ -356,10 +364,11 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_cavity_flags(LatticeDev lat, lynx_elem* elems, lynx_step* steps,
                                                       const T* __restrict__ energy_in, T* __restrict__ e_run,
                                                       int32_t* __restrict__ status, const int2* __restrict__ cavs, int n_cavs,
-                                                      int32_t* __restrict__ words) {
+                                                      int32_t* __restrict__ words, int32_t* __restrict__ spec_valid /* or null */) {
   const T* pool = static_cast<const T*>(lat.pool);
   const int64_t B = lat.batch;
   const int nt = blockDim.x;
+  if (threadIdx.x == 0 && spec_valid) *spec_valid = 0;  // until k_cavity_flags_spec's assumption has been found to hold
   if (words) {
     // what k_cavity_flags_spec found: valid if every step cavity's batch gains energy.  One thread per cavity.
     int ok = 1, first_bad = 0x7fffffff;
@@ -389,7 +398,10 @@ __global__ __launch_bounds__(256) void k_cavity_flags(LatticeDev lat, lynx_elem*
     }
     __syncthreads();  // everybody has read its words
     for (int c = threadIdx.x; c < n_cavs; c += nt) words[c] = 0;  // ready for the next call
-    if (valid) return;
+    if (valid) {
+      if (threadIdx.x == 0 && spec_valid) *spec_valid = 1;  // ... and with it the energies that kernel left in e_steps
+      return;
+    }
   }
   // every sample's energy on its way through the cavities: in registers for batches of up to 8 per thread, in
   // `e_run` beyond (hundreds of thousands of ParameterBeam settings)
@@ -501,6 +513,24 @@ __device__ __forceinline__ T energy_before_step(const LatticeDev& lat, int64_t b
   return e;
 }
 
+// The same from what k_cavity_flags_spec left behind: e[k][b] = the energy behind k step cavities, `before[s]` = the number
+// of step cavities in front of step s (made by the host once per lattice) -- ONE load instead of a walk through every
+// earlier cavity's parameters (two dependent loads and a cosine each: up to half of k_build_pieces' time on BASELINE
+// config 5, whose last pieces have seven cavities in front of them).  Valid if that kernel's assumption held (`*valid`,
+// set by k_cavity_flags); lattices without cavities pass e = null.
+template <typename T>
+struct StepEnergies {
+  const T* e;
+  const int32_t* before;
+  const int32_t* valid;
+  int64_t Bp;
+};
+template <typename T>
+__device__ __forceinline__ T energy_at_step(const LatticeDev& lat, const StepEnergies<T>& se, int64_t b, T energy_in, int s) {
+  if (se.e && *se.valid) return se.e[(int64_t)se.before[s] * se.Bp + b];
+  return energy_before_step<T>(lat, b, energy_in, s);
+}
+
 // LDS of k_build_pieces: the running product [49][64] float64 (sample index fastest: conflict-free) and
 // every lane's element map [64][49] T (49 is odd: conflict-free); a lane only ever touches its own cells,
 // so the wave needs no barrier.  Registers hold one element map and one column of the product -- the
@@ -514,7 +544,8 @@ template <typename T> constexpr size_t build_pieces_lds() { return 49 * 64 * siz
 template <typename T>
 __global__ __launch_bounds__(64, 4) void k_build_pieces(LatticeDev lat, const BuildPiece* __restrict__ pieces,
                                                      const T* __restrict__ energy_in, int64_t Bp,
-                                                     double* __restrict__ products, T* __restrict__ coefs) {
+                                                     double* __restrict__ products, T* __restrict__ coefs,
+                                                     StepEnergies<T> se) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* P = reinterpret_cast<double*>(smem_raw) + threadIdx.x;                       // P[q * 64]
   T* M = reinterpret_cast<T*>(smem_raw + 49 * 64 * sizeof(double)) + threadIdx.x * 49;  // M[q]
@@ -524,7 +555,7 @@ __global__ __launch_bounds__(64, 4) void k_build_pieces(LatticeDev lat, const Bu
   const BuildPiece pc = pieces[blockIdx.y];
   const T* pool = static_cast<const T*>(lat.pool);
   const lynx_step st = lat.steps[pc.step];
-  const T energy = energy_before_step<T>(lat, b, energy_in[b], pc.step);
+  const T energy = energy_at_step<T>(lat, se, b, energy_in[b], pc.step);
   T coef[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) coef[q] = T(0);
@@ -632,10 +663,7 @@ template <typename T> constexpr size_t emit_steps_lds() { return 64 * 68 * sizeo
 
 // row i of a step's final map: product . eye(7) unless raw (segment.py:331-335), multiplied out so that a
 // NaN / Inf entry spreads along its row exactly as in the reference; finite entries come back unchanged
-__device__ __forceinline__ void emit_row(const double* src, int64_t Bp, int i, bool raw, double (&out)[7]) {
-  double x[7];
-#pragma unroll
-  for (int k = 0; k < 7; ++k) x[k] = src[(i * 7 + k) * Bp];
+__device__ __forceinline__ void emit_row_of(const double (&x)[7], bool raw, double (&out)[7]) {
   if (raw) {
 #pragma unroll
     for (int j = 0; j < 7; ++j) out[j] = x[j];
@@ -649,6 +677,15 @@ __device__ __forceinline__ void emit_row(const double* src, int64_t Bp, int i, b
     }
   }
 }
+// rows [I0, I0 + N) of a product, all of their loads in flight at once: the product buffer is in HBM, a row at a time
+// is seven dependent round trips per map (the kernel is one wave per SIMD when it runs alone: nothing hides them)
+template <int I0, int N>
+__device__ __forceinline__ void load_rows(const double* src, int64_t Bp, double (&x)[N][7]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int k = 0; k < 7; ++k) x[i][k] = src[((I0 + i) * 7 + k) * Bp];
+}
 
 template <typename T>
 __global__ __launch_bounds__(64, 4) void k_emit_steps(LatticeDev lat, const int32_t* __restrict__ step_slot,
@@ -656,7 +693,8 @@ __global__ __launch_bounds__(64, 4) void k_emit_steps(LatticeDev lat, const int3
                                                    const double* __restrict__ products, const T* __restrict__ coefs,
                                                    int merge_pairs, T* __restrict__ steps_out, T* __restrict__ energy_out,
                                                    const int32_t* __restrict__ step_unit, int n_units,
-                                                   float* __restrict__ units_out, float* __restrict__ extras_out) {
+                                                   float* __restrict__ units_out, float* __restrict__ extras_out,
+                                                   StepEnergies<T> se) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* row = reinterpret_cast<T*>(smem_raw) + threadIdx.x * 68;
   const int64_t b_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
@@ -676,21 +714,30 @@ __global__ __launch_bounds__(64, 4) void k_emit_steps(LatticeDev lat, const int3
     const lynx_step sr = lat.steps[s - 1];
     const double* rsrc = products + (int64_t)step_slot[s - 1] * 49 * Bp + b;
     T R[49];
-#pragma unroll 1
-    for (int i = 0; i < 7; ++i) {
-      double o[7];
-      emit_row(rsrc, Bp, i, (sr.flags & LYNX_STEP_FLAG_RAW) != 0, o);
+    {
+      const bool run_raw = (sr.flags & LYNX_STEP_FLAG_RAW) != 0;
+      const auto run_rows = [&](auto first, const auto& x) {  // rows first, first + 1, ... -> the row buffer, rounded
+        constexpr int I0 = decltype(first)::value;
 #pragma unroll
-      for (int j = 0; j < 7; ++j) row[i * 7 + j] = (T)o[j];  // parked in the row buffer, then into registers
+        for (int i = 0; i < (int)(sizeof(x) / sizeof(x[0])); ++i) {
+          double o[7];
+          emit_row_of(x[i], run_raw, o);
+#pragma unroll
+          for (int j = 0; j < 7; ++j) row[(I0 + i) * 7 + j] = (T)o[j];  // parked in the row buffer, then into registers
+        }
+      };
+      double x[4][7];
+      load_rows<0, 4>(rsrc, Bp, x);
+      run_rows(std::integral_constant<int, 0>{}, x);
+      double y[3][7];
+      load_rows<4, 3>(rsrc, Bp, y);
+      run_rows(std::integral_constant<int, 4>{}, y);
     }
     LYNX_FORGET();
 #pragma unroll
     for (int q = 0; q < 49; ++q) R[q] = row[q];
     T c4[2] = {T(0), T(0)}, c5[2] = {T(0), T(0)};  // the cavity's (s, delta) block
-#pragma unroll 1
-    for (int i = 0; i < 7; ++i) {
-      double x[7];
-      emit_row(src, Bp, i, true, x);
+    const auto cavity_row = [&](int i, const double (&x)[7]) {  // (the cavity's map is raw: its rows as they are)
       if (i == 4) {
         c4[0] = (T)x[4];
         c4[1] = (T)x[5];
@@ -706,6 +753,21 @@ __global__ __launch_bounds__(64, 4) void k_emit_steps(LatticeDev lat, const int3
         for (int k = 1; k < 7; ++k) acc = fma((double)(T)x[k], (double)R[k * 7 + j], acc);
         row[i * 7 + j] = (T)acc;
       }
+    };
+    {  // (two rows at a time: with the run's map in 49 registers there is no room for more in flight)
+      double x[2][7];
+      load_rows<0, 2>(src, Bp, x);
+      cavity_row(0, x[0]);
+      cavity_row(1, x[1]);
+      load_rows<2, 2>(src, Bp, x);
+      cavity_row(2, x[0]);
+      cavity_row(3, x[1]);
+      load_rows<4, 2>(src, Bp, x);
+      cavity_row(4, x[0]);
+      cavity_row(5, x[1]);
+      double z[1][7];
+      load_rows<6, 1>(src, Bp, z);
+      cavity_row(6, z[0]);
     }
     T ci[4];
     entry_ill = cavity_entry_inverse<T>(c4[0], c4[1], c5[0], c5[1], ci);
@@ -717,12 +779,36 @@ __global__ __launch_bounds__(64, 4) void k_emit_steps(LatticeDev lat, const int3
     row[66] = R[5 * 7 + 4];
     row[67] = R[5 * 7 + 5];
   } else {
-#pragma unroll 1
-    for (int i = 0; i < 7; ++i) {
-      double o[7];
-      emit_row(src, Bp, i, raw, o);
+    {
+      const auto rows = [&](auto first, const auto& x) {
+        constexpr int I0 = decltype(first)::value;
 #pragma unroll
-      for (int j = 0; j < 7; ++j) row[i * 7 + j] = (T)o[j];
+        for (int i = 0; i < (int)(sizeof(x) / sizeof(x[0])); ++i) {
+          double o[7];
+          emit_row_of(x[i], raw, o);
+#pragma unroll
+          for (int j = 0; j < 7; ++j) row[(I0 + i) * 7 + j] = (T)o[j];
+        }
+      };
+      if constexpr (sizeof(T) == 4) {
+        double x[4][7];
+        load_rows<0, 4>(src, Bp, x);
+        rows(std::integral_constant<int, 0>{}, x);
+        double y[3][7];
+        load_rows<4, 3>(src, Bp, y);
+        rows(std::integral_constant<int, 4>{}, y);
+      } else {  // (float64 rows cost twice the registers on their way out)
+        double x[2][7];
+        load_rows<0, 2>(src, Bp, x);
+        rows(std::integral_constant<int, 0>{}, x);
+        load_rows<2, 2>(src, Bp, x);
+        rows(std::integral_constant<int, 2>{}, x);
+        load_rows<4, 2>(src, Bp, x);
+        rows(std::integral_constant<int, 4>{}, x);
+        double z[1][7];
+        load_rows<6, 1>(src, Bp, z);
+        rows(std::integral_constant<int, 6>{}, z);
+      }
     }
     if (pair_run) {  // rows 4 and 5 in front: they give the s and delta entering the cavity
       LYNX_FORGET();
@@ -740,7 +826,7 @@ __global__ __launch_bounds__(64, 4) void k_emit_steps(LatticeDev lat, const int3
   }
   row[LYNX_FLAGS_OFFSET] = (T)(step_descriptor(lat, s, merge_pairs) | (entry_ill ? LYNX_DESC_ILL : 0));
   if (s == S - 1) {
-    const T e_out = energy_before_step<T>(lat, b, energy_in[b], S);
+    const T e_out = energy_at_step<T>(lat, se, b, energy_in[b], S);
     row[LYNX_ENERGY_OFFSET] = e_out;
     if (energy_out && live) energy_out[b] = e_out;
   }

@@ -146,6 +146,9 @@ struct lynx_ctx {
   size_t scratch_obs_bytes = 0;
   void* scratch_erun = nullptr;      // k_cavity_flags: every sample's energy on its way through the cavities
   size_t scratch_erun_bytes = 0;
+  void* scratch_esteps = nullptr;    // k_cavity_flags_spec -> lanes build: every sample's energy behind 0, 1, ... step cavities [k][Bp]
+  size_t scratch_esteps_bytes = 0;
+  int32_t* d_spec_valid = nullptr;   // ... and whether they hold (k_cavity_flags)
   void* scratch_products = nullptr;  // lanes = samples build: piece / pair products [slot][49][Bp] float64
   size_t scratch_products_bytes = 0;
   void* scratch_coefs = nullptr;     // ... and cavity coefficients [S][8][Bp]
@@ -213,6 +216,8 @@ struct lynx_lattice {
   int32_t n_cavities = 0;
   int32_t* d_cav_words = nullptr;  // one word per cavity: the predicates OR-ed over the batch (k_cavity_flags_spec); kept zero between calls
   int2* d_cavs = nullptr;          // the cavities in lattice order: (element, its step if it is one of its own else -1)
+  int32_t* d_cav_before = nullptr;  // [S + 1]: step cavities in front of step s (StepEnergies, lynx_device.hpp)
+  int32_t n_step_cavities = 0;
   int64_t pool_count = 0;
   std::vector<lynx_elem> h_elems;
   std::vector<lynx_step> h_steps;
@@ -459,6 +464,8 @@ int lynx_ctx_create(int device, lynx_ctx** out) {
   HIP_TRY(nullptr, hipHostMalloc((void**)&ctx->h_status, 2 * sizeof(int32_t), hipHostMallocMapped));
   ctx->h_status[0] = ctx->h_status[1] = 0;
   HIP_TRY(nullptr, hipHostGetDevicePointer((void**)&ctx->d_status, ctx->h_status, 0));
+  HIP_TRY(nullptr, hipMalloc((void**)&ctx->d_spec_valid, sizeof(int32_t)));
+  HIP_TRY(nullptr, hipMemset(ctx->d_spec_valid, 0, sizeof(int32_t)));
   // the word hipStreamWaitValue32 polls: signal memory (what HIP documents for it); without it the build simply
   // starts at the head of the streaming kernel instead of in its tail
   if (hipDeviceGetAttribute(&ctx->can_wait_value, hipDeviceAttributeCanUseStreamWaitValue, device) != hipSuccess) ctx->can_wait_value = 0;
@@ -504,6 +511,8 @@ int lynx_ctx_destroy(lynx_ctx* ctx) {
   if (ctx->scratch_tickets) (void)hipFree(ctx->scratch_tickets);
   if (ctx->scratch_obs) (void)hipFree(ctx->scratch_obs);
   if (ctx->scratch_erun) (void)hipFree(ctx->scratch_erun);
+  if (ctx->scratch_esteps) (void)hipFree(ctx->scratch_esteps);
+  if (ctx->d_spec_valid) (void)hipFree(ctx->d_spec_valid);
   if (ctx->scratch_products) (void)hipFree(ctx->scratch_products);
   if (ctx->scratch_coefs) (void)hipFree(ctx->scratch_coefs);
   for (int i = 0; i < lynx_ctx::kTableSlots + 2; ++i)
@@ -898,7 +907,15 @@ int lynx_lattice_create(lynx_ctx* ctx, int dtype, int64_t batch, int32_t n_elems
       return rc;
     }
     HIP_TRY(ctx, hipMemcpyAsync(lat->d_cavs, cavs.data(), cavs.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, sync_main(ctx));  // `cavs` goes out of scope
+    std::vector<int32_t> before((size_t)n_steps + 1, 0);
+    for (int32_t s = 0; s < n_steps; ++s) before[s + 1] = before[s] + (steps[s].kind == LYNX_STEP_CAVITY ? 1 : 0);
+    lat->n_step_cavities = before[n_steps];
+    if ((rc = ctx_alloc(ctx, before.size() * sizeof(int32_t), (void**)&lat->d_cav_before))) {
+      delete lat;
+      return rc;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(lat->d_cav_before, before.data(), before.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, sync_main(ctx));  // `cavs` and `before` go out of scope
   }
   HIP_TRY(ctx, sync_main(ctx));
   memset(&lat->h_pool, 0, sizeof(lat->h_pool));
@@ -949,6 +966,7 @@ int lynx_lattice_destroy(lynx_lattice* lat) {
   ctx_free(ctx, lat->d_pool);
   if (lat->d_cav_words) ctx_free(ctx, lat->d_cav_words);
   if (lat->d_cavs) ctx_free(ctx, lat->d_cavs);
+  if (lat->d_cav_before) ctx_free(ctx, lat->d_cav_before);
   for (int32_t* p : lat->d_step_unit)
     if (p) ctx_free(ctx, p);
   if (lat->d_bwd_tasks) ctx_free(ctx, lat->d_bwd_tasks);
@@ -1008,18 +1026,26 @@ static void build_shape(lynx_ctx* ctx, const lynx_lattice* lat, bool underneath,
 // Whole-batch cavity predicates for this call's energies, on `stream`, in front of whatever builds maps
 // there (no-op for lattices without cavities).
 template <typename T>
-static int launch_cavity_flags(lynx_ctx* ctx, lynx_lattice* lat, hipStream_t stream, const void* d_energy_in) {
+static int launch_cavity_flags(lynx_ctx* ctx, lynx_lattice* lat, hipStream_t stream, const void* d_energy_in,
+                               bool for_lanes_build = false) {
   if (!lat->has_cavity || lat->n_steps == 0) return LYNX_OK;
   int rc;
   if ((rc = ensure_scratch(ctx, &ctx->scratch_erun, &ctx->scratch_erun_bytes, (size_t)lat->batch * sizeof(T)))) return rc;
+  // the lanes build reads every sample's energy in front of every step from what the first kernel computes on its way
+  const int64_t Bp = (lat->batch + 63) / 64 * 64;
+  T* e_steps = nullptr;
+  if (for_lanes_build) {
+    if ((rc = ensure_scratch(ctx, &ctx->scratch_esteps, &ctx->scratch_esteps_bytes, (size_t)(lat->n_step_cavities + 1) * Bp * sizeof(T)))) return rc;
+    e_steps = (T*)ctx->scratch_esteps;
+  }
   // the predicates for every cavity at once, assuming every batch gains energy (one lane per sample), then one small
   // workgroup that checks the assumption, publishes the bits and -- should it not hold -- walks the serial way
   hipLaunchKernelGGL(k_cavity_flags_spec<T>, dim3((unsigned)((lat->batch + 255) / 256)), dim3(256), 0, stream, dev_view(lat),
-                     lat->d_cavs, lat->n_cavities, (const T*)d_energy_in, lat->d_cav_words);
+                     lat->d_cavs, lat->n_cavities, (const T*)d_energy_in, lat->d_cav_words, e_steps, Bp);
   HIP_TRY(ctx, hipGetLastError());
   hipLaunchKernelGGL(k_cavity_flags<T>, dim3(1), dim3(256), 0, stream, dev_view(lat), lat->d_elems, lat->d_steps,
                      (const T*)d_energy_in, (T*)ctx->scratch_erun, ctx->d_status, lat->d_cavs, lat->n_cavities,
-                     lat->d_cav_words);
+                     lat->d_cav_words, e_steps ? ctx->d_spec_valid : (int32_t*)nullptr);
   HIP_TRY(ctx, hipGetLastError());
   return LYNX_OK;
 }
@@ -1090,9 +1116,10 @@ static int launch_build_lanes(lynx_ctx* ctx, lynx_lattice* lat, hipStream_t stre
   if ((rc = ensure_scratch(ctx, &ctx->scratch_coefs, &ctx->scratch_coefs_bytes, (size_t)std::max(1, lat->n_steps) * 8 * Bp * sizeof(T))))
     return rc;
   const LatticeDev lv = dev_view(lat);
+  const StepEnergies<T> se{lat->has_cavity ? (const T*)ctx->scratch_esteps : (const T*)nullptr, lat->d_cav_before, ctx->d_spec_valid, Bp};
   if ((rc = allow_lds(ctx, k_build_pieces<T>, build_pieces_lds<T>()))) return rc;
   hipLaunchKernelGGL(k_build_pieces<T>, dim3((unsigned)groups, (unsigned)lat->n_pieces), dim3(64), build_pieces_lds<T>(), stream, lv,
-                     lat->d_pieces, (const T*)d_energy_in, Bp, (double*)ctx->scratch_products, (T*)ctx->scratch_coefs);
+                     lat->d_pieces, (const T*)d_energy_in, Bp, (double*)ctx->scratch_products, (T*)ctx->scratch_coefs, se);
   HIP_TRY(ctx, hipGetLastError());
   // narrow trees (BASELINE config 4: 8, 4, 2, 1 tasks per level) in one launch: underneath a streaming kernel every
   // launch of the chain costs ~20 us, the product itself 3-6 (config 4: 0.995 -> 0.985 ms/step, same box)
@@ -1119,7 +1146,7 @@ static int launch_build_lanes(lynx_ctx* ctx, lynx_lattice* lat, hipStream_t stre
                      lat->d_step_slot, (const T*)d_energy_in, Bp, (const double*)ctx->scratch_products,
                      (const T*)ctx->scratch_coefs, merge_pairs, (T*)d_steps_out, (T*)d_energy_out,
                      d_units ? lat->d_step_unit[merge_pairs ? 1 : 0] : (const int32_t*)nullptr,
-                     lat->units[merge_pairs ? 1 : 0].n_units, d_units, d_extras);
+                     lat->units[merge_pairs ? 1 : 0].n_units, d_units, d_extras, se);
   HIP_TRY(ctx, hipGetLastError());
   return LYNX_OK;
 }
@@ -1130,13 +1157,14 @@ template <typename T>
 static int launch_build(lynx_ctx* ctx, lynx_lattice* lat, hipStream_t stream, const void* d_energy_in,
                         void* d_steps_out, void* d_energy_out, int merge_pairs = 0, bool underneath = false,
                         float* d_units = nullptr, float* d_extras = nullptr) {
-  {
-    const int rc = launch_cavity_flags<T>(ctx, lat, stream, d_energy_in);
-    if (rc) return rc;
-  }
   // large batches: lanes = samples (an order of magnitude fewer wave-instructions); small ones: one
   // workgroup per sample, whose tree is shallower than a chain of launches
-  if (lat->n_steps > 0 && lat->batch >= ctx->knobs.lanes_build_min_batch) {
+  const bool lanes = lat->n_steps > 0 && lat->batch >= ctx->knobs.lanes_build_min_batch;
+  {
+    const int rc = launch_cavity_flags<T>(ctx, lat, stream, d_energy_in, lanes);
+    if (rc) return rc;
+  }
+  if (lanes) {
     const int rc = sync_pool(ctx, lat);
     return rc ? rc : launch_build_lanes<T>(ctx, lat, stream, d_energy_in, d_steps_out, d_energy_out, merge_pairs, d_units, d_extras);
   }
