@@ -170,6 +170,9 @@ int lynx_diag_copy(lynx_ctx* ctx, void* d_dst, const void* d_src, size_t bytes, 
 /* ---- device buffers (reference: jax.Array storage behind `ParticleBeam.particles`,
  *      particle_beam.py:24-45; the Python side owns the handles) ----------------------- */
 int lynx_buf_alloc(lynx_ctx* ctx, size_t bytes, void** d_out);
+/* ... for a result the host will read back (what `track` returns of a ParameterBeam: mu, cov -- element.py:71-82; a
+ * moment record): small blocks are host memory the GPU writes through, reading them back is a wait and a memcpy */
+int lynx_buf_alloc_result(lynx_ctx* ctx, size_t bytes, void** d_out);
 int lynx_buf_free(lynx_ctx* ctx, void* d_ptr);
 int lynx_buf_h2d(lynx_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 int lynx_buf_d2h(lynx_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);

@@ -74,6 +74,7 @@ SIGNATURES = {
     "lynx_ctx_reload_knobs": (_i, [_vp]),
     "lynx_diag_copy": (_i, [_vp, _vp, _vp, _sz, _i, _i, C.POINTER(C.c_float)]),
     "lynx_buf_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
+    "lynx_buf_alloc_result": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "lynx_buf_free": (_i, [_vp, _vp]),
     "lynx_buf_h2d": (_i, [_vp, _vp, _vp, _sz]),
     "lynx_buf_d2h": (_i, [_vp, _vp, _vp, _sz]),

@@ -52,6 +52,7 @@ struct Knobs {
   int build_in_tail = 1;      // LYNX_BUILD_IN_TAIL     start the next build in the tail of the streaming kernel
   int small_inline = -1;      // LYNX_SMALL_INLINE      short calls: build, stream and reduce back to back on ONE stream, no events
   int bwd_reuse_table = 1;    // LYNX_BWD_REUSE_TABLE   the reverse pass reads the step table the forward call just built (0: builds its own)
+  int host_visible_records = 1;  // LYNX_HOST_VISIBLE_RECORDS  moment records of a few samples in host memory the GPU writes through (0: device memory)
   int inline_pool = 1;        // LYNX_INLINE_POOL       small lattices: the parameters by value in the kernel arguments (0: always from memory)
 };
 
@@ -66,7 +67,7 @@ static void load_knobs(Knobs* k) {
       {"LYNX_FUSE_MAX_CHUNKS", &k->fuse_max_chunks}, {"LYNX_MERGE_STEPS", &k->merge_steps},
       {"LYNX_REDUCE_WIDE", &k->reduce_wide}, {"LYNX_REDUCE_TICKET", &k->reduce_ticket}, {"LYNX_TRACK_UNITS", &k->track_units}, {"LYNX_BWD_UNITS", &k->bwd_units},
       {"LYNX_BWD_MERGE", &k->bwd_merge}, {"LYNX_BWD_PAIRS", &k->bwd_pairs}, {"LYNX_BUILD_IN_TAIL", &k->build_in_tail},
-      {"LYNX_SMALL_INLINE", &k->small_inline}, {"LYNX_INLINE_POOL", &k->inline_pool}, {"LYNX_BWD_REUSE_TABLE", &k->bwd_reuse_table}};
+      {"LYNX_SMALL_INLINE", &k->small_inline}, {"LYNX_INLINE_POOL", &k->inline_pool}, {"LYNX_HOST_VISIBLE_RECORDS", &k->host_visible_records}, {"LYNX_BWD_REUSE_TABLE", &k->bwd_reuse_table}};
   for (const auto& t : table) {
     const char* v = getenv(t.name);
     if (v && *v) *t.value = atoi(v);
@@ -137,6 +138,7 @@ struct lynx_ctx {
   // caching allocator: size class -> free blocks; live pointer -> size class
   std::multimap<size_t, void*> free_blocks;
   std::unordered_map<void*, size_t> live;
+  std::vector<std::pair<const char*, size_t>> host_ranges;  // the host-visible blocks there are (live or cached)
   // internal scratch (grown on demand, stream-ordered reuse)
   void* scratch_level = nullptr;  // second level of the moment reduction (long beams)
   size_t scratch_level_bytes = 0;
@@ -309,6 +311,58 @@ static size_t size_class(size_t bytes) {
   return (bytes + g - 1) / g * g;
 }
 
+// Small result blocks the host reads right after the call (a sample's moment record: 288 bytes) can live in HOST memory
+// the GPU writes through: reading them back then is a wait for the stream and a memcpy, not a copy command with a
+// round trip of its own (BASELINE config 2 with sigma_x read after every call: NOTES.md).  Same allocator, another
+// size-class name space (kHostVisible set in the class); `is_host_visible` tells lynx_buf_d2h and friends.
+constexpr size_t kHostVisible = (size_t)1 << 62;
+constexpr size_t kHostVisibleMax = 4096;
+
+// caller holds ctx->mu
+static void free_block(lynx_ctx* ctx, void* p, size_t size_class_key) {
+  if (size_class_key & kHostVisible) {
+    for (size_t i = 0; i < ctx->host_ranges.size(); ++i)
+      if (ctx->host_ranges[i].first == (const char*)p) {
+        ctx->host_ranges.erase(ctx->host_ranges.begin() + (long)i);
+        break;
+      }
+    (void)hipHostFree(p);
+  } else {
+    (void)hipFree(p);
+  }
+}
+
+static bool is_host_visible(lynx_ctx* ctx, const void* p) {
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  for (const auto& r : ctx->host_ranges)
+    if ((const char*)p >= r.first && (const char*)p < r.first + r.second) return true;
+  return false;
+}
+
+static int ctx_alloc_host_visible(lynx_ctx* ctx, size_t bytes, void** out) {
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  const size_t sc = size_class(bytes) | kHostVisible;
+  auto it = ctx->free_blocks.find(sc);
+  if (it != ctx->free_blocks.end()) {
+    *out = it->second;
+    ctx->free_blocks.erase(it);
+    ctx->live[*out] = sc;
+    return LYNX_OK;
+  }
+  void *p = nullptr, *d = nullptr;
+  hipError_t e = hipHostMalloc(&p, sc & ~kHostVisible, hipHostMallocMapped | hipHostMallocCoherent);
+  if (e == hipSuccess) e = hipHostGetDevicePointer(&d, p, 0);
+  if (e != hipSuccess || d != p) {  // (one address for both sides is what the rest of the library assumes)
+    if (p) (void)hipHostFree(p);
+    (void)hipGetLastError();
+    return fail(ctx, LYNX_ERR_NOMEM, std::string("hipHostMalloc (host-visible block): ") + hipGetErrorString(e));
+  }
+  ctx->live[p] = sc;
+  ctx->host_ranges.emplace_back((const char*)p, sc & ~kHostVisible);
+  *out = p;
+  return LYNX_OK;
+}
+
 static int ctx_alloc(lynx_ctx* ctx, size_t bytes, void** out) {
   std::lock_guard<std::mutex> lock(ctx->mu);
   const size_t sc = size_class(bytes);
@@ -323,7 +377,7 @@ static int ctx_alloc(lynx_ctx* ctx, size_t bytes, void** out) {
   hipError_t e = hipMalloc(&p, sc);
   if (e != hipSuccess) {
     // give cached blocks back and retry once
-    for (auto& kv : ctx->free_blocks) (void)hipFree(kv.second);
+    for (auto& kv : ctx->free_blocks) free_block(ctx, kv.second, kv.first);
     ctx->free_blocks.clear();
     e = hipMalloc(&p, sc);
     if (e != hipSuccess)
@@ -505,8 +559,8 @@ int lynx_ctx_destroy(lynx_ctx* ctx) {
     if (slot.buf) (void)hipFree(slot.buf);
   }
   (void)hipStreamDestroy(ctx->s_side);
-  for (auto& kv : ctx->free_blocks) (void)hipFree(kv.second);
-  for (auto& kv : ctx->live) (void)hipFree(kv.first);
+  for (auto& kv : ctx->free_blocks) free_block(ctx, kv.second, kv.first);
+  for (auto& kv : ctx->live) free_block(ctx, kv.first, kv.second);
   if (ctx->scratch_level) (void)hipFree(ctx->scratch_level);
   if (ctx->scratch_tickets) (void)hipFree(ctx->scratch_tickets);
   if (ctx->scratch_obs) (void)hipFree(ctx->scratch_obs);
@@ -721,6 +775,15 @@ int lynx_buf_alloc(lynx_ctx* ctx, size_t bytes, void** d_out) {
   return ctx_alloc(ctx, bytes, d_out);
 }
 
+// A block for a RESULT the host is going to read back (a ParameterBeam's outgoing mu and cov, a moment record): small
+// ones come from host memory the GPU writes through, so that lynx_buf_d2h is a wait and a memcpy (ctx_alloc_host_visible);
+// large ones, and all of them once the context has a communicator, are device memory like any other block.
+int lynx_buf_alloc_result(lynx_ctx* ctx, size_t bytes, void** d_out) {
+  HIP_TRY(ctx, use_device(ctx));
+  if (bytes <= kHostVisibleMax && ctx->comm_ranks == 0 && ctx->knobs.host_visible_records) return ctx_alloc_host_visible(ctx, bytes, d_out);
+  return ctx_alloc(ctx, bytes, d_out);
+}
+
 int lynx_buf_free(lynx_ctx* ctx, void* d_ptr) {
   if (ctx && d_ptr) ctx->fwd_table.written(d_ptr, 1);  // (a freed energy block may come back with other contents)
   return ctx_free(ctx, d_ptr);
@@ -729,6 +792,13 @@ int lynx_buf_free(lynx_ctx* ctx, void* d_ptr) {
 int lynx_buf_h2d(lynx_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
   if (bytes == 0) return LYNX_OK;
   ctx->fwd_table.written(d_dst, bytes);
+  if (is_host_visible(ctx, d_dst)) {  // host memory the GPU reads through: wait for whoever still uses it, then write
+    const int rc = wait_for_side(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, sync_main(ctx));
+    memcpy(d_dst, h_src, bytes);
+    return LYNX_OK;
+  }
   HIP_TRY(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, sync_main(ctx));  // h_src is pageable and may be freed
   return LYNX_OK;
@@ -739,6 +809,11 @@ int lynx_buf_d2h(lynx_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
   {
     const int rc = wait_for_side(ctx);  // the block may be a moment record or a gathered block
     if (rc) return rc;
+  }
+  if (is_host_visible(ctx, d_src)) {  // the GPU wrote it through to host memory: no copy command, just the wait
+    HIP_TRY(ctx, sync_main(ctx));
+    memcpy(h_dst, d_src, bytes);
+    return check_status(ctx);
   }
   HIP_TRY(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, sync_main(ctx));
@@ -753,7 +828,8 @@ int lynx_buf_d2d(lynx_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) {
     if (rc) return rc;
   }
   ctx->fwd_table.written(d_dst, bytes);
-  HIP_TRY(ctx, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  // (either side may be a host-visible block: the runtime works the direction out from the addresses)
+  HIP_TRY(ctx, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDefault, ctx->stream));
   ctx->main_dirty = true;
   return LYNX_OK;
 }
@@ -779,7 +855,7 @@ int lynx_pool_trim(lynx_ctx* ctx) {
     if (rc) return rc;
   }
   std::lock_guard<std::mutex> lock(ctx->mu);
-  for (auto& kv : ctx->free_blocks) (void)hipFree(kv.second);
+  for (auto& kv : ctx->free_blocks) free_block(ctx, kv.second, kv.first);
   ctx->free_blocks.clear();
   return LYNX_OK;
 }
@@ -1762,7 +1838,13 @@ int lynx_track_particles_new(lynx_ctx* ctx, lynx_lattice* lat, int64_t n_particl
   const bool moments = (flags & (LYNX_TRACK_MOMENTS | LYNX_TRACK_COVARIANCE)) != 0;
   int rc = ctx_alloc(ctx, (size_t)lat->batch * (size_t)n_particles * 7 * es, &d_out[0]);
   if (!rc && want_energy_out) rc = ctx_alloc(ctx, (size_t)lat->batch * es, &d_out[1]);
-  if (!rc && moments) rc = ctx_alloc(ctx, (size_t)lat->batch * LYNX_MOMENT_STRIDE * sizeof(double), &d_out[2]);
+  if (!rc && moments) {
+    // a few samples' records, one process: where the host reads them without a copy command (many samples, or records
+    // that RCCL gathers: device memory)
+    const size_t bytes = (size_t)lat->batch * LYNX_MOMENT_STRIDE * sizeof(double);
+    if (bytes <= kHostVisibleMax && ctx->comm_ranks == 0 && ctx->knobs.host_visible_records) rc = ctx_alloc_host_visible(ctx, bytes, &d_out[2]);
+    else rc = ctx_alloc(ctx, bytes, &d_out[2]);
+  }
   if (!rc && lat->n_observers > 0) rc = ctx_alloc(ctx, (size_t)lat->batch * lat->n_observers * 2 * sizeof(double), &d_out[3]);
   if (!rc)
     rc = lynx_track_particles(ctx, lat, n_particles, d_energy_in, d_p_in, d_out[0], d_out[1], (double*)d_out[2], flags,

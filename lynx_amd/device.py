@@ -145,6 +145,13 @@ class Runtime:
     def empty(self, shape, dtype) -> "DeviceArray":
         return DeviceArray(self, tuple(int(s) for s in shape), np.dtype(dtype))
 
+    def empty_result(self, shape, dtype) -> "DeviceArray":
+        """For what a call returns and the host reads next (`lynx_buf_alloc_result`: small blocks are host memory the GPU writes through)."""
+        shape, dtype = tuple(int(s) for s in shape), np.dtype(dtype)
+        ptr = C.c_void_p()
+        self.check(self.lib.lynx_buf_alloc_result(self.ctx, max(math.prod(shape) * dtype.itemsize, 1), C.byref(ptr)))
+        return DeviceArray.adopt(self, ptr.value, shape, dtype)
+
     def to_device(self, host) -> "DeviceArray":
         host = np.ascontiguousarray(host)
         arr = self.empty(host.shape, host.dtype)

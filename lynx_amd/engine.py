@@ -420,8 +420,8 @@ def run_program_parameters(cache, program: Program, beam):
     lat = _ready(cache, program, batch_shape, dtype, beam._energy._host)
     mu_in = beam._mu_d.device(rt)
     cov_in = beam._cov_d.device(rt)
-    mu_out = rt.empty(mu_in.shape, dtype)
-    cov_out = rt.empty(cov_in.shape, dtype)
+    mu_out = rt.empty_result(mu_in.shape, dtype)
+    cov_out = rt.empty_result(cov_in.shape, dtype)
     e_in = beam._energy.broadcast_device(rt, batch_shape)
     e_out = rt.empty(batch_shape, dtype) if lat.has_cavity_step else None
     rt.check(rt.lib.lynx_track_moments(rt.ctx, lat.handle, _ptr(e_in), _ptr(mu_in), _ptr(cov_in),
