@@ -101,6 +101,7 @@ struct lynx_ctx {
   // sync_main, cleared by every entry point that enqueues): asking the runtime -- hipStreamQuery -- puts a marker
   // packet into the queue whose release costs the next kernel ~5 us behind a kernel that left dirty lines in L2.
   bool main_idle = true;
+  bool plain_events = false;  // events with HIP's default (system-scope) fence: jobs of more than one rank
   // The step table (and unit records) the latest forward call built, for a reverse pass that follows it directly on the
   // same lattice, incoming energy and merge form: it reads them instead of building its own (BASELINE config 5: 80 us
   // of 2.27 ms).  Good while no later call has taken a table slot (`seq`), the lattice has not been written to
@@ -294,8 +295,14 @@ static hipError_t use_device(lynx_ctx* ctx) {
 // synchronisation of their own, and RCCL fences what it sends.  Same box, alternating (scripts/gpu/r4/evscope.sh):
 // BASELINE config 3 49.7-50.7 -> 47.0 us/step, the 128-sample shard of config 4 139.8-140.8 -> 135.8-136.2, config 3
 // at 8 M particles 170.8-174.8 -> 168.5; hipEventReleaseToDevice instead: no change.
-static unsigned sync_event_flags() { return hipEventDisableTiming | hipEventDisableSystemFence; }
-static unsigned timing_event_flags() { return hipEventDefault | hipEventDisableSystemFence; }
+// With MORE THAN ONE RANK the events keep HIP's default: there a recorded event may also stand between RCCL's traffic from
+// other devices and whoever reads it next, and none of that has run on hardware the builder had (lynx_ctx::plain_events).
+static unsigned sync_event_flags(const lynx_ctx* ctx) {
+  return hipEventDisableTiming | (ctx->plain_events ? 0u : (unsigned)hipEventDisableSystemFence);
+}
+static unsigned timing_event_flags(const lynx_ctx* ctx) {
+  return hipEventDefault | (ctx->plain_events ? 0u : (unsigned)hipEventDisableSystemFence);
+}
 
 static hipError_t sync_main(lynx_ctx* ctx) {
   const hipError_t e = hipStreamSynchronize(ctx->stream);
@@ -481,6 +488,31 @@ int lynx_device_count(int* count) {
   return LYNX_OK;
 }
 
+// the context's own inter-stream events (again, with other flags, when a communicator of more than one rank arrives)
+static int make_sync_events(lynx_ctx* ctx) {
+  const auto make = [&](hipEvent_t* e) -> hipError_t {
+    if (*e) (void)hipEventDestroy(*e);
+    *e = nullptr;
+    return hipEventCreateWithFlags(e, sync_event_flags(ctx));
+  };
+  HIP_TRY(ctx, make(&ctx->ev_side_in));
+  HIP_TRY(ctx, make(&ctx->ev_main_mark));
+  for (auto& slot : ctx->partial_ring) {
+    HIP_TRY(ctx, make(&slot.track_done));
+    HIP_TRY(ctx, make(&slot.reduced));
+    slot.pending = false;
+  }
+  for (int i = 0; i < lynx_ctx::kTableSlots; ++i) {
+    HIP_TRY(ctx, make(&ctx->ev_built[i]));
+    HIP_TRY(ctx, make(&ctx->ev_streamed_own[i]));
+    ctx->streamed_valid[i] = false;
+  }
+  HIP_TRY(ctx, make(&ctx->ev_mark));
+  for (hipEvent_t e : ctx->side_events) (void)hipEventDestroy(e);  // idle "done" events: made again on demand
+  ctx->side_events.clear();
+  return LYNX_OK;
+}
+
 int lynx_ctx_create(int device, lynx_ctx** out) {
   *out = nullptr;
   int n = 0;
@@ -502,17 +534,12 @@ int lynx_ctx_create(int device, lynx_ctx** out) {
     HIP_TRY(nullptr, hipStreamCreateWithPriority(&ctx->s_build, hipStreamNonBlocking, prio_high));
     HIP_TRY(nullptr, hipStreamCreateWithPriority(&ctx->s_side, hipStreamNonBlocking, prio_high));
   }
-  HIP_TRY(nullptr, hipEventCreateWithFlags(&ctx->ev_side_in, sync_event_flags()));
-  HIP_TRY(nullptr, hipEventCreateWithFlags(&ctx->ev_main_mark, sync_event_flags()));
-  for (auto& slot : ctx->partial_ring) {
-    HIP_TRY(nullptr, hipEventCreateWithFlags(&slot.track_done, sync_event_flags()));
-    HIP_TRY(nullptr, hipEventCreateWithFlags(&slot.reduced, sync_event_flags()));
+  {
+    const char* world = getenv("WORLD_SIZE");  // (the launcher's; lynx_comm_init looks again)
+    ctx->plain_events = world && atoi(world) > 1;
+    const int rc = make_sync_events(ctx);
+    if (rc) return rc;
   }
-  for (int i = 0; i < lynx_ctx::kTableSlots; ++i) {
-    HIP_TRY(nullptr, hipEventCreateWithFlags(&ctx->ev_built[i], sync_event_flags()));
-    HIP_TRY(nullptr, hipEventCreateWithFlags(&ctx->ev_streamed_own[i], sync_event_flags()));
-  }
-  HIP_TRY(nullptr, hipEventCreateWithFlags(&ctx->ev_mark, sync_event_flags()));
   HIP_TRY(nullptr, hipEventCreate(&ctx->ev_start));
   HIP_TRY(nullptr, hipEventCreate(&ctx->ev_stop));
   HIP_TRY(nullptr, hipHostMalloc((void**)&ctx->h_status, 2 * sizeof(int32_t), hipHostMallocMapped));
@@ -635,7 +662,7 @@ static int side_event(lynx_ctx* ctx, hipEvent_t* out) {
       ctx->side_events.pop_back();
     }
   }
-  if (!*out) HIP_TRY(ctx, hipEventCreateWithFlags(out, sync_event_flags()));
+  if (!*out) HIP_TRY(ctx, hipEventCreateWithFlags(out, sync_event_flags(ctx)));
   return LYNX_OK;
 }
 
@@ -1384,8 +1411,8 @@ static int launch_direct_inst(lynx_ctx* ctx, const TrackPlan& p, const LatticeDe
   // kernel's duration.
   hipEvent_t e0 = nullptr, e1 = p.done;
   if (ctx->profiling) {  // every profiled launch needs time stamps of its own
-    HIP_TRY(ctx, hipEventCreateWithFlags(&e0, timing_event_flags()));
-    HIP_TRY(ctx, hipEventCreateWithFlags(&e1, timing_event_flags()));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&e0, timing_event_flags(ctx)));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&e1, timing_event_flags(ctx)));
   }
   hipExtLaunchKernelGGL((k_track_direct<T, MOM, FULL, UNROLL, FUSED, XPOSE>), dim3(p.grid), dim3(kTrackThreads),
                         (std::uint32_t)p.lds, ctx->stream, e0, e1, 0u, lv, p.a, (const T*)d_energy_in, (const T*)d_p_in,
@@ -1510,8 +1537,8 @@ static int launch_units_inst(lynx_ctx* ctx, const TrackPlan& p, int32_t U, int32
   if (rc) return rc;
   hipEvent_t e0 = nullptr, e1 = p.done;
   if (ctx->profiling) {  // every profiled launch needs time stamps of its own
-    HIP_TRY(ctx, hipEventCreateWithFlags(&e0, timing_event_flags()));
-    HIP_TRY(ctx, hipEventCreateWithFlags(&e1, timing_event_flags()));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&e0, timing_event_flags(ctx)));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&e1, timing_event_flags(ctx)));
   }
   hipExtLaunchKernelGGL((k_track_units<MOM, FULL, PAIRS>), dim3(p.grid), dim3(kTrackThreads), (std::uint32_t)lds, ctx->stream, e0, e1,
                         0u, p.a, U, S, (const float*)d_p_in, (float*)d_p_out, (float*)d_energy_out, (const float*)d_steps,
@@ -2372,6 +2399,19 @@ int lynx_comm_init(lynx_ctx* ctx, int n_ranks, int rank, const char* id) {
   memcpy(&uid, id, sizeof(uid));
   NCCL_TRY(ctx, ncclCommInitRank(&ctx->comm, n_ranks, uid, rank));
   ctx->comm_ranks = n_ranks;
+  if (n_ranks > 1 && !ctx->plain_events) {  // (a job that did not say WORLD_SIZE: its events get HIP's default fence now)
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->s_build));
+    HIP_TRY(ctx, sync_main(ctx));
+    const int rc = wait_for_side(ctx);
+    if (rc) return rc;
+    {
+      std::lock_guard<std::mutex> lock(ctx->mu);
+      retire_side_ops(ctx, true);
+    }
+    ctx->plain_events = true;
+    ctx->last_stream_stop = nullptr;
+    return make_sync_events(ctx);
+  }
   return LYNX_OK;
 }
 
@@ -2416,8 +2456,8 @@ int lynx_gather_moments(lynx_ctx* ctx, const double* d_send, double* d_recv, int
     if (rc) return rc;
     hipEvent_t g0 = nullptr, g1 = nullptr;
     if (ctx->profiling) {
-      HIP_TRY(ctx, hipEventCreateWithFlags(&g0, timing_event_flags()));
-      HIP_TRY(ctx, hipEventCreateWithFlags(&g1, timing_event_flags()));
+      HIP_TRY(ctx, hipEventCreateWithFlags(&g0, timing_event_flags(ctx)));
+      HIP_TRY(ctx, hipEventCreateWithFlags(&g1, timing_event_flags(ctx)));
       HIP_TRY(ctx, hipEventRecord(g0, ctx->stream));
     }
     NCCL_TRY(ctx, ncclAllGather(d_send, d_recv, (size_t)count, ncclDouble, ctx->comm, ctx->stream));
@@ -2445,8 +2485,8 @@ int lynx_gather_moments(lynx_ctx* ctx, const double* d_send, double* d_recv, int
   if (rc) return rc;
   hipEvent_t g0 = nullptr, g1 = nullptr;
   if (ctx->profiling) {  // the gather's own duration on its stream (bench.py at N > 1: how long a rank waits for the others)
-    HIP_TRY(ctx, hipEventCreateWithFlags(&g0, timing_event_flags()));
-    HIP_TRY(ctx, hipEventCreateWithFlags(&g1, timing_event_flags()));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&g0, timing_event_flags(ctx)));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&g1, timing_event_flags(ctx)));
     HIP_TRY(ctx, hipEventRecord(g0, ctx->s_side));
   }
   NCCL_TRY(ctx, ncclAllGather(d_send, d_recv, (size_t)count, ncclDouble, ctx->comm, ctx->s_side));
