@@ -536,7 +536,8 @@ int lynx_ctx_create(int device, lynx_ctx** out) {
   }
   {
     const char* world = getenv("WORLD_SIZE");  // (the launcher's; lynx_comm_init looks again)
-    ctx->plain_events = world && atoi(world) > 1;
+    const char* plain = getenv("LYNX_PLAIN_EVENTS");  // (one rank's share of a job rehearsed in a process of its own)
+    ctx->plain_events = (world && atoi(world) > 1) || (plain && atoi(plain) != 0);
     const int rc = make_sync_events(ctx);
     if (rc) return rc;
   }

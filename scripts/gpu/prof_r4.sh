@@ -25,7 +25,7 @@ done
 PYTHONPATH=$GRAFT_REPO_ROOT timeout -k 10 300 python scripts/gpu/latency.py > $OUT/latency_table.json 2> $OUT/latency_table.err
 echo "progress: bench lines done"
 for rep in 1 2 3; do for b in 1024 512 256 128; do
-  LYNX_FORCE_COMM=1 timeout -k 10 200 python bench.py --no-cpu-baseline --batch $b --steps 60 --warmup 5 > $OUT/shard_b${b}_$rep.json 2> $OUT/shard_b${b}_$rep.err
+  LYNX_FORCE_COMM=1 LYNX_PLAIN_EVENTS=1 timeout -k 10 200 python bench.py --no-cpu-baseline --batch $b --steps 60 --warmup 5 > $OUT/shard_b${b}_$rep.json 2> $OUT/shard_b${b}_$rep.err
 done; done
 for un in 1 0; do
   LYNX_TRACK_UNITS=$un timeout -k 10 200 python bench.py --workload c5 --steps 40 --warmup 5 --no-cpu-baseline > $OUT/c5_units$un.json 2> $OUT/c5_units$un.err
