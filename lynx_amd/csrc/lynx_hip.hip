@@ -1064,6 +1064,7 @@ int lynx_lattice_set_flags(lynx_lattice* lat, const int32_t* elem_flags, const i
 int lynx_lattice_destroy(lynx_lattice* lat) {
   if (!lat) return LYNX_OK;
   lynx_ctx* ctx = lat->ctx;
+  if (ctx->fwd_table.lat == lat) ctx->fwd_table.valid = false;  // (the next lattice may get this address)
   ctx_free(ctx, lat->d_elems);
   ctx_free(ctx, lat->d_steps);
   ctx_free(ctx, lat->d_elem_step);
