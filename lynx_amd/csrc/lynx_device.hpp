@@ -1216,6 +1216,7 @@ struct TrackArgs {
   int32_t tail_wg;
   unsigned int* tail_flag;
   int32_t stash_offset;  // merged tables: byte offset in LDS of the lanes' four-float stashes (kEntryStash), 16-byte aligned
+  int32_t reversed;      // 1: the workgroups walk the batch from its end (see track_particles_t: every other long call)
 };
 
 __device__ __forceinline__ void announce_tail(const TrackArgs& a) {
@@ -1736,8 +1737,9 @@ __global__ __launch_bounds__(kTrackThreads, (track_waves_per_simd<T, MOM, FULL, 
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
-  const int64_t b = blockIdx.x / a.chunks;
-  const int chunk = blockIdx.x % a.chunks;
+  const unsigned wg = a.reversed ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
+  const int64_t b = wg / a.chunks;
+  const int chunk = wg % a.chunks;
   const int64_t end = a.n_particles;
   const int S = lat.n_steps;
   // This workgroup's `a.tiles_per_wg` tiles of 256*UNROLL particles: one contiguous stretch (taking every

@@ -53,6 +53,7 @@ struct Knobs {
   int small_inline = -1;      // LYNX_SMALL_INLINE      short calls: build, stream and reduce back to back on ONE stream, no events
   int bwd_reuse_table = 1;    // LYNX_BWD_REUSE_TABLE   the reverse pass reads the step table the forward call just built (0: builds its own)
   int host_visible_records = 1;  // LYNX_HOST_VISIBLE_RECORDS  moment records of a few samples in host memory the GPU writes through (0: device memory)
+  int alternate_order = 1;    // LYNX_ALTERNATE_ORDER   long calls walk the batch forwards and backwards in turn (0: always forwards, 2: every call backwards)
   int inline_pool = 1;        // LYNX_INLINE_POOL       small lattices: the parameters by value in the kernel arguments (0: always from memory)
 };
 
@@ -67,7 +68,7 @@ static void load_knobs(Knobs* k) {
       {"LYNX_FUSE_MAX_CHUNKS", &k->fuse_max_chunks}, {"LYNX_MERGE_STEPS", &k->merge_steps},
       {"LYNX_REDUCE_WIDE", &k->reduce_wide}, {"LYNX_REDUCE_TICKET", &k->reduce_ticket}, {"LYNX_TRACK_UNITS", &k->track_units}, {"LYNX_BWD_UNITS", &k->bwd_units},
       {"LYNX_BWD_MERGE", &k->bwd_merge}, {"LYNX_BWD_PAIRS", &k->bwd_pairs}, {"LYNX_BUILD_IN_TAIL", &k->build_in_tail},
-      {"LYNX_SMALL_INLINE", &k->small_inline}, {"LYNX_INLINE_POOL", &k->inline_pool}, {"LYNX_HOST_VISIBLE_RECORDS", &k->host_visible_records}, {"LYNX_BWD_REUSE_TABLE", &k->bwd_reuse_table}};
+      {"LYNX_SMALL_INLINE", &k->small_inline}, {"LYNX_INLINE_POOL", &k->inline_pool}, {"LYNX_ALTERNATE_ORDER", &k->alternate_order}, {"LYNX_HOST_VISIBLE_RECORDS", &k->host_visible_records}, {"LYNX_BWD_REUSE_TABLE", &k->bwd_reuse_table}};
   for (const auto& t : table) {
     const char* v = getenv(t.name);
     if (v && *v) *t.value = atoi(v);
@@ -102,6 +103,7 @@ struct lynx_ctx {
   // packet into the queue whose release costs the next kernel ~5 us behind a kernel that left dirty lines in L2.
   bool main_idle = true;
   bool plain_events = false;  // events with HIP's default (system-scope) fence: jobs of more than one rank
+  unsigned long_calls = 0;    // streaming launches of 256 MB and more so far (TrackArgs::reversed)
   // The step table (and unit records) the latest forward call built, for a reverse pass that follows it directly on the
   // same lattice, incoming energy and merge form: it reads them instead of building its own (BASELINE config 5: 80 us
   // of 2.27 ms).  Good while no later call has taken a table slot (`seq`), the lattice has not been written to
@@ -1350,6 +1352,7 @@ static TrackPlan plan_track(lynx_ctx* ctx, const lynx_lattice* lat, int64_t B, i
   p.a.tail_seq = 0;
   p.a.tail_wg = 0;
   p.a.stash_offset = 0;
+  p.a.reversed = 0;
   // wave tiles: with non-temporal full-width stores +7 % on single-map float32 programs (BASELINE config 4:
   // 5.4 -> 5.8 TB/s) and +10 % (+7 % of that from the stores) on float64 (config 3 at 8 M particles); slower on
   // multi-step float32 programs, which want two particles per lane, not four
@@ -1741,6 +1744,13 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
     p.a.tail_seq = ++ctx->tail_seq;
     p.a.tail_wg = (int32_t)std::max<int64_t>(0, (int64_t)p.grid - 4 * cus);
   }
+  // Every other LONG call walks the batch from its end: what the previous pass left in the 256 MB Infinity Cache -- the
+  // end of its incoming beam -- is then what this one reads first, if it is the same beam again (the optimisation loop:
+  // one incoming beam, new settings every step).  BASELINE config 3 at 8 M particles (448 MB in): 171 -> 161.5 us/step;
+  // config 4 (2.87 GB in): 980.6 -> 972.  Same workgroups, same records, another order of dispatch.
+  if (!use_units && ctx->knobs.alternate_order &&
+      (ctx->knobs.alternate_order == 2 || (size_t)B * N * 7 * sizeof(T) >= ((size_t)256 << 20)))
+    p.a.reversed = ctx->knobs.alternate_order == 2 ? 1 : (int32_t)(ctx->long_calls++ & 1u);
   p.done = (slot >= 0 && async_build) ? ctx->ev_streamed_own[slot] : nullptr;
   if (side && !p.done) p.done = ring->track_done;  // the side stream's reduction starts behind it
   if (use_units) rc = launch_units(ctx, p, n_units, S, d_p_in, d_p_out, d_energy_out, d_steps, d_units, d_extras, d_partials, moments);

@@ -1119,6 +1119,7 @@ VARIANTS = [
     {"LYNX_FUSE_MAX_CHUNKS": "64", "LYNX_UNROLL": "1"}, {"LYNX_MIN_TILES_PER_WG": "1"}, {"LYNX_MERGE_STEPS": "0"},
     {"LYNX_SIDE_REDUCE": "1"}, {"LYNX_ASYNC_BUILD": "1", "LYNX_BUILD_HOST_WAIT": "1"}, {"LYNX_BUILD_IN_TAIL": "0", "LYNX_ASYNC_BUILD": "1"},
     {"LYNX_SMALL_INLINE": "0"}, {"LYNX_SMALL_INLINE": "1"},
+    {"LYNX_ALTERNATE_ORDER": "2", "LYNX_UNROLL": "1"}, {"LYNX_ALTERNATE_ORDER": "2", "LYNX_TRACK_UNITS": "0"},
 ]
 
 
@@ -1905,6 +1906,30 @@ def test_small_results_live_in_host_memory_the_gpu_writes_through(lx, dtype, mon
     device = everything()
     for a, b, c in zip(through, again, device):
         assert np.array_equal(a, b, equal_nan=True) and np.array_equal(a, c, equal_nan=True)
+
+
+@pytest.mark.parametrize("dtype,n", [(np.float32, 40_000), (np.float32, 40_003), (np.float64, 20_001)])
+def test_the_order_the_workgroups_walk_the_batch_in_changes_nothing(lx, dtype, n, monkeypatch):
+    """
+    Long calls (256 MB of particles and more) walk the batch forwards and backwards in turn, so that a pass over the
+    same incoming beam starts with what the previous one left in the Infinity Cache (TrackArgs::reversed).  The same
+    workgroups write the same particles and the same records: bit for bit (LYNX_ALTERNATE_ORDER=2 reverses every call,
+    whatever its size; 0 never does).
+    """
+    B = 7
+    scale = 0.5 + np.arange(B) / (B - 1)
+    f = lambda v: np.full(B, v)  # noqa: E731
+    desc = []
+    for _ in range(4):
+        desc += [("quadrupole", dict(length=f(0.2), k1=4.2 * scale)), ("drift", dict(length=f(0.5))),
+                 ("quadrupole", dict(length=f(0.2), k1=-4.2 * scale)), ("drift", dict(length=f(0.5)))]
+    results = []
+    for order in ("0", "2"):
+        monkeypatch.setenv("LYNX_ALTERNATE_ORDER", order)
+        out, ref = _particle_case(lx, desc, dtype, (B,), n, seed=4)
+        results.append((np.asarray(out.particles), out.moment_record().copy()))
+    _assert_moments(out, ref, dtype)
+    assert np.array_equal(results[0][0], results[1][0]) and np.array_equal(results[0][1], results[1][1], equal_nan=True)
 
 
 def test_attribute_writes_between_tracks_take_effect(lx):
