@@ -804,15 +804,36 @@ __global__ __launch_bounds__(64) void k_moments_bwd(LatticeDev lat, const T* __r
   if (lane < 49) grad_cov_in[b * 49 + lane] = s_g[lane];
 }
 
-// partials [B][chunks][S][64] -> tbar [B][S][64]; one 64-thread workgroup per (sample, step)
+// partials [B][chunks][S][64] -> tbar [B][S][64]; one workgroup per (sample, step): one wave when a sample has a few
+// chunks (large batches), four waves that take every fourth chunk each -- eight loads in flight per lane -- when it has
+// many (one sample of 100 000 particles has 196: the single wave's chain of dependent loads took 41 us of a 145 us
+// optimisation step).  Float64 sums, the waves' shares added in wave order: deterministic.
 template <typename T>
-__global__ __launch_bounds__(64) void k_reduce_tbar(const T* __restrict__ partials, int chunks, int S,
-                                                     T* __restrict__ tbar) {
+__global__ __launch_bounds__(256) void k_reduce_tbar(const T* __restrict__ partials, int chunks, int S,
+                                                      T* __restrict__ tbar) {
+  __shared__ double s_part[4][64];
   const int64_t b = blockIdx.x / S;
   const int s = blockIdx.x % S;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+  const T* src = partials + ((b * chunks) * S + s) * (int64_t)kGradStride + lane;
+  const int64_t pitch = (int64_t)S * kGradStride;
   double v = 0.0;
-  for (int c = 0; c < chunks; ++c) v += (double)partials[((b * chunks + c) * S + s) * (int64_t)kGradStride + lane];
+  int c = wave;
+  for (; c + 7 * waves < chunks; c += 8 * waves) {
+    T x[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = src[(int64_t)(c + k * waves) * pitch];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v += (double)x[k];
+  }
+  for (; c < chunks; c += waves) v += (double)src[(int64_t)c * pitch];
+  if (waves > 1) {
+    s_part[wave][lane] = v;
+    __syncthreads();
+    if (wave != 0) return;
+    v = s_part[0][lane];
+    for (int w = 1; w < waves; ++w) v += s_part[w][lane];
+  }
   tbar[(b * S + s) * (int64_t)kGradStride + lane] = (T)v;
 }
 
@@ -827,11 +848,11 @@ template <typename T> inline size_t build_bwd_lds_fixed(int S, int E) {
 //   scratch (HBM, per sample): maps [E][49] and prefix/M_bar [E+1][49]
 // ---------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void k_build_bwd(LatticeDev lat, const T* __restrict__ energy_in,
-                                                    T* tbar, T* __restrict__ scratch,
-                                                    T* __restrict__ grad_params /* [B][E][8] */,
-                                                    T* __restrict__ grad_energy /* [B] */, int merged_pairs,
-                                                    int maps_in_lds, const unsigned short* __restrict__ tasks, int n_tasks) {
+__device__ __forceinline__ void build_bwd_sample(const LatticeDev& lat, const T* __restrict__ energy_in,
+                                                 T* tbar, T* __restrict__ scratch,
+                                                 T* __restrict__ grad_params /* [B][E][8] */,
+                                                 T* __restrict__ grad_energy /* [B] */, int merged_pairs,
+                                                 int maps_in_lds, const unsigned short* __restrict__ tasks, int n_tasks) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int E = lat.n_elems, S = lat.n_steps;
   T* s_energy = reinterpret_cast<T*>(smem_raw);  // [S+1]
@@ -1075,6 +1096,26 @@ __global__ __launch_bounds__(256) void k_build_bwd(LatticeDev lat, const T* __re
       gp[2] += carry * (-p[1] * t_sin(phi)) * T(LYNX_PI / 180.0);    // dE_out/dphase[deg]
     }
   }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_build_bwd(LatticeDev lat, const T* __restrict__ energy_in,
+                                                    T* tbar, T* __restrict__ scratch, T* __restrict__ grad_params,
+                                                    T* __restrict__ grad_energy, int merged_pairs, int maps_in_lds,
+                                                    const unsigned short* __restrict__ tasks, int n_tasks) {
+  build_bwd_sample<T>(lat, energy_in, tbar, scratch, grad_params, grad_energy, merged_pairs, maps_in_lds, tasks, n_tasks);
+}
+
+// ... of a small lattice, whose parameters come with the arguments (InlinePool, lynx_device.hpp): a reverse pass right behind
+// a parameter write does not have to bring the pool in HBM up to date first
+template <typename T, int BYTES>
+__global__ __launch_bounds__(256) void k_build_bwd_inline(InlinePool<BYTES> /* read in place: inline_pool_view */, LatticeDev lat,
+                                                           const T* __restrict__ energy_in, T* tbar, T* __restrict__ scratch,
+                                                           T* __restrict__ grad_params, T* __restrict__ grad_energy,
+                                                           int merged_pairs, int maps_in_lds,
+                                                           const unsigned short* __restrict__ tasks, int n_tasks) {
+  build_bwd_sample<T>(inline_pool_view(lat), energy_in, tbar, scratch, grad_params, grad_energy, merged_pairs, maps_in_lds, tasks,
+                      n_tasks);
 }
 
 }  // namespace lynx

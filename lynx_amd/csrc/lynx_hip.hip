@@ -1936,7 +1936,9 @@ static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const v
   const int64_t B = lat->batch;
   const int32_t S = lat->n_steps, E = lat->n_elems;
   int rc;
-  if ((rc = sync_pool(ctx, lat))) return rc;  // (k_build_bwd reads the parameters from memory)
+  // (k_build_bwd reads the parameters: from its arguments if the lattice's pool travels there, from memory otherwise)
+  const bool pool_in_args = lat->prog_pool && ctx->knobs.inline_pool != 0;
+  if (!pool_in_args && (rc = sync_pool(ctx, lat))) return rc;
   // forward step tables; packed float32 pairs walk [run, cavity] pairs in the merged form of the forward
   // kernel (LYNX_BWD_MERGE=0: every step on its own), k_build_bwd takes the cotangents apart again
   constexpr int W = LaneOf<Z>::W;
@@ -1987,14 +1989,22 @@ static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const v
   // read them where they are -- and make the slot's next build wait for this reverse pass too
   const lynx_ctx::FwdTable& ft = ctx->fwd_table;
   const bool reuse = ctx->knobs.bwd_reuse_table && ft.valid && ft.lat == lat && ft.version == lat->version &&
-                     ft.energy == d_energy_in && ft.seq == ctx->seq && ft.merged == merged && (!d_units || ft.units) &&
+                     ft.energy == d_energy_in && ft.seq == ctx->seq && ft.merged == merged &&
                      ctx->scratch_steps_bytes[ft.slot] >= steps_bytes;
   const void* d_table = ctx->scratch_steps[lynx_ctx::kTableBwd];
   if (reuse) {
     d_table = ctx->scratch_steps[ft.slot];
-    if (d_units) {
+    if (d_units && ft.units) {
       d_units = (float*)ctx->scratch_units[ft.slot];
       d_extras = (float*)ctx->scratch_units[lynx_ctx::kTableSlots + ft.slot];
+    } else if (d_units) {  // the forward call walked the table itself (a single-map program): the records from its rows
+      if constexpr (sizeof(T) == 4) {
+        const UnitPlan& up = lat->units[merged ? 1 : 0];
+        const int64_t n = B * up.n_units;
+        hipLaunchKernelGGL(k_pack_units, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, up, B, S,
+                           (const float*)d_table, d_units, d_extras);
+        HIP_TRY(ctx, hipGetLastError());
+      }
     }
   } else if ((rc = launch_build<T>(ctx, lat, ctx->stream, d_energy_in, ctx->scratch_steps[lynx_ctx::kTableBwd], nullptr, merged, false,
                                    d_units, d_extras))) {
@@ -2047,8 +2057,8 @@ static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const v
                      (T*)ctx->scratch_grad[0], (T*)d_grad_p_in, (const float*)d_units, kUnitStride, kUnitClassShift, (int)kClassU,
                      d_grad_observations);
   HIP_TRY(ctx, hipGetLastError());
-  hipLaunchKernelGGL(k_reduce_tbar<T>, dim3((unsigned)(B * S)), dim3(64), 0, ctx->stream, (const T*)ctx->scratch_grad[0],
-                     (int)chunks, (int)S, (T*)ctx->scratch_grad[1]);
+  hipLaunchKernelGGL(k_reduce_tbar<T>, dim3((unsigned)(B * S)), dim3(chunks >= 16 ? 256 : 64), 0, ctx->stream,
+                     (const T*)ctx->scratch_grad[0], (int)chunks, (int)S, (T*)ctx->scratch_grad[1]);
   HIP_TRY(ctx, hipGetLastError());
   if constexpr (W == 2) {
     if (d_units) {  // class-U samples: the units' transverse blocks from the sample's S_x, S_y (lynx_grad_units.hpp)
@@ -2068,11 +2078,24 @@ static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const v
   if ((rc = ensure_bwd_tasks(ctx, lat))) return rc;
   const int maps_in_lds = lds2 + maps_bytes <= kBwdMapsLdsBytes;
   if (maps_in_lds) lds2 += maps_bytes;
-  if ((rc = allow_lds(ctx, k_build_bwd<T>, lds2))) return rc;
   HIP_TRY(ctx, hipMemsetAsync(d_grad_params, 0, (size_t)B * E * kGradParams * sizeof(T), ctx->stream));
-  hipLaunchKernelGGL(k_build_bwd<T>, dim3((unsigned)B), dim3(256), lds2, ctx->stream, lv, (const T*)d_energy_in,
-                     (T*)ctx->scratch_grad[1], (T*)ctx->scratch_grad[2], (T*)d_grad_params, (T*)d_grad_energy_in, merged,
-                     maps_in_lds, lat->d_bwd_tasks, lat->n_bwd_tasks);
+  if (pool_in_args && (size_t)lat->pool_count * sizeof(T) <= (size_t)kInlinePoolSmall) {
+    if ((rc = allow_lds(ctx, k_build_bwd_inline<T, kInlinePoolSmall>, lds2))) return rc;
+    hipLaunchKernelGGL((k_build_bwd_inline<T, kInlinePoolSmall>), dim3((unsigned)B), dim3(256), lds2, ctx->stream,
+                       *reinterpret_cast<const InlinePool<kInlinePoolSmall>*>(&lat->h_pool), lv, (const T*)d_energy_in,
+                       (T*)ctx->scratch_grad[1], (T*)ctx->scratch_grad[2], (T*)d_grad_params, (T*)d_grad_energy_in, merged,
+                       maps_in_lds, lat->d_bwd_tasks, lat->n_bwd_tasks);
+  } else if (pool_in_args) {
+    if ((rc = allow_lds(ctx, k_build_bwd_inline<T, kInlinePoolLarge>, lds2))) return rc;
+    hipLaunchKernelGGL((k_build_bwd_inline<T, kInlinePoolLarge>), dim3((unsigned)B), dim3(256), lds2, ctx->stream, lat->h_pool, lv,
+                       (const T*)d_energy_in, (T*)ctx->scratch_grad[1], (T*)ctx->scratch_grad[2], (T*)d_grad_params,
+                       (T*)d_grad_energy_in, merged, maps_in_lds, lat->d_bwd_tasks, lat->n_bwd_tasks);
+  } else {
+    if ((rc = allow_lds(ctx, k_build_bwd<T>, lds2))) return rc;
+    hipLaunchKernelGGL(k_build_bwd<T>, dim3((unsigned)B), dim3(256), lds2, ctx->stream, lv, (const T*)d_energy_in,
+                       (T*)ctx->scratch_grad[1], (T*)ctx->scratch_grad[2], (T*)d_grad_params, (T*)d_grad_energy_in, merged,
+                       maps_in_lds, lat->d_bwd_tasks, lat->n_bwd_tasks);
+  }
   HIP_TRY(ctx, hipGetLastError());
   return LYNX_OK;
 }

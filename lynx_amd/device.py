@@ -152,6 +152,14 @@ class Runtime:
         self.check(self.lib.lynx_buf_alloc_result(self.ctx, max(math.prod(shape) * dtype.itemsize, 1), C.byref(ptr)))
         return DeviceArray.adopt(self, ptr.value, shape, dtype)
 
+    def to_device_result(self, host) -> "DeviceArray":
+        """`to_device` into a block of `empty_result`: a small array the host has just made and the next call reads once (cotangents)."""
+        host = np.ascontiguousarray(host)
+        arr = self.empty_result(host.shape, host.dtype)
+        if host.nbytes:
+            self.check(self.lib.lynx_buf_h2d(self.ctx, arr.ptr, host.ctypes.data, host.nbytes))
+        return arr
+
     def to_device(self, host) -> "DeviceArray":
         host = np.ascontiguousarray(host)
         arr = self.empty(host.shape, host.dtype)

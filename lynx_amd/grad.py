@@ -211,14 +211,15 @@ class TrackVJP:
                     rec[:, _tri(i, j)] = G[:, i, j] + G[:, j, i]
         lat = engine._ready(self.cache, program, batch_shape, dtype, beam._energy._host)
         E = lat.E
-        g_rec = rt.to_device(rec)
-        g_par = rt.empty((B, max(E, 1), 8), dtype)
-        g_en = rt.empty((B,), dtype)
+        # (cotangents in and gradients out: small ones live in host memory the GPU reads and writes through)
+        g_rec = rt.to_device_result(rec)
+        g_par = rt.empty_result((B, max(E, 1), 8), dtype)
+        g_en = rt.empty_result((B,), dtype)
         g_p = rt.empty((*batch_shape, beam.num_particles, 7), dtype) if wrt_particles else None
         fwd = self.outgoing._moments.device(rt)
         e_in = beam._energy.broadcast_device(rt, batch_shape)
         obs_bar = _reading_cotangents(program, readings, batch_shape)
-        g_obs = None if obs_bar is None else rt.to_device(obs_bar)  # (named: alive until the call has been enqueued)
+        g_obs = None if obs_bar is None else rt.to_device_result(obs_bar)  # (named: alive until the call has been enqueued)
         rt.check(rt.lib.lynx_track_particles_backward(
             rt.ctx, lat.handle, beam.num_particles, C.c_void_p(e_in.ptr), C.c_void_p(beam._particles.device(rt).ptr),
             C.c_void_p(fwd.ptr), C.c_void_p(g_rec.ptr), C.c_void_p(g_par.ptr), C.c_void_p(g_en.ptr),

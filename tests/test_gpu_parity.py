@@ -12,7 +12,7 @@ import pytest
 
 from oracle import lynx_oracle as o
 
-from .helpers import (assert_parameter_beam, make_lattice, map_err, moment_distances, random_samples, rel_err,
+from .helpers import (MOMENT_KEYS, assert_parameter_beam, make_lattice, map_err, moment_distances, random_samples, rel_err,
                       singular_entry_voltage)
 
 pytestmark = pytest.mark.gpu
@@ -500,56 +500,71 @@ def _subset(desc, pick, cast=None):
     return out
 
 
-def test_config_5_on_the_bench_beam_product_oracle32_oracle64_distances(lx, record_property):
+def test_config_5_on_the_bench_beam_product_oracle32_oracle64_distances(lx):
     """
     `bench.py --workload c5` times [Drift, misaligned Quadrupole, Drift, Cavity] x 8 on a beam with sigma_s = 1e-5; the
     other config-5 tests use sigma_s = 1e-4.  This one runs EXACTLY the benched input -- `bench.describe("c5")`,
     `bench.BEAM_SIGMA`, 4096 x 10 000 particles, default environment (structured step loop, lanes build, merged pairs)
-    -- and compares, on environments {0, 2047, 4095} plus eight drawn at random per run (seed recorded), every beam
-    moment of the product with the float32 oracle and with the float64 oracle (float32 parameters and particles cast
-    up), next to the distance between the two oracles; units: north_star's tolerance scale (helpers.moment_distances).
+    -- and compares, for ALL 4096 environments (the oracles take them 128 at a time, ~20 s), every beam moment of the
+    product with the float32 oracle and with the float64 oracle (float32 parameters and particles cast up), next to the
+    distance between the two oracles; units: north_star's tolerance scale (helpers.moment_distances).
+    (Until late in round 4 this test looked at eleven environments per run, three fixed and eight drawn, and compared
+    the worst of them; it failed once in twenty runs -- 9 % of the environments are beyond 1e-4 in mu_p.)
 
     What decides the size of these numbers is the kick, cavity.py:150-160:
         delta_out = delta_in E b0 / (E_out b1) + V b0 / (E_out b1) (cos(-s b0 k + phi) - cos(phi)).
     With sigma_s = 1e-5 the phase s b0 k is ~3e-4 rad, so cos(phi + eps) - cos(phi) ~ sin(phi) eps + eps^2/2 is a
     difference of two numbers of order one that agree to 4-5 digits: each float32 cosine carries an absolute error of
-    ~6e-8 (half an ulp at 1), i.e. ~1e-3 of the difference, and the rounding of cos(phi) is COMMON to all particles of a
-    sample -- it moves mu_p as a whole (up to 6e-8 V b0/(E_out b1) per cavity against a scale |mu_p| + sigma_p ~ 1e-3)
-    in the oracle as in the kernel.  So for mu_p (and, behind it, mu_s) 1e-4 is not a property of the implementation
-    but of float32: the float32 oracle itself is that far from the float64 one.  Asserted: every moment within 1e-4 of
-    the float32 oracle, or -- where the float32 oracle is itself further than 5e-5 from float64 -- within twice the
-    distance between the two oracles.  Measured on MI355X (printed by the test): see DESIGN.md section 2.
+    ~6e-8 (half an ulp at 1), i.e. ~1e-3 of the difference, and because all particles of a sample sit within 3e-4 rad
+    of each other that error is COMMON to them -- it moves mu_p as a whole, by up to 6e-8 V b0/(E_out b1) per cavity
+    against a scale |mu_p| + sigma_p ~ 5e-5.  Two float32 evaluations with different cosines (NumPy's, the kernel's
+    polynomial, XLA's in the reference) therefore disagree in mu_p by what either disagrees with float64: measured
+    over the 4096 environments, product - oracle32 up to 4.3e-4 (99.9 %: 3.9e-4), oracle32 - oracle64 up to 5.0e-4;
+    every other moment of the product is within 6.3e-5 of the float32 oracle (sigma_p; the rest 2.3e-5).
+    For mu_p 1e-4 is not a property of an implementation but of float32 on this beam.  Asserted: every moment but mu_p
+    within 1e-4 of the float32 oracle in EVERY environment; mu_p: the product's worst distance from the float32
+    oracle no larger than 1.5 times the float32 oracle's own worst distance from float64, and below 1e-3.
     """
     dtype = np.float32
     desc, segment, beam, energy = _bench_workload(lx, "c5", dtype)
     B, N = beam.batch_shape[0], beam.num_particles
     assert (B, N, len(desc)) == (4096, 10_000, 32)
     out = segment.track(beam)
-    pick, _ = random_samples(B, 8, always=(0, 2047, 4095), record=record_property)
-    P = np.asarray(beam.particles)[pick]
-    _, specs32 = make_lattice(_subset(desc, pick), dtype)
-    _, specs64 = make_lattice(_subset(desc, pick, cast=np.float64), np.float64)
-    e = np.full(len(pick), energy, dtype=dtype)
-    ref32 = o.segment_track(specs32, o.particle_beam(P, e, dtype), dtype)
-    ref64 = o.segment_track(specs64, o.particle_beam(P.astype(np.float64), e.astype(np.float64), np.float64), np.float64)
-    m32, m64 = o.beam_moments(ref32, ddof=1), o.beam_moments(ref64, ddof=1)
-    got = {key: np.asarray(getattr(out, key))[pick] for key in m32 if hasattr(out, key)}
-    d_p32 = moment_distances(got, m32, scale=m64)
-    d_p64 = moment_distances(got, m64, scale=m64)
-    d_3264 = moment_distances(m32, m64, scale=m64)
-    print("config 5 on the bench beam (sigma_s = 1e-5), samples", pick)
+    got_all = {key: np.asarray(getattr(out, key)) for key in MOMENT_KEYS}
+    P_all = np.asarray(beam.particles)
+    tracked_all = np.asarray(out.particles)
+    energy_all = np.asarray(out.energy)
+    worst = {key: np.zeros(3) for key in MOMENT_KEYS}  # product-oracle32, product-oracle64, oracle32-oracle64
+    for lo in range(0, B, 128):
+        pick = list(range(lo, lo + 128))
+        P = P_all[pick]
+        _, specs32 = make_lattice(_subset(desc, pick), dtype)
+        _, specs64 = make_lattice(_subset(desc, pick, cast=np.float64), np.float64)
+        e = np.full(len(pick), energy, dtype=dtype)
+        ref32 = o.segment_track(specs32, o.particle_beam(P, e, dtype), dtype)
+        ref64 = o.segment_track(specs64, o.particle_beam(P.astype(np.float64), e.astype(np.float64), np.float64), np.float64)
+        m32, m64 = o.beam_moments(ref32, ddof=1), o.beam_moments(ref64, ddof=1)
+        got = {key: got_all[key][pick] for key in MOMENT_KEYS}
+        for k, d in enumerate((moment_distances(got, m32, scale=m64), moment_distances(got, m64, scale=m64),
+                               moment_distances(m32, m64, scale=m64))):
+            for key in MOMENT_KEYS:
+                worst[key][k] = max(worst[key][k], d[key])
+        if lo % 1024 == 0:  # the particles of a stretch of samples, and their energies
+            for c in range(7):
+                err = rel_err(tracked_all[pick][..., c], ref32["particles"][..., c])
+                assert err < (5e-4 if c == 5 else 1e-4), (lo, c, err)
+            assert rel_err(energy_all[pick], ref32["energy"]) < 1e-6
+    print("config 5 on the bench beam (sigma_s = 1e-5), all 4096 environments: worst distance per moment")
     print(f"{'moment':>10} {'product-oracle32':>18} {'product-oracle64':>18} {'oracle32-oracle64':>18}")
-    for key in d_p32:
-        print(f"{key:>10} {d_p32[key]:18.2e} {d_p64[key]:18.2e} {d_3264[key]:18.2e}")
-    for key in d_p32:
-        assert d_p32[key] <= max(1e-4, 2 * d_3264[key]), (key, d_p32[key], d_3264[key])
-        assert d_p64[key] <= max(1e-4, 3 * d_3264[key]), (key, d_p64[key], d_3264[key])
-    # the particles of those samples and the energies of all
-    tracked = np.asarray(out.particles)[pick]
-    for c in range(7):
-        err = rel_err(tracked[..., c], ref32["particles"][..., c])
-        assert err < (5e-4 if c == 5 else 1e-4), (c, err)
-    assert rel_err(np.asarray(out.energy)[pick], ref32["energy"]) < 1e-6
+    for key in MOMENT_KEYS:
+        print(f"{key:>10} {worst[key][0]:18.2e} {worst[key][1]:18.2e} {worst[key][2]:18.2e}")
+    for key in MOMENT_KEYS:
+        if key == "mu_p":
+            assert worst[key][0] <= 1.5 * worst[key][2] and worst[key][0] < 1e-3, (key, worst[key])
+            assert worst[key][1] <= 2.0 * worst[key][2], (key, worst[key])
+        else:
+            assert worst[key][0] <= 1e-4, (key, worst[key])
+            assert worst[key][1] <= max(1e-4, 3 * worst[key][2]), (key, worst[key])
     assert np.all(np.asarray(out.moment_record())[:, 35] == N)
 
 
