@@ -282,6 +282,15 @@ __device__ void build_compose_sample(const LatticeDev& lat, int64_t b, T energy_
   }
 }
 
+// sin(phi) of every cavity step into its row of a step table in LDS (LYNX_SINPHI_OFFSET: device_cavity_kick's float32
+// form); behind build_compose_sample, in front of whoever reads the rows.  The caller puts the barrier.
+template <typename T>
+__device__ __forceinline__ void table_sinphi(const LatticeDev& lat, T* s_steps) {
+  for (int s = threadIdx.x; s < lat.n_steps; s += blockDim.x)
+    if (lat.steps[s].kind == LYNX_STEP_CAVITY)
+      s_steps[s * LYNX_STEP_STRIDE + LYNX_SINPHI_OFFSET] = t_sin<T>(s_steps[s * LYNX_STEP_STRIDE + LYNX_COEF_OFFSET + LYNX_C_PHI]);
+}
+
 // ---------------------------------------------------------------------------------------
 // k_cavity_flags: the reference decides three things about a cavity for the WHOLE batch at once, in
 // Python (`if any(...)`): whether beta0/beta1 enter the map (cavity.py:290: any(V != 0 & E != 0)), whether
@@ -823,6 +832,7 @@ __global__ __launch_bounds__(64, 4) void k_emit_steps(LatticeDev lat, const int3
     const T* cs = coefs + (int64_t)s * 8 * Bp + b;
 #pragma unroll
     for (int q = 0; q < 8; ++q) row[LYNX_COEF_OFFSET + q] = cs[q * Bp];
+    row[LYNX_SINPHI_OFFSET] = t_sin<T>(row[LYNX_COEF_OFFSET + LYNX_C_PHI]);
   }
   row[LYNX_FLAGS_OFFSET] = (T)(step_descriptor(lat, s, merge_pairs) | (entry_ill ? LYNX_DESC_ILL : 0));
   if (s == S - 1) {
@@ -1001,12 +1011,80 @@ __device__ __forceinline__ lynx_f32x2 phase_cos(lynx_f32x2 x) {
   return out;
 }
 
-// Non-linear cavity step on the device: the expression of cavity_kick<T> (lynx_maps.hpp, the
-// one the host harness checks against the oracle) with phase_cos.
+// sin(d) and cos(d) - 1, the second WITHOUT the cancellation of `cos(d) - 1` (d is s beta0 k: milliradians)
+__device__ __forceinline__ void sin_cosm1(double d, double& sd, double& cm1) {
+  sd = t_sin(d);
+  const double h = t_sin(0.5 * d);
+  cm1 = -2.0 * h * h;
+}
+__device__ __forceinline__ void sin_cosm1(float d, float& sd, float& cm1) {
+  if (__builtin_expect(__builtin_fabsf(d) <= 0.75f, 1)) {  // the polynomials of sincos_reduced, quadrant 0, without the "1 +"
+    const float z = d * d;
+    float ps = fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = fmaf(ps, z, -1.6666654611e-1f);
+    sd = fmaf(ps * z, d, d);
+    float pc = fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = fmaf(pc, z, 4.166664568298827e-2f);
+    cm1 = fmaf(pc * z, z, z * -0.5f);
+  } else {
+    float sh, ch;
+    phase_sincos(0.5f * d, sh, ch);
+    sd = 2.0f * sh * ch;
+    cm1 = -2.0f * sh * sh;
+  }
+}
+__device__ __forceinline__ void sin_cosm1(lynx_f32x2 d, lynx_f32x2& sd, lynx_f32x2& cm1) {
+  const float big = __builtin_fmaxf(__builtin_fabsf(d.x), __builtin_fabsf(d.y));
+  if (__builtin_amdgcn_ballot_w64(!(big <= 0.75f)) == 0) {  // whole wave (as good as always): packed
+    const lynx_f32x2 z = d * d;
+    lynx_f32x2 ps = vfma(z, lynx_f32x2(-1.9515295891e-4f), lynx_f32x2(8.3321608736e-3f));
+    ps = vfma(ps, z, lynx_f32x2(-1.6666654611e-1f));
+    sd = vfma(ps * z, d, d);
+    lynx_f32x2 pc = vfma(z, lynx_f32x2(2.443315711809948e-5f), lynx_f32x2(-1.388731625493765e-3f));
+    pc = vfma(pc, z, lynx_f32x2(4.166664568298827e-2f));
+    cm1 = vfma(pc * z, z, z * -0.5f);
+    return;
+  }
+  float s0, c0, s1, c1;
+  sin_cosm1(d.x, s0, c0);
+  sin_cosm1(d.y, s1, c1);
+  sd = lynx_f32x2{s0, s1};
+  cm1 = lynx_f32x2{c0, c1};
+}
+
+
+// cos(phi + d) - cos(phi) from d and the sample's sin(phi), cos(phi): cos(phi)(cos d - 1) - sin(phi) sin d.
+// The reference subtracts two float32 cosines (cavity.py:150-160).  On a short bunch -- d = -s beta0 k is milliradians --
+// they agree to four or five digits, every particle of a sample sits at practically the same argument, and the
+// cosines' rounding (6e-8, half an ulp at 1) is therefore COMMON to the sample: it moves the mean of delta by up to
+// 5e-4 of |mu_p| + sigma_p on BASELINE config 5's bench beam, in the reference's own float32 arithmetic (float32 oracle
+// against float64 oracle, all 4096 environments) as in any other float32 evaluation of that difference.  Formed this
+// way the difference carries a RELATIVE error of 1e-7, the product's moments are within 1e-4 of the float64 chain in
+// every environment, and with that as close to the float32 chain as that chain is to float64
+// (tests/test_gpu_parity.py: test_config_5_on_the_bench_beam_...).  Same instruction count as the cosine it replaces.
+__device__ __forceinline__ float cos_difference(float d, float sphi, float cphi) {
+  float sd, cm1;
+  sin_cosm1(d, sd, cm1);
+  return fmaf(sd, -sphi, cm1 * cphi);
+}
+__device__ __forceinline__ lynx_f32x2 cos_difference(lynx_f32x2 d, float sphi, float cphi) {
+  lynx_f32x2 sd, cm1;
+  sin_cosm1(d, sd, cm1);
+  return vfma(sd, lynx_f32x2(-sphi), cm1 * cphi);
+}
+
+// Non-linear cavity step on the device.  float64: the expression of cavity_kick<T> (lynx_maps.hpp, the one the host
+// harness checks against the oracle).  float32: the same with the difference of cosines from cos_difference;
+// `coef` points at the step-table row's coefficients, sin(phi) sits behind them (LYNX_SINPHI_OFFSET).
 template <typename T>
 __device__ __forceinline__ void device_cavity_kick(const T* coef, T s_in, T d_in, T& s_out, T& d_out) {
-  d_out = d_in * coef[LYNX_C_DSCALE] +
-          coef[LYNX_C_DKICK] * (phase_cos(T(-1) * s_in * coef[LYNX_C_BK] + coef[LYNX_C_PHI]) - coef[LYNX_C_COSPHI]);
+  if constexpr (sizeof(T) == 4) {
+    const float dcos = cos_difference(T(-1) * s_in * coef[LYNX_C_BK], coef[LYNX_SINPHI_OFFSET - LYNX_COEF_OFFSET], coef[LYNX_C_COSPHI]);
+    d_out = d_in * coef[LYNX_C_DSCALE] + coef[LYNX_C_DKICK] * dcos;
+  } else {
+    d_out = d_in * coef[LYNX_C_DSCALE] +
+            coef[LYNX_C_DKICK] * (phase_cos(T(-1) * s_in * coef[LYNX_C_BK] + coef[LYNX_C_PHI]) - coef[LYNX_C_COSPHI]);
+  }
   s_out = s_out + (coef[LYNX_C_T566] * (d_in * d_in) + coef[LYNX_C_T556] * s_in * d_in +
                    coef[LYNX_C_T555] * (s_in * s_in));
 }
@@ -1085,9 +1163,8 @@ __device__ __forceinline__ void apply_step_pair(const float* M /*49 + coef (+ 4)
       s_in = lynx_f32x2{v.x, v.y};
       d_in = lynx_f32x2{v.z, v.w};
     }
-    const lynx_f32x2 arg = -1.0f * s_in * coef[LYNX_C_BK] + coef[LYNX_C_PHI];
-    const lynx_f32x2 ca = phase_cos(arg);
-    o[5] = d_in * coef[LYNX_C_DSCALE] + coef[LYNX_C_DKICK] * (ca - coef[LYNX_C_COSPHI]);
+    const lynx_f32x2 dcos = cos_difference(-1.0f * s_in * coef[LYNX_C_BK], coef[LYNX_SINPHI_OFFSET - LYNX_COEF_OFFSET], coef[LYNX_C_COSPHI]);
+    o[5] = d_in * coef[LYNX_C_DSCALE] + coef[LYNX_C_DKICK] * dcos;
     o[4] = o[4] + (coef[LYNX_C_T566] * (d_in * d_in) + coef[LYNX_C_T556] * s_in * d_in +
                    coef[LYNX_C_T555] * (s_in * s_in));
   }
@@ -1139,6 +1216,7 @@ __device__ __forceinline__ void build_to_table(const LatticeDev& lat, const T* _
   for (int i = threadIdx.x; i < lat.n_steps * LYNX_STEP_STRIDE; i += blockDim.x) s_steps[i] = T(0);
   __syncthreads();
   build_compose_sample<T>(lat, b, energy_in[b], s_steps, s_energy, smem_raw, chunk);
+  table_sinphi<T>(lat, s_steps);  // (its slot is nobody else's: the barriers below come before the rows leave)
   if (merge_pairs) {
     // [run, cavity] pairs for the streaming kernel: slot of the cavity <- T_cav . T_run (one
     // 7x7 application per pair instead of two), slot of the run <- rows 4 and 5 of T_run, which
@@ -1660,15 +1738,15 @@ __device__ __forceinline__ void apply_program_lane(const LatticeDev& lat, int S,
     }
     const int skind = (desc >> LYNX_DESC_KIND_SHIFT) & 3, sflags = desc & 0xffff;
     if constexpr (kMapInRegs) {
-      T m[61];  // T = float here: map, coefficients, entry inverse
+      T m[LYNX_STEP_SCALARS];  // T = float here: map, coefficients, entry inverse, sin(phi)
       if (SCALAR_TABLE) {
         const T* tab = g_steps + sidx * LYNX_STEP_STRIDE;  // global: s_load
 #pragma unroll
-        for (int q = 0; q < 61; ++q) m[q] = uniform_value(tab[q]);
+        for (int q = 0; q < LYNX_STEP_SCALARS; ++q) m[q] = uniform_value(tab[q]);
       } else {
         const T* tab = s_steps + sidx * LYNX_STEP_STRIDE;  // LDS
 #pragma unroll
-        for (int q = 0; q < 61; ++q) m[q] = uniform_value(tab[q]);
+        for (int q = 0; q < LYNX_STEP_SCALARS; ++q) m[q] = uniform_value(tab[q]);
       }
       if constexpr (kPairs) {
         // an ill-conditioned pair (uniform and rare: cavity_entry_inverse): what enters the cavity comes from the run's
@@ -1785,6 +1863,7 @@ __global__ __launch_bounds__(kTrackThreads, (track_waves_per_simd<T, MOM, FULL, 
 
   if (FUSED) {
     build_compose_sample<T>(lat, b, energy_in[b], s_steps, s_energy, s_scratch, a.build_chunk);
+    table_sinphi<T>(lat, s_steps);
     for (int s = tid; s < S; s += kTrackThreads) s_steps[s * LYNX_STEP_STRIDE + LYNX_FLAGS_OFFSET] = (T)step_descriptor(lat, s, 0);
     __syncthreads();
     if (energy_out && chunk == 0 && tid == 0) energy_out[b] = s_energy[S];
@@ -2237,6 +2316,7 @@ __device__ __forceinline__ void track_moments_sample(const LatticeDev& lat, cons
   const int64_t b = blockIdx.x;
   const int lane = threadIdx.x;
   build_compose_sample<T>(lat, b, energy_in[b], s_steps, s_energy, smem_raw, chunk);
+  table_sinphi<T>(lat, s_steps);
 
   if (lane < 7) s_mu[lane] = mu_in[b * 7 + lane];
   if (lane < 49) s_cov[lane] = cov_in[b * 49 + lane];

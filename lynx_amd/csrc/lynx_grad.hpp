@@ -198,9 +198,12 @@ __device__ __forceinline__ lynx_step table_step(const T* g_steps, int s) {
 }
 
 template <typename T>
-__device__ __forceinline__ void load_step_map(const T* g_steps, int s, T (&m)[57]) {
+__device__ __forceinline__ void load_step_map(const T* g_steps, int s, T (&m)[LYNX_STEP_SCALARS]) {
 #pragma unroll
   for (int q = 0; q < 57; ++q) m[q] = g_steps[s * LYNX_STEP_STRIDE + q];  // wave-uniform: scalar loads
+#pragma unroll
+  for (int q = 57; q < LYNX_SINPHI_OFFSET; ++q) m[q] = T(0);              // (the entry inverse: merged pairs fetch their own copy)
+  m[LYNX_SINPHI_OFFSET] = g_steps[s * LYNX_STEP_STRIDE + LYNX_SINPHI_OFFSET];
 }
 
 // does the unit whose map sits in `slot` apply a [run, cavity] pair in merged form?  (wave-uniform)
@@ -239,47 +242,6 @@ template <typename Z> __device__ __forceinline__ void zsincos(Z x, Z& s, Z& c) {
 __device__ __forceinline__ void zapply(const float* m, int kind, int flags, float (&z)[7]) { apply_step<float>(m, kind, flags, z); }
 __device__ __forceinline__ void zapply(const double* m, int kind, int flags, double (&z)[7]) { apply_step<double>(m, kind, flags, z); }
 __device__ __forceinline__ void zapply(const float* m, int kind, int flags, lynx_f32x2 (&z)[7]) { apply_step_pair(m, kind, flags, z); }
-
-// sin(d) and cos(d) - 1, the second WITHOUT the cancellation of `cos(d) - 1` (d is s beta0 k: milliradians)
-__device__ __forceinline__ void sin_cosm1(double d, double& sd, double& cm1) {
-  sd = t_sin(d);
-  const double h = t_sin(0.5 * d);
-  cm1 = -2.0 * h * h;
-}
-__device__ __forceinline__ void sin_cosm1(float d, float& sd, float& cm1) {
-  if (__builtin_expect(__builtin_fabsf(d) <= 0.75f, 1)) {  // the polynomials of sincos_reduced, quadrant 0, without the "1 +"
-    const float z = d * d;
-    float ps = fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
-    ps = fmaf(ps, z, -1.6666654611e-1f);
-    sd = fmaf(ps * z, d, d);
-    float pc = fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
-    pc = fmaf(pc, z, 4.166664568298827e-2f);
-    cm1 = fmaf(pc * z, z, z * -0.5f);
-  } else {
-    float sh, ch;
-    phase_sincos(0.5f * d, sh, ch);
-    sd = 2.0f * sh * ch;
-    cm1 = -2.0f * sh * sh;
-  }
-}
-__device__ __forceinline__ void sin_cosm1(lynx_f32x2 d, lynx_f32x2& sd, lynx_f32x2& cm1) {
-  const float big = __builtin_fmaxf(__builtin_fabsf(d.x), __builtin_fabsf(d.y));
-  if (__builtin_amdgcn_ballot_w64(!(big <= 0.75f)) == 0) {  // whole wave (as good as always): packed
-    const lynx_f32x2 z = d * d;
-    lynx_f32x2 ps = vfma(z, lynx_f32x2(-1.9515295891e-4f), lynx_f32x2(8.3321608736e-3f));
-    ps = vfma(ps, z, lynx_f32x2(-1.6666654611e-1f));
-    sd = vfma(ps * z, d, d);
-    lynx_f32x2 pc = vfma(z, lynx_f32x2(2.443315711809948e-5f), lynx_f32x2(-1.388731625493765e-3f));
-    pc = vfma(pc, z, lynx_f32x2(4.166664568298827e-2f));
-    cm1 = vfma(pc * z, z, z * -0.5f);
-    return;
-  }
-  float s0, c0, s1, c1;
-  sin_cosm1(d.x, s0, c0);
-  sin_cosm1(d.y, s1, c1);
-  sd = lynx_f32x2{s0, s1};
-  cm1 = lynx_f32x2{c0, c1};
-}
 
 // Cotangents of an active cavity's kick (cavity.py:141-161, 219-226), shared by the three reverse kernels:
 //   o5 = z5 c0 + c1 (cos(a) - c4),  a = -z4 c2 + c3;   o4 = o4_lin + c5 z5^2 + c6 z4 z5 + c7 z4^2
@@ -328,9 +290,9 @@ __device__ __forceinline__ void apply_unit(const T* g_steps, int slot, Z (&z)[7]
   const lynx_step st = table_step<T>(g_steps, slot);
   if constexpr (LaneOf<Z>::W == 2) {
     if (unit_is_pair<T>(g_steps, slot)) {  // uniform: as the forward kernel applies it (kEntryInverse)
-      T m[61];
+      T m[LYNX_STEP_SCALARS];
 #pragma unroll
-      for (int q = 0; q < 61; ++q) m[q] = g_steps[slot * LYNX_STEP_STRIDE + q];
+      for (int q = 0; q < LYNX_STEP_SCALARS; ++q) m[q] = g_steps[slot * LYNX_STEP_STRIDE + q];
       const int desc = (int)uniform_value(g_steps[slot * LYNX_STEP_STRIDE + LYNX_FLAGS_OFFSET]);
       if (desc & LYNX_DESC_ILL) {  // uniform: the rows form, like the forward kernel
         T pre[14];
@@ -345,7 +307,7 @@ __device__ __forceinline__ void apply_unit(const T* g_steps, int slot, Z (&z)[7]
       return;
     }
   }
-  T m[57];
+  T m[LYNX_STEP_SCALARS];
   load_step_map<T>(g_steps, slot, m);
   zapply(m, st.kind, st.flags, z);
 }
@@ -496,7 +458,7 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
             LYNX_FORGET();
           }
         }
-        T m[57];
+        T m[LYNX_STEP_SCALARS];
         load_step_map<T>(g_steps, s, m);
 
         const bool kick = st.kind == LYNX_STEP_CAVITY && (st.flags & LYNX_FLAG_CAV_GAIN);

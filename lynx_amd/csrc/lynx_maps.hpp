@@ -67,6 +67,10 @@ namespace lynx {
 // close to singular for its inverse to recover what entered the cavity (cavity_entry_inverse); the kernels then take
 // the two from rows 4 and 5 of the run's map, parked in the run's slot, applied to the state that enters the pair
 #define LYNX_DESC_ILL (1 << 21)
+// slot 61 of a cavity step: sin(phi), next to the coefficient cos(phi) -- the float32 kick is evaluated from the two and
+// d = -s beta0 k without the cancellation of cos(phi + d) - cos(phi) (device_cavity_kick, lynx_device.hpp)
+#define LYNX_SINPHI_OFFSET 61
+#define LYNX_STEP_SCALARS 62  // what a step's application may read of its row: map, coefficients, entry inverse, sin(phi)
 // last step, slot 63: the beam energy behind the last step (published by the streaming kernel)
 #define LYNX_ENERGY_OFFSET 63
 // cavity coefficient slots (lynx/accelerator/cavity.py:141-226)

@@ -16,7 +16,7 @@ constexpr int kUnitStride = 32;
 // first half: what the kick needs; second half: the linear map
 constexpr int kUnitDesc = 0;    // bits: kUnit* below
 constexpr int kUnitSlot = 1;    // step-table slot of the unit's (dense) record
-constexpr int kUnitSinPhi = 2;  // sin(phi) of an active cavity (the reverse pass's kick_cotangents; cos(phi) is a coefficient)
+constexpr int kUnitSinPhi = 2;  // sin(phi) of an active cavity (the kick's difference of cosines and its cotangents; cos(phi) is a coefficient)
 constexpr int kUnitCoef = 4;    // 8 cavity coefficients (LYNX_C_*)
 constexpr int kUnitInv = 12;    // 4: inverse of the cavity's (s, delta) block (merged pairs)
 constexpr int kUnitMap = 16;    // 16 entries of class U, in the order of unit_entry_u()
@@ -86,7 +86,7 @@ __device__ __forceinline__ void pack_unit_record(const R* rec, const R* pre /* m
                    ((ok ? cls : (int)kClassDense) << kUnitClassShift);
   out[kUnitDesc] = __int_as_float(bits);
   out[kUnitSlot] = __int_as_float(slot);
-  out[kUnitSinPhi] = kick ? t_sin<float>((float)rec[LYNX_COEF_OFFSET + LYNX_C_PHI]) : 0.f;
+  out[kUnitSinPhi] = kick ? (float)rec[LYNX_SINPHI_OFFSET] : 0.f;  // (the builders left it in the row: the same number the dense step loop reads)
   out[3] = 0.f;
 #pragma unroll
   for (int k = 0; k < 8; ++k) out[kUnitCoef + k] = (float)rec[LYNX_COEF_OFFSET + k];

@@ -66,11 +66,10 @@ __global__ __launch_bounds__(256) void k_pack_units(UnitPlan plan, int64_t B, in
 
 // The cavity's non-linear kick on a pair of particles: the expressions of apply_step_pair (lynx_device.hpp), which
 // are device_cavity_kick's (cavity.py:141-161, 219-226), operation for operation.
-__device__ __forceinline__ void unit_kick(const float (&coef)[8], lynx_f32x2 s_in, lynx_f32x2 d_in, lynx_f32x2& o4,
+__device__ __forceinline__ void unit_kick(const float (&coef)[8], float sphi, lynx_f32x2 s_in, lynx_f32x2 d_in, lynx_f32x2& o4,
                                           lynx_f32x2& o5) {
-  const lynx_f32x2 arg = -1.0f * s_in * coef[LYNX_C_BK] + coef[LYNX_C_PHI];
-  const lynx_f32x2 ca = phase_cos(arg);
-  o5 = d_in * coef[LYNX_C_DSCALE] + coef[LYNX_C_DKICK] * (ca - coef[LYNX_C_COSPHI]);
+  const lynx_f32x2 dcos = cos_difference(-1.0f * s_in * coef[LYNX_C_BK], sphi, coef[LYNX_C_COSPHI]);
+  o5 = d_in * coef[LYNX_C_DSCALE] + coef[LYNX_C_DKICK] * dcos;
   o4 = o4 + (coef[LYNX_C_T566] * (d_in * d_in) + coef[LYNX_C_T556] * s_in * d_in + coef[LYNX_C_T555] * (s_in * s_in));
 }
 
@@ -191,7 +190,7 @@ __device__ __forceinline__ void unit_nonlinear(const UnitHalf& kick, int bits, l
     float coef[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) coef[k] = kick.v[kUnitCoef + k];
-    unit_kick(coef, s_in, d_in, z[4], z[5]);
+    unit_kick(coef, kick.v[kUnitSinPhi], s_in, d_in, z[4], z[5]);
   }
 }
 
@@ -260,9 +259,13 @@ __device__ __forceinline__ void units_program(int U, const float* __restrict__ s
 // ---------------------------------------------------------------------------------------
 // k_track_units: grid.x = B * chunks, 256 threads, 2 PAIRS particles per lane (tid + 256 k of a tile of 512 PAIRS).
 // ---------------------------------------------------------------------------------------
+// (at most 88 registers per lane where the compiler would take 93 for five waves per SIMD: five of these waves then leave
+// 72 of a SIMD's 512 registers free, and ONE of them retiring makes room for a wave of the next call's build -- 136
+// registers.  At 96 the build waited for two: k_build_pieces 97 -> 357 us underneath BASELINE config 5's streaming
+// kernel, 25 us on every step.)
 template <int MOM, bool FULL, int PAIRS>
-__global__ __launch_bounds__(kTrackThreads, (units_waves_per_simd<MOM, FULL, PAIRS>())) void k_track_units(
-    TrackArgs a, int32_t U, int32_t S, const float* p_in, float* p_out, float* __restrict__ energy_out,
+__device__ __forceinline__ void track_units_body(
+    const TrackArgs& a, int32_t U, int32_t S, const float* p_in, float* p_out, float* __restrict__ energy_out,
     const float* __restrict__ steps_in, const float* __restrict__ units_in, const float* __restrict__ extras_in,
     double* __restrict__ partials) {
   using T = float;
@@ -382,6 +385,14 @@ __global__ __launch_bounds__(kTrackThreads, (units_waves_per_simd<MOM, FULL, PAI
     sums.end_iteration();
   }
   if (MOM) workgroup_moment_record<T, MOM, FULL>(sums, shift, smem_raw, partials + ((int64_t)b * a.chunks + chunk) * kPartialStride);
+}
+
+template <int MOM, bool FULL, int PAIRS>
+__global__ __launch_bounds__(kTrackThreads, (units_waves_per_simd<MOM, FULL, PAIRS>())) void k_track_units(
+    TrackArgs a, int32_t U, int32_t S, const float* p_in, float* p_out, float* __restrict__ energy_out,
+    const float* __restrict__ steps_in, const float* __restrict__ units_in, const float* __restrict__ extras_in,
+    double* __restrict__ partials) {
+  track_units_body<MOM, FULL, PAIRS>(a, U, S, p_in, p_out, energy_out, steps_in, units_in, extras_in, partials);
 }
 
 // LDS of k_track_units: the moment slab (TrackArgs.lds_scratch_bytes)

@@ -94,10 +94,13 @@ def test_gpu_reproduces_golden(dtype, built_library):
     pb = lx.ParameterBeam.from_parameters(sigma_x=np.full(3, 1e-4, dtype), sigma_xp=np.full(3, 1e-5, dtype),
                                           mu_x=np.asarray([1e-4, -2e-4, 0.0], dtype), energy=np.full(3, 6e6, dtype), dtype=dtype)
     pout = seg.track(pb)
-    # mu AND the covariance, entry by entry at north_star's tolerance (measured, scripts/gpu/r3_pb_study.py: 2.4e-6 / 1.8e-5
-    # from the float32 fixture; the float32 reference itself sits 6e-3 from float64 in mu_p here: phase + float32 cos)
+    # mu AND the covariance, entry by entry at north_star's tolerance.  The float32 fixture itself sits 6e-3 from the
+    # float64 one in mu_p here (the kick's difference of two float32 cosines, cavity.py:150-160); the product forms that
+    # difference without the cancellation (device_cavity_kick) and lands on the float64 fixture: every entry within the
+    # tolerance of the float32 fixture or of the float64 one
     assert_parameter_beam(pout, {"mu": G[f"mixed/mu_out/{tag}"], "cov": G[f"mixed/cov_out/{tag}"]},
-                          1e-4 if dtype == np.float32 else 1e-9)
+                          1e-4 if dtype == np.float32 else 1e-9,
+                          alt={"mu": G["mixed/mu_out/float64"], "cov": G["mixed/cov_out/float64"]} if dtype == np.float32 else None)
     # C2 moments at N = 100k
     P2 = o.gaussian_particles((1,), 100_000, seed=0, dtype=dtype)
     out2 = lx.Segment(ares).track(lx.ParticleBeam(P2, np.array([1e8], dtype), dtype=dtype))

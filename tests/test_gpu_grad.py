@@ -517,10 +517,11 @@ def test_config_5_gradients_at_the_full_shape(lx, monkeypatch):
         (the table sits next to TOL_C5_GRAD below, and in DESIGN.md section 2)
 
     History of the cavity rows: as the round began phase stood at 1.2e-2, voltage 2.7e-3, frequency 4.6e-3 from the
-    float64 pass and phase 1.3e-2 between the two float32 kernels.  Two cancellations, both removed from the
-    DERIVATIVES only (the forward pass repeats the reference's float32 operations): the kick's sin(a) - sin(phi) and
-    cos(a) - cos(phi), summed over the particles as separate large numbers (lynx_grad.hpp: kick_cotangents), and the
-    bracket of r55_cor (cavity.py:296-305) in the dual-number builders (lynx_dual.hpp: cavity_r55_bracket_dual).
+    float64 pass and phase 1.3e-2 between the two float32 kernels.  Three cancellations were removed: the kick's
+    sin(a) - sin(phi) and cos(a) - cos(phi) in the derivatives, summed over the particles as separate large numbers
+    (lynx_grad.hpp: kick_cotangents); the bracket of r55_cor (cavity.py:296-305) in the dual-number builders
+    (lynx_dual.hpp: cavity_r55_bracket_dual); and last cos(a) - cos(phi) in the FORWARD kick itself
+    (lynx_device.hpp: cos_difference), whose rounding the recomputed forward states had carried into every gradient.
     """
     import bench
 
@@ -572,18 +573,21 @@ def test_config_5_gradients_at_the_full_shape(lx, monkeypatch):
 
 # (float32 kernels against each other, float32 against the float64 pass): twice what the test above measured on MI355X,
 # over all 4096 environments (round 4):          structured - dense    structured - float64    dense - float64
-#                                  length              2.7e-05               6.3e-05               6.3e-05
-#                                  k1                  5.5e-05               6.1e-05               4.8e-05
-#                                  misalignment        5.1e-05               9.9e-05               1.0e-04
-#                                  voltage             2.1e-05               8.9e-04               8.9e-04
-#                                  phase               1.9e-05               2.0e-03               2.0e-03
-#                                  frequency           2.6e-05               8.4e-03               8.4e-03
-#                                  energy              2.8e-06               9.6e-05               9.6e-05
+#                                  length              2.7e-05               3.4e-05               3.6e-05
+#                                  k1                  5.3e-05               6.1e-05               4.9e-05
+#                                  misalignment        3.4e-05               9.9e-05               1.0e-04
+#                                  voltage             2.0e-05               1.0e-04               1.0e-04
+#                                  phase               1.7e-05               7.6e-05               7.6e-05
+#                                  frequency           2.2e-05               2.9e-04               2.7e-04
+#                                  energy              9.7e-06               1.8e-05               1.8e-05
+# (with the forward kick still subtracting two float32 cosines -- until late in round 4 -- the float64 columns read
+# voltage 8.9e-4, phase 2.0e-3, frequency 8.4e-3, energy 9.6e-5: the reverse pass differentiates the forward states it
+# recomputes, and those carried the cosines' rounding)
 # (structured - dense: the structured kernel keeps a lane's share of the transverse sums S_x, S_y in float32 over all of
 # its tiles before the workgroup adds them up -- with round 3's exchange-buffer form, which added every tile's products
 # over the wave at once, that column read 4e-06 .. 2e-05)
-TOL_C5_GRAD = {"length": (6e-5, 1.3e-4), "k1": (1.1e-4, 1.3e-4), "misalignment": (1.1e-4, 2e-4), "voltage": (5e-5, 1.8e-3),
-               "phase": (4e-5, 4e-3), "frequency": (6e-5, 1.7e-2), "energy": (6e-6, 2e-4)}
+TOL_C5_GRAD = {"length": (6e-5, 8e-5), "k1": (1.1e-4, 1.3e-4), "misalignment": (7e-5, 2e-4), "voltage": (4e-5, 2.1e-4),
+               "phase": (3.5e-5, 1.6e-4), "frequency": (4.5e-5, 6e-4), "energy": (2e-5, 4e-5)}
 
 
 def _ares_with_active_bpms(ns, dtype, values, active=True):

@@ -38,6 +38,11 @@ def _particle_case(lx, desc, dtype, batch_shape, n, seed, energy=1e8, sigma=None
     e = np.full(batch_shape, energy, dtype=dtype)
     out = lx.Segment(elements).track(lx.ParticleBeam(P, e, dtype=dtype))
     ref = o.segment_track(specs, o.particle_beam(P, e, dtype), dtype)
+    if dtype == np.float32 and any(kind == "cavity" for kind, _ in desc):
+        # behind an active cavity the float32 chain is not its own measure (see _assert_moments): the float64 chain next to it
+        up = lambda v: np.asarray(np.asarray(v, dtype=np.float32), dtype=np.float64) if isinstance(v, (np.ndarray, list, float)) else v  # noqa: E731
+        _, specs64 = make_lattice([(kind, {k: up(v) for k, v in kw.items()}) for kind, kw in desc], np.float64)
+        ref["float64_chain"] = o.segment_track(specs64, o.particle_beam(P.astype(np.float64), e.astype(np.float64), np.float64), np.float64)
     return out, ref
 
 
@@ -51,14 +56,27 @@ def _assert_particles(out, ref, dtype):
 
 
 def _assert_moments(out, ref, dtype):
-    m = o.beam_moments(ref, ddof=1)
+    """
+    Every beam moment within north_star's tolerance of the reference's chain.  float32 lattices with an active cavity
+    (`_particle_case` then hands the float64 chain over too): within the tolerance of the float32 chain OR of the
+    float64 chain.  The kick subtracts two cosines (cavity.py:150-160) that agree to four or five digits on a short
+    bunch, at an argument all particles of a sample practically share -- the float32 chain's mean of delta carries
+    that cosine's rounding as a whole, up to 5e-4 of |mu_p| + sigma_p on BASELINE config 5's bench beam; the product
+    forms the difference without the cancellation (device_cavity_kick) and sits on the float64 chain to 1e-6.
+    """
+    chains = [o.beam_moments(ref, ddof=1)] + ([o.beam_moments(ref["float64_chain"], ddof=1)] if "float64_chain" in ref else [])
+    scale = chains[-1]
+
+    def within(key, tolerance_scale):
+        got = np.asarray(getattr(out, key), dtype=np.float64)
+        return np.any([np.abs(got - np.asarray(m[key], dtype=np.float64)) <= TOL_MOM[dtype] * tolerance_scale for m in chains], axis=0)
+
     for key in ("mu_x", "mu_xp", "mu_y", "mu_yp", "mu_s", "mu_p"):
-        sig = m["sigma" + key[2:]]
-        assert np.all(np.abs(getattr(out, key) - m[key]) <= TOL_MOM[dtype] * (np.abs(m[key]) + sig)), key
+        assert np.all(within(key, np.abs(scale[key]) + scale["sigma" + key[2:]])), key
     for key in ("sigma_x", "sigma_xp", "sigma_y", "sigma_yp", "sigma_s", "sigma_p"):
-        assert np.allclose(getattr(out, key), m[key], rtol=TOL_MOM[dtype], atol=0), key
+        assert np.all(within(key, scale[key])), key
     for key, a, b in (("sigma_xxp", "sigma_x", "sigma_xp"), ("sigma_yyp", "sigma_y", "sigma_yp")):
-        assert np.all(np.abs(getattr(out, key) - m[key]) <= TOL_MOM[dtype] * m[a] * m[b]), key
+        assert np.all(within(key, scale[a] * scale[b])), key
 
 
 # ---------------------------------------------------------------------------------------------
@@ -507,9 +525,7 @@ def test_config_5_on_the_bench_beam_product_oracle32_oracle64_distances(lx):
     `bench.BEAM_SIGMA`, 4096 x 10 000 particles, default environment (structured step loop, lanes build, merged pairs)
     -- and compares, for ALL 4096 environments (the oracles take them 128 at a time, ~20 s), every beam moment of the
     product with the float32 oracle and with the float64 oracle (float32 parameters and particles cast up), next to the
-    distance between the two oracles; units: north_star's tolerance scale (helpers.moment_distances).
-    (Until late in round 4 this test looked at eleven environments per run, three fixed and eight drawn, and compared
-    the worst of them; it failed once in twenty runs -- 9 % of the environments are beyond 1e-4 in mu_p.)
+    distance between the two oracles; units: north_star's tolerance scale (helpers.moment_distances' scales).
 
     What decides the size of these numbers is the kick, cavity.py:150-160:
         delta_out = delta_in E b0 / (E_out b1) + V b0 / (E_out b1) (cos(-s b0 k + phi) - cos(phi)).
@@ -517,20 +533,24 @@ def test_config_5_on_the_bench_beam_product_oracle32_oracle64_distances(lx):
     difference of two numbers of order one that agree to 4-5 digits: each float32 cosine carries an absolute error of
     ~6e-8 (half an ulp at 1), i.e. ~1e-3 of the difference, and because all particles of a sample sit within 3e-4 rad
     of each other that error is COMMON to them -- it moves mu_p as a whole, by up to 6e-8 V b0/(E_out b1) per cavity
-    against a scale |mu_p| + sigma_p ~ 5e-5.  Two float32 evaluations with different cosines (NumPy's, the kernel's
-    polynomial, XLA's in the reference) therefore disagree in mu_p by what either disagrees with float64: measured
-    over the 4096 environments, product - oracle32 up to 4.3e-4 (99.9 %: 3.9e-4), oracle32 - oracle64 up to 5.0e-4;
-    every other moment of the product is within 6.3e-5 of the float32 oracle (sigma_p; the rest 2.3e-5).
-    For mu_p 1e-4 is not a property of an implementation but of float32 on this beam.  Asserted: every moment but mu_p
-    within 1e-4 of the float32 oracle in EVERY environment; mu_p: the product's worst distance from the float32
-    oracle no larger than 1.5 times the float32 oracle's own worst distance from float64, and below 1e-3.
+    against a scale |mu_p| + sigma_p ~ 5e-5.  The reference's float32 chain (the float32 oracle) is therefore up to
+    5.0e-4 away from its float64 chain in mu_p on this input, 9 % of the environments beyond 1e-4 -- and so is every
+    float32 evaluation that subtracts two cosines, with whatever cosine (NumPy's, XLA's, this library's polynomial until
+    late in round 4: up to 4.3e-4 from the float32 oracle, 5.9e-4 from the float64 one).  The kernels now form the
+    difference as cos(phi)(cos d - 1) - sin(phi) sin d (device_cavity_kick: relative error 1e-7, same instruction
+    count), and with that the product is ON the float64 chain -- mu_p 2e-8, sigma_p 1e-6, mu_s 2e-7 -- in every
+    environment; its distance from the float32 chain is that chain's own distance from float64.
+
+    Asserted, per environment and per moment: within 1e-4 of the float32 chain or of the float64 chain, and -- the
+    round-3 verdict's criterion -- d(product, float32 chain) <= max(1e-4, 2 d(float32 chain, float64 chain)); for the
+    moments the kick decides (mu_s, mu_p, sigma_s, sigma_p) within 1e-5 of the float64 chain.
     """
     dtype = np.float32
     desc, segment, beam, energy = _bench_workload(lx, "c5", dtype)
     B, N = beam.batch_shape[0], beam.num_particles
     assert (B, N, len(desc)) == (4096, 10_000, 32)
     out = segment.track(beam)
-    got_all = {key: np.asarray(getattr(out, key)) for key in MOMENT_KEYS}
+    got_all = {key: np.asarray(getattr(out, key), dtype=np.float64) for key in MOMENT_KEYS}
     P_all = np.asarray(beam.particles)
     tracked_all = np.asarray(out.particles)
     energy_all = np.asarray(out.energy)
@@ -544,11 +564,22 @@ def test_config_5_on_the_bench_beam_product_oracle32_oracle64_distances(lx):
         ref32 = o.segment_track(specs32, o.particle_beam(P, e, dtype), dtype)
         ref64 = o.segment_track(specs64, o.particle_beam(P.astype(np.float64), e.astype(np.float64), np.float64), np.float64)
         m32, m64 = o.beam_moments(ref32, ddof=1), o.beam_moments(ref64, ddof=1)
-        got = {key: got_all[key][pick] for key in MOMENT_KEYS}
-        for k, d in enumerate((moment_distances(got, m32, scale=m64), moment_distances(got, m64, scale=m64),
-                               moment_distances(m32, m64, scale=m64))):
-            for key in MOMENT_KEYS:
-                worst[key][k] = max(worst[key][k], d[key])
+        for key in MOMENT_KEYS:
+            if key.startswith("mu_"):
+                scale = np.abs(m64[key]) + m64["sigma" + key[2:]]
+            elif key in ("sigma_xxp", "sigma_yyp"):
+                scale = m64["sigma_x"] * m64["sigma_xp"] if key == "sigma_xxp" else m64["sigma_y"] * m64["sigma_yp"]
+            else:
+                scale = m64[key]
+            r32 = np.asarray(m32[key], dtype=np.float64)
+            d_p32 = np.abs(got_all[key][pick] - r32) / scale
+            d_p64 = np.abs(got_all[key][pick] - m64[key]) / scale
+            d_3264 = np.abs(r32 - m64[key]) / scale
+            assert np.all(np.minimum(d_p32, d_p64) <= 1e-4), (key, lo, float(np.max(np.minimum(d_p32, d_p64))))
+            assert np.all(d_p32 <= np.maximum(1e-4, 2 * d_3264)), (key, lo, float(np.max(d_p32)), float(np.max(d_3264)))
+            if key in ("mu_s", "mu_p", "sigma_s", "sigma_p"):
+                assert np.all(d_p64 <= 1e-5), (key, lo, float(np.max(d_p64)))
+            worst[key] = np.maximum(worst[key], [d_p32.max(), d_p64.max(), d_3264.max()])
         if lo % 1024 == 0:  # the particles of a stretch of samples, and their energies
             for c in range(7):
                 err = rel_err(tracked_all[pick][..., c], ref32["particles"][..., c])
@@ -558,13 +589,6 @@ def test_config_5_on_the_bench_beam_product_oracle32_oracle64_distances(lx):
     print(f"{'moment':>10} {'product-oracle32':>18} {'product-oracle64':>18} {'oracle32-oracle64':>18}")
     for key in MOMENT_KEYS:
         print(f"{key:>10} {worst[key][0]:18.2e} {worst[key][1]:18.2e} {worst[key][2]:18.2e}")
-    for key in MOMENT_KEYS:
-        if key == "mu_p":
-            assert worst[key][0] <= 1.5 * worst[key][2] and worst[key][0] < 1e-3, (key, worst[key])
-            assert worst[key][1] <= 2.0 * worst[key][2], (key, worst[key])
-        else:
-            assert worst[key][0] <= 1e-4, (key, worst[key])
-            assert worst[key][1] <= max(1e-4, 3 * worst[key][2]), (key, worst[key])
     assert np.all(np.asarray(out.moment_record())[:, 35] == N)
 
 
@@ -667,9 +691,11 @@ def test_c4_shape_composed_map_is_the_exact_product_of_its_float32_element_maps(
 def test_c5_shape_moments(lx):
     """
     BASELINE config 5's shape ([Drift, misaligned Quad, Drift, Cavity] x 8 at 6 MeV, 10 000 particles,
-    float32): beam moments against the float32 oracle at north_star's 1e-4.  sigma_s and sigma_p pass
-    through eight cavity kicks cos(phi + eps) - cos(phi) evaluated in float32 (cavity.py:150-160) -- in
-    the oracle as in the kernel; the test prints the distance to the float64 oracle as well.
+    float32): every beam moment within north_star's 1e-4 of the reference's chain in float32 or in float64
+    (_assert_moments).  mu_p and sigma_p pass through eight cavity kicks cos(phi + eps) - cos(phi) (cavity.py:150-160):
+    evaluated in float32 as two cosines -- the oracle -- the mean of delta is 2e-4 of its scale away from the float64
+    chain even on this 0.1 mm bunch; the kernel forms the difference without the cancellation and is asserted within
+    1e-4 of the float64 chain as a whole (measured: 1e-6).  Both distances are printed.
     """
     B, N = 16, 10_000
     rng = np.random.default_rng(3)
@@ -691,7 +717,7 @@ def test_c5_shape_moments(lx):
     d32 = _moment_distance(out, o.beam_moments(ref, ddof=1))
     d64 = _moment_distance(out, o.beam_moments(ref64, ddof=1))
     print(f"C5 shape: moments {d32:.2e} from the float32 reference, {d64:.2e} from float64")
-    assert d32 < 1e-4
+    assert d64 < 1e-4 and d32 < 1e-3
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
