@@ -1062,15 +1062,36 @@ __device__ __forceinline__ void sin_cosm1(lynx_f32x2 d, lynx_f32x2& sd, lynx_f32
 // way the difference carries a RELATIVE error of 1e-7, the product's moments are within 1e-4 of the float64 chain in
 // every environment, and with that as close to the float32 chain as that chain is to float64
 // (tests/test_gpu_parity.py: test_config_5_on_the_bench_beam_...).  Same instruction count as the cosine it replaces.
-__device__ __forceinline__ float cos_difference(float d, float sphi, float cphi) {
-  float sd, cm1;
-  sin_cosm1(d, sd, cm1);
-  return fmaf(sd, -sphi, cm1 * cphi);
+// |d| <= 0.25 rad (9 mm of s at 1.3 GHz): Taylor polynomials -- sin d to d^5 (relative error d^6/5040 < 5e-8), cos d - 1 to
+// d^6 (< 1e-8) -- in ten packed operations where the cosine they replace took eight and its argument and the
+// subtraction two more.  (sin_cosm1's longer polynomials up to 0.75 rad: fourteen, BASELINE config 5's streaming kernel
+// 0.521 -> 0.553 ms.)  Beyond: the two cosines as the reference subtracts them -- they no longer cancel there.
+constexpr float kCosDifferenceSmall = 0.25f;
+template <typename V>
+__device__ __forceinline__ V cos_difference_small(V d, float sphi, float cphi) {
+  const V z = d * d;
+  const V p = vfma(z, V(8.3333333333e-3f), V(-1.6666666667e-1f));
+  const V sd = vfma(p * z, d, d);                                               // sin d
+  V q = vfma(z, V(-1.3888888889e-3f), V(4.1666666667e-2f));
+  q = vfma(q, z, V(-0.5f));
+  return vfma(q * z, V(cphi), sd * (-sphi));                                    // cos phi (cos d - 1) - sin phi sin d
 }
-__device__ __forceinline__ lynx_f32x2 cos_difference(lynx_f32x2 d, float sphi, float cphi) {
-  lynx_f32x2 sd, cm1;
-  sin_cosm1(d, sd, cm1);
-  return vfma(sd, lynx_f32x2(-sphi), cm1 * cphi);
+__device__ __forceinline__ float cos_difference(float d, float phi, float sphi, float cphi) {
+  if (__builtin_expect(__builtin_fabsf(d) <= kCosDifferenceSmall, 1)) return cos_difference_small<float>(d, sphi, cphi);
+  return phase_cos(d + phi) - cphi;
+}
+__device__ __forceinline__ lynx_f32x2 cos_difference(lynx_f32x2 d, float phi, float sphi, float cphi) {
+  const float big = __builtin_fmaxf(__builtin_fabsf(d.x), __builtin_fabsf(d.y));
+  if (__builtin_amdgcn_ballot_w64(!(big <= kCosDifferenceSmall)) == 0) return cos_difference_small<lynx_f32x2>(d, sphi, cphi);  // whole wave
+  // element by element (what a particle gets does not depend on its wave), one after the other: this path is rare and
+  // must not cost the kernels around it registers -- with both elements' two forms alive at once the streaming kernel
+  // of multi-step programs took 92 registers instead of 88, and the next call's build waves (136) then waited for TWO
+  // of its waves to retire on a SIMD instead of one (k_build_pieces 97 -> 357 us underneath BASELINE config 5's kernel)
+  lynx_f32x2 out;
+  out.x = cos_difference(d.x, phi, sphi, cphi);
+  __builtin_amdgcn_sched_barrier(0);
+  out.y = cos_difference(d.y, phi, sphi, cphi);
+  return out;
 }
 
 // Non-linear cavity step on the device.  float64: the expression of cavity_kick<T> (lynx_maps.hpp, the one the host
@@ -1079,7 +1100,8 @@ __device__ __forceinline__ lynx_f32x2 cos_difference(lynx_f32x2 d, float sphi, f
 template <typename T>
 __device__ __forceinline__ void device_cavity_kick(const T* coef, T s_in, T d_in, T& s_out, T& d_out) {
   if constexpr (sizeof(T) == 4) {
-    const float dcos = cos_difference(T(-1) * s_in * coef[LYNX_C_BK], coef[LYNX_SINPHI_OFFSET - LYNX_COEF_OFFSET], coef[LYNX_C_COSPHI]);
+    const float dcos = cos_difference(T(-1) * s_in * coef[LYNX_C_BK], coef[LYNX_C_PHI], coef[LYNX_SINPHI_OFFSET - LYNX_COEF_OFFSET],
+                                      coef[LYNX_C_COSPHI]);
     d_out = d_in * coef[LYNX_C_DSCALE] + coef[LYNX_C_DKICK] * dcos;
   } else {
     d_out = d_in * coef[LYNX_C_DSCALE] +
@@ -1163,7 +1185,8 @@ __device__ __forceinline__ void apply_step_pair(const float* M /*49 + coef (+ 4)
       s_in = lynx_f32x2{v.x, v.y};
       d_in = lynx_f32x2{v.z, v.w};
     }
-    const lynx_f32x2 dcos = cos_difference(-1.0f * s_in * coef[LYNX_C_BK], coef[LYNX_SINPHI_OFFSET - LYNX_COEF_OFFSET], coef[LYNX_C_COSPHI]);
+    const lynx_f32x2 dcos = cos_difference(-1.0f * s_in * coef[LYNX_C_BK], coef[LYNX_C_PHI], coef[LYNX_SINPHI_OFFSET - LYNX_COEF_OFFSET],
+                                           coef[LYNX_C_COSPHI]);
     o[5] = d_in * coef[LYNX_C_DSCALE] + coef[LYNX_C_DKICK] * dcos;
     o[4] = o[4] + (coef[LYNX_C_T566] * (d_in * d_in) + coef[LYNX_C_T556] * s_in * d_in +
                    coef[LYNX_C_T555] * (s_in * s_in));
@@ -2478,9 +2501,7 @@ __global__ __launch_bounds__(64) void k_apply_moments_lanes(LatticeDev lat, cons
       for (int i = 0; i < 7; ++i) C[i * 7 + j] = out[i];
     }
     if (kick) {
-      T coef[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) coef[q] = M[LYNX_COEF_OFFSET + q];
+      const T* coef = M + LYNX_COEF_OFFSET;  // (the row itself: the kick reads sin(phi) behind the coefficients)
       T s_o = mu[4], d_o;
       device_cavity_kick<T>(coef, s_in, d_in, s_o, d_o);  // cavity.py:134-140, 202-206
       mu[4] = s_o;

@@ -185,7 +185,10 @@ __global__ __launch_bounds__(kTrackThreads, (MAXU <= 8 ? LYNX_BWD_UNITS_WAVES : 
           const Z o4 = pk_fma(z5, r.m45, z4 * r.m44), o5 = pk_fma(z5, r.m55, z4 * r.m54);
           z4 = o4;
           z5 = o5;
-          if (r.bits & kUnitKick) unit_kick(r.coef, r.sphi, s_in, d_in, z4, z5);
+          if (r.bits & kUnitKick) {
+            float unused = 0.f;
+            unit_kick<true>(r.coef, r.sphi, s_in, d_in, z4, z5, unused);
+          }
         }
       }
       zf[4] = z4;

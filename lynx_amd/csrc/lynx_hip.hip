@@ -473,7 +473,11 @@ static int ensure_tickets(lynx_ctx* ctx, size_t count) {
   if (rc) return rc;
   ctx->scratch_tickets = (unsigned int*)buf;
   ctx->scratch_tickets_count = have / sizeof(unsigned int);
-  HIP_TRY(ctx, hipMemset(buf, 0, have));
+  // (hipMemset runs on the null stream and need not have finished when it returns; the context's streams do not wait for
+  // that stream -- a reduction launched right behind this took tickets that the fill then wiped: one moment record of
+  // zeros in the first call of a process, once in about thirty processes)
+  HIP_TRY(ctx, hipMemsetAsync(buf, 0, have, ctx->stream));
+  HIP_TRY(ctx, sync_main(ctx));
   return LYNX_OK;
 }
 
@@ -560,6 +564,7 @@ int lynx_ctx_create(int device, lynx_ctx** out) {
     ctx->can_wait_value = 0;
   }
   if (ctx->d_tail_flag) HIP_TRY(nullptr, hipMemset(ctx->d_tail_flag, 0, 8));
+  HIP_TRY(nullptr, hipDeviceSynchronize());  // (hipMemset runs on the null stream and need not have finished when it returns)
   *out = ctx;
   return LYNX_OK;
 }

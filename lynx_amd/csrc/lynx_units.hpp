@@ -66,9 +66,21 @@ __global__ __launch_bounds__(256) void k_pack_units(UnitPlan plan, int64_t B, in
 
 // The cavity's non-linear kick on a pair of particles: the expressions of apply_step_pair (lynx_device.hpp), which
 // are device_cavity_kick's (cavity.py:141-161, 219-226), operation for operation.
+// COMPLETE = false: the difference of cosines from cos_difference_small alone, which holds for |d| <= 0.25 rad (d = -s
+// beta0 k: 9 mm of s at 1.3 GHz), and `widest` keeps the largest |d| the lane has seen -- the streaming kernel looks
+// at it once per tile and does a tile that went beyond again with COMPLETE = true, like a tile that met a non-finite
+// value.  (The complete form's branch and its second cosine in the unit loop cost four registers: see cos_difference.)
+template <bool COMPLETE>
 __device__ __forceinline__ void unit_kick(const float (&coef)[8], float sphi, lynx_f32x2 s_in, lynx_f32x2 d_in, lynx_f32x2& o4,
-                                          lynx_f32x2& o5) {
-  const lynx_f32x2 dcos = cos_difference(-1.0f * s_in * coef[LYNX_C_BK], sphi, coef[LYNX_C_COSPHI]);
+                                          lynx_f32x2& o5, float& widest) {
+  const lynx_f32x2 d = -1.0f * s_in * coef[LYNX_C_BK];
+  lynx_f32x2 dcos;
+  if constexpr (COMPLETE) {
+    dcos = cos_difference(d, coef[LYNX_C_PHI], sphi, coef[LYNX_C_COSPHI]);
+  } else {
+    dcos = cos_difference_small<lynx_f32x2>(d, sphi, coef[LYNX_C_COSPHI]);
+    widest = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(d.x), __builtin_fabsf(d.y)), widest);  // (v_max3_f32)
+  }
   o5 = d_in * coef[LYNX_C_DSCALE] + coef[LYNX_C_DKICK] * dcos;
   o4 = o4 + (coef[LYNX_C_T566] * (d_in * d_in) + coef[LYNX_C_T556] * s_in * d_in + coef[LYNX_C_T555] * (s_in * s_in));
 }
@@ -178,8 +190,9 @@ __device__ __forceinline__ void unit_linear(const UnitHalf& map, const float* __
 }
 
 // the non-linear part of a unit, if it has one; (s_own, d_own): the s and delta that entered the unit
+template <bool COMPLETE>
 __device__ __forceinline__ void unit_nonlinear(const UnitHalf& kick, int bits, lynx_f32x2 s_own, lynx_f32x2 d_own,
-                                               lynx_f32x2 (&z)[7]) {
+                                               lynx_f32x2 (&z)[7], float& widest) {
   if (bits & kUnitKick) {  // uniform
     lynx_f32x2 s_in = s_own, d_in = d_own;
     if (bits & kUnitInverse) {
@@ -190,7 +203,7 @@ __device__ __forceinline__ void unit_nonlinear(const UnitHalf& kick, int bits, l
     float coef[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) coef[k] = kick.v[kUnitCoef + k];
-    unit_kick(coef, kick.v[kUnitSinPhi], s_in, d_in, z[4], z[5]);
+    unit_kick<COMPLETE>(coef, kick.v[kUnitSinPhi], s_in, d_in, z[4], z[5], widest);
   }
 }
 
@@ -217,7 +230,8 @@ __device__ __forceinline__ void unit_linear_dense(const float* __restrict__ tab,
 // `all_dense`: every unit in its dense form.  One record fetch per unit serves all pairs.
 template <int PAIRS>
 __device__ __forceinline__ void units_program(int U, const float* __restrict__ s_units, const float* __restrict__ s_extras,
-                                              const float* __restrict__ g_steps, bool all_dense, lynx_f32x2 (&z)[PAIRS][7]) {
+                                              const float* __restrict__ g_steps, bool all_dense, lynx_f32x2 (&z)[PAIRS][7],
+                                              float& widest) {
 #pragma unroll 1
   for (int u = 0; u < U; ++u) {
     const float* rec = s_units + u * kUnitStride;
@@ -251,8 +265,13 @@ __device__ __forceinline__ void units_program(int U, const float* __restrict__ s
 #pragma unroll
       for (int p = 0; p < PAIRS; ++p) unit_linear_dense(g_steps + slot * LYNX_STEP_STRIDE, z[p]);
     }
+    if (all_dense) {  // (uniform; also the pass that does a tile again whose kicks went beyond cos_difference_small's range)
 #pragma unroll
-    for (int p = 0; p < PAIRS; ++p) unit_nonlinear(kick, bits, s_own[p], d_own[p], z[p]);
+      for (int p = 0; p < PAIRS; ++p) unit_nonlinear<true>(kick, bits, s_own[p], d_own[p], z[p], widest);
+    } else {
+#pragma unroll
+      for (int p = 0; p < PAIRS; ++p) unit_nonlinear<false>(kick, bits, s_own[p], d_own[p], z[p], widest);
+    }
   }
 }
 
@@ -343,10 +362,12 @@ __device__ __forceinline__ void track_units_body(
     // cosine and squares included; so the check in front of the units was 10 instructions per tile for nothing)
     bool all_dense = false;
     for (;;) {
-      units_program<PAIRS>(U, g_units, g_extras, g_steps, all_dense, z);
+      float widest = 0.f;  // the largest |d| of a kick on this lane (unit_kick)
+      units_program<PAIRS>(U, g_units, g_extras, g_steps, all_dense, z, widest);
       // what came out: a value that overflowed on the way (or met a non-finite coefficient) would have spread through
-      // the dense chain's zero entries -- then the tile is done again, densely
-      if (all_dense || !any_not_finite()) break;
+      // the dense chain's zero entries -- then the tile is done again, densely; so is a tile one of whose kicks left
+      // the range of the short form of the difference of cosines (a NaN there is among the non-finite ones)
+      if (all_dense || !(any_not_finite() || __builtin_amdgcn_ballot_w64(widest > kCosDifferenceSmall) != 0)) break;
       all_dense = true;
       // reload the tile; the outgoing beam has not been written yet, so in-place tracking is safe
 #pragma unroll
