@@ -720,8 +720,10 @@ def main():
             "data": "synthetic",
             "config": config,
             # config 5's step loop is the structured one (lynx_units.hpp) unless LYNX_TRACK_UNITS=0 asks for the dense loop
-            "roofline": {"bound": "hbm", "kernel": "k_track_units" if (args.workload == "c5" and os.environ.get("LYNX_TRACK_UNITS", "1") != "0")
-                         else "k_track_direct", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            # (its cells are merged [run, cavity] pairs of class U: k_track_unit_pairs, unless LYNX_UNIT_PAIRS=0 keeps the general kernel)
+            "roofline": {"bound": "hbm", "kernel": ("k_track_direct" if (args.workload != "c5" or os.environ.get("LYNX_TRACK_UNITS", "1") == "0")
+                                                    else "k_track_units" if os.environ.get("LYNX_UNIT_PAIRS", "1") == "0" else "k_track_unit_pairs"),
+                         "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes,

@@ -46,6 +46,7 @@ struct Knobs {
   int reduce_wide = 0;        // LYNX_REDUCE_WIDE       1: one 1024-thread workgroup per sample for beams of few samples with a few hundred records each
   int reduce_ticket = 1;      // LYNX_REDUCE_TICKET     samples with more records than one workgroup walks: both levels in one launch (0: two launches)
   int track_units = 1;        // LYNX_TRACK_UNITS       structured step loop (2: insist)
+  int unit_pairs = 1;         // LYNX_UNIT_PAIRS        lattices of merged [run, cavity] pairs of class U: the kernel written for that form (0: the general one, 2: insist)
   int bwd_units = 1;          // LYNX_BWD_UNITS         structured reverse pass
   int bwd_merge = 1;          // LYNX_BWD_MERGE         merged pairs in the reverse pass
   int bwd_pairs = 1;          // LYNX_BWD_PAIRS         two particles per lane in the float32 reverse pass
@@ -66,7 +67,7 @@ static void load_knobs(Knobs* k) {
       {"LYNX_GATHER_OVERLAP", &k->gather_overlap}, {"LYNX_LANES_BUILD_MIN_BATCH", &k->lanes_build_min_batch},
       {"LYNX_PIECE", &k->piece}, {"LYNX_PAIR_LEVELS_FUSED", &k->pair_levels_fused},
       {"LYNX_FUSE_MAX_CHUNKS", &k->fuse_max_chunks}, {"LYNX_MERGE_STEPS", &k->merge_steps},
-      {"LYNX_REDUCE_WIDE", &k->reduce_wide}, {"LYNX_REDUCE_TICKET", &k->reduce_ticket}, {"LYNX_TRACK_UNITS", &k->track_units}, {"LYNX_BWD_UNITS", &k->bwd_units},
+      {"LYNX_REDUCE_WIDE", &k->reduce_wide}, {"LYNX_REDUCE_TICKET", &k->reduce_ticket}, {"LYNX_TRACK_UNITS", &k->track_units}, {"LYNX_UNIT_PAIRS", &k->unit_pairs}, {"LYNX_BWD_UNITS", &k->bwd_units},
       {"LYNX_BWD_MERGE", &k->bwd_merge}, {"LYNX_BWD_PAIRS", &k->bwd_pairs}, {"LYNX_BUILD_IN_TAIL", &k->build_in_tail},
       {"LYNX_SMALL_INLINE", &k->small_inline}, {"LYNX_INLINE_POOL", &k->inline_pool}, {"LYNX_ALTERNATE_ORDER", &k->alternate_order}, {"LYNX_HOST_VISIBLE_RECORDS", &k->host_visible_records}, {"LYNX_BWD_REUSE_TABLE", &k->bwd_reuse_table}};
   for (const auto& t : table) {
@@ -1538,19 +1539,21 @@ static int ensure_units_plan(lynx_ctx* ctx, lynx_lattice* lat, bool merged) {
   return LYNX_OK;
 }
 
-template <int MOM, bool FULL, int PAIRS>
+template <int MOM, bool FULL, int PAIRS, bool PAIR_FORM = false>
 static int launch_units_inst(lynx_ctx* ctx, const TrackPlan& p, int32_t U, int32_t S, const void* d_p_in, void* d_p_out,
                              void* d_energy_out, const void* d_steps, const void* d_units, const void* d_extras,
                              double* d_partials) {
   const size_t lds = units_lds_bytes((size_t)p.a.lds_scratch_bytes, U);
-  int rc = allow_lds(ctx, k_track_units<MOM, FULL, PAIRS>, lds);
+  auto kernel = k_track_units<MOM, FULL, PAIRS>;
+  if constexpr (PAIR_FORM) kernel = k_track_unit_pairs<MOM, FULL>;
+  int rc = allow_lds(ctx, kernel, lds);
   if (rc) return rc;
   hipEvent_t e0 = nullptr, e1 = p.done;
   if (ctx->profiling) {  // every profiled launch needs time stamps of its own
     HIP_TRY(ctx, hipEventCreateWithFlags(&e0, timing_event_flags(ctx)));
     HIP_TRY(ctx, hipEventCreateWithFlags(&e1, timing_event_flags(ctx)));
   }
-  hipExtLaunchKernelGGL((k_track_units<MOM, FULL, PAIRS>), dim3(p.grid), dim3(kTrackThreads), (std::uint32_t)lds, ctx->stream, e0, e1,
+  hipExtLaunchKernelGGL(kernel, dim3(p.grid), dim3(kTrackThreads), (std::uint32_t)lds, ctx->stream, e0, e1,
                         0u, p.a, U, S, (const float*)d_p_in, (float*)d_p_out, (float*)d_energy_out, (const float*)d_steps,
                         (const float*)d_units, (const float*)d_extras, d_partials);
   HIP_TRY(ctx, hipGetLastError());
@@ -1561,8 +1564,11 @@ static int launch_units_inst(lynx_ctx* ctx, const TrackPlan& p, int32_t U, int32
 
 static int launch_units(lynx_ctx* ctx, const TrackPlan& p, int32_t U, int32_t S, const void* d_p_in, void* d_p_out,
                         void* d_energy_out, const void* d_steps, const void* d_units, const void* d_extras,
-                        double* d_partials, bool moments) {
+                        double* d_partials, bool moments, bool pair_form) {
 #define LYNX_UNITS_ARGS ctx, p, U, S, d_p_in, d_p_out, d_energy_out, d_steps, d_units, d_extras, d_partials
+  // every unit proposed as a merged [run, cavity] pair of class U: k_track_unit_pairs
+  if (pair_form)
+    return moments ? launch_units_inst<3, false, 1, true>(LYNX_UNITS_ARGS) : launch_units_inst<0, false, 1, true>(LYNX_UNITS_ARGS);
   if (p.unroll == 4) {  // two pairs per lane
     if (!moments) return launch_units_inst<0, false, 2>(LYNX_UNITS_ARGS);
     if (p.mom_mode == 3) return p.full_cov ? launch_units_inst<3, true, 2>(LYNX_UNITS_ARGS) : launch_units_inst<3, false, 2>(LYNX_UNITS_ARGS);
@@ -1758,8 +1764,18 @@ static int track_particles_t(lynx_ctx* ctx, lynx_lattice* lat, const LatticeDev&
     p.a.reversed = ctx->knobs.alternate_order == 2 ? 1 : (int32_t)(ctx->long_calls++ & 1u);
   p.done = (slot >= 0 && async_build) ? ctx->ev_streamed_own[slot] : nullptr;
   if (side && !p.done) p.done = ring->track_done;  // the side stream's reduction starts behind it
-  if (use_units) rc = launch_units(ctx, p, n_units, S, d_p_in, d_p_out, d_energy_out, d_steps, d_units, d_extras, d_partials, moments);
-  else rc = launch_direct<T>(ctx, p, lv, d_energy_in, d_p_in, d_p_out, d_energy_out, d_steps, d_partials, d_obs, moments);
+  if (use_units) {
+    const UnitPlan& up = lat->units[p.a.merged_pairs ? 1 : 0];
+    bool pair_form = ctx->knobs.unit_pairs != 0;
+    for (int u = 0; u < up.n_units && pair_form; ++u) pair_form = up.cls[u] == kClassU && up.pair[u];
+    pair_form = pair_form && p.unroll != 4 && (!moments || (p.mom_mode == 3 && !p.full_cov));  // (the forms that fit 88 registers)
+    if (ctx->knobs.unit_pairs == 2 && !pair_form)
+      rc = fail(ctx, LYNX_ERR_INVALID, "LYNX_UNIT_PAIRS=2: this call does not take the kernel for lattices of [run, cavity] pairs");
+    else
+      rc = launch_units(ctx, p, n_units, S, d_p_in, d_p_out, d_energy_out, d_steps, d_units, d_extras, d_partials, moments, pair_form);
+  } else {
+    rc = launch_direct<T>(ctx, p, lv, d_energy_in, d_p_in, d_p_out, d_energy_out, d_steps, d_partials, d_obs, moments);
+  }
   if (rc) {
     if (tail) --ctx->tail_seq;  // nothing will announce this number: a later build must not wait for it
     return rc;

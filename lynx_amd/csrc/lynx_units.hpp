@@ -227,8 +227,9 @@ __device__ __forceinline__ void unit_linear_dense(const float* __restrict__ tab,
 }
 
 // The program on the PAIRS pairs of particles a lane holds.  `s_units` / `s_extras`: the sample's records;
-// `all_dense`: every unit in its dense form.  One record fetch per unit serves all pairs.
-template <int PAIRS>
+// `all_dense`: every unit in its dense form.  One record fetch per unit serves all pairs.  DENSE_ONLY: the linear maps in
+// their dense form whatever the records say (what k_track_units' pair form keeps for samples that are not of its form).
+template <int PAIRS, bool DENSE_ONLY>
 __device__ __forceinline__ void units_program(int U, const float* __restrict__ s_units, const float* __restrict__ s_extras,
                                               const float* __restrict__ g_steps, bool all_dense, lynx_f32x2 (&z)[PAIRS][7],
                                               float& widest) {
@@ -239,7 +240,7 @@ __device__ __forceinline__ void units_program(int U, const float* __restrict__ s
     unit_fetch(rec + kUnitMap, map);
     unit_fetch(rec, kick);
     const int bits = __builtin_amdgcn_readfirstlane(__float_as_int(kick.v[kUnitDesc]));  // wave-uniform: scalar branches
-    const int cls = all_dense ? (int)kClassDense : ((bits >> kUnitClassShift) & 3);
+    const int cls = (DENSE_ONLY || all_dense) ? (int)kClassDense : ((bits >> kUnitClassShift) & 3);
     lynx_f32x2 s_own[PAIRS], d_own[PAIRS];
 #pragma unroll
     for (int p = 0; p < PAIRS; ++p) {
@@ -254,10 +255,10 @@ __device__ __forceinline__ void units_program(int U, const float* __restrict__ s
 #pragma unroll
       for (int p = 0; p < PAIRS; ++p) merged_pair_entry(pre, z[p], s_own[p], d_own[p]);
     }
-    if (cls == kClassU) {
+    if (!DENSE_ONLY && cls == kClassU) {
 #pragma unroll
       for (int p = 0; p < PAIRS; ++p) unit_linear<kClassU>(map, nullptr, z[p]);
-    } else if (cls == kClassD) {
+    } else if (!DENSE_ONLY && cls == kClassD) {
 #pragma unroll
       for (int p = 0; p < PAIRS; ++p) unit_linear<kClassD>(map, s_extras + u * kUnitExtraStride, z[p]);
     } else {
@@ -275,6 +276,37 @@ __device__ __forceinline__ void units_program(int U, const float* __restrict__ s
   }
 }
 
+// The same program for a sample ALL of whose units are merged [run, cavity] pairs of class U with an active cavity driven
+// by the entry inverse -- BASELINE config 5's [Drift, misaligned Quadrupole, Drift, Cavity] cells: the same functions in
+// the same order as units_program, so the same bits, without the descriptor's scalar branches around them (a third of
+// the generic loop's scalar instructions, and the register copies where its paths meet).
+constexpr int kUnitFormMask = kUnitKick | kUnitInverse | kUnitRows | (3 << kUnitClassShift);
+constexpr int kUnitFormPairU = kUnitKick | kUnitInverse | ((int)kClassU << kUnitClassShift);
+template <int PAIRS>
+__device__ __forceinline__ void units_program_pairs_u(int U, const float* __restrict__ s_units, lynx_f32x2 (&z)[PAIRS][7],
+                                                      float& widest) {
+#pragma unroll 1
+  for (int u = 0; u < U; ++u) {
+    const float* rec = s_units + u * kUnitStride;
+    UnitHalf kick, map;
+    unit_fetch(rec + kUnitMap, map);
+    unit_fetch(rec, kick);
+#pragma unroll
+    for (int p = 0; p < PAIRS; ++p) {
+      const lynx_f32x2 s_own = z[p][4], d_own = z[p][5];
+      unit_linear<kClassU>(map, nullptr, z[p]);
+      unit_nonlinear<false>(kick, kUnitFormPairU, s_own, d_own, z[p], widest);
+    }
+  }
+}
+
+// true if every unit of the sample has the form units_program_pairs_u is written for (wave-uniform: one descriptor per lane)
+__device__ __forceinline__ bool units_all_pairs_u(int U, const float* __restrict__ s_units) {
+  const int lane = threadIdx.x & 63;
+  const int form = lane < U ? (__float_as_int(s_units[lane * kUnitStride + kUnitDesc]) & kUnitFormMask) : kUnitFormPairU;
+  return __builtin_amdgcn_ballot_w64(form != kUnitFormPairU) == 0;
+}
+
 // ---------------------------------------------------------------------------------------
 // k_track_units: grid.x = B * chunks, 256 threads, 2 PAIRS particles per lane (tid + 256 k of a tile of 512 PAIRS).
 // ---------------------------------------------------------------------------------------
@@ -282,7 +314,7 @@ __device__ __forceinline__ void units_program(int U, const float* __restrict__ s
 // 72 of a SIMD's 512 registers free, and ONE of them retiring makes room for a wave of the next call's build -- 136
 // registers.  At 96 the build waited for two: k_build_pieces 97 -> 357 us underneath BASELINE config 5's streaming
 // kernel, 25 us on every step.)
-template <int MOM, bool FULL, int PAIRS>
+template <int MOM, bool FULL, int PAIRS, bool PAIR_FORM>
 __device__ __forceinline__ void track_units_body(
     const TrackArgs& a, int32_t U, int32_t S, const float* p_in, float* p_out, float* __restrict__ energy_out,
     const float* __restrict__ steps_in, const float* __restrict__ units_in, const float* __restrict__ extras_in,
@@ -320,6 +352,7 @@ __device__ __forceinline__ void track_units_body(
   }
   if (energy_out && chunk == 0 && tid == 0 && S > 0) energy_out[b] = g_steps[(S - 1) * LYNX_STEP_STRIDE + LYNX_ENERGY_OFFSET];
 
+  const bool pairs_u = PAIR_FORM && units_all_pairs_u(U, g_units);
   LaneSums<T, MOM, FULL> sums;
   sums.init();
   T shift[6];
@@ -363,7 +396,12 @@ __device__ __forceinline__ void track_units_body(
     bool all_dense = false;
     for (;;) {
       float widest = 0.f;  // the largest |d| of a kick on this lane (unit_kick)
-      units_program<PAIRS>(U, g_units, g_extras, g_steps, all_dense, z, widest);
+      if constexpr (PAIR_FORM) {
+        if (__builtin_expect(pairs_u && !all_dense, 1)) units_program_pairs_u<PAIRS>(U, g_units, z, widest);
+        else units_program<PAIRS, true>(U, g_units, g_extras, g_steps, all_dense, z, widest);
+      } else {
+        units_program<PAIRS, false>(U, g_units, g_extras, g_steps, all_dense, z, widest);
+      }
       // what came out: a value that overflowed on the way (or met a non-finite coefficient) would have spread through
       // the dense chain's zero entries -- then the tile is done again, densely; so is a tile one of whose kicks left
       // the range of the short form of the difference of cosines (a NaN there is among the non-finite ones)
@@ -393,7 +431,7 @@ __device__ __forceinline__ void track_units_body(
       }
     if (MOM && it == 0) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) shift[k] = in_vector_register(wave_first(zo[0][k]));
+      for (int k = 0; k < 6; ++k) shift[k] = PAIR_FORM ? wave_first(zo[0][k]) : in_vector_register(wave_first(zo[0][k]));
     }
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
@@ -413,7 +451,22 @@ __global__ __launch_bounds__(kTrackThreads, (units_waves_per_simd<MOM, FULL, PAI
     TrackArgs a, int32_t U, int32_t S, const float* p_in, float* p_out, float* __restrict__ energy_out,
     const float* __restrict__ steps_in, const float* __restrict__ units_in, const float* __restrict__ extras_in,
     double* __restrict__ partials) {
-  track_units_body<MOM, FULL, PAIRS>(a, U, S, p_in, p_out, energy_out, steps_in, units_in, extras_in, partials);
+  track_units_body<MOM, FULL, PAIRS, false>(a, U, S, p_in, p_out, energy_out, steps_in, units_in, extras_in, partials);
+}
+
+// The kernel for a lattice whose plan PROPOSES a merged [run, cavity] pair of class U for every unit: samples that keep the
+// promise (units_all_pairs_u looks at the records) walk units_program_pairs_u, the others -- a cavity without voltage, a
+// map that failed the class check -- every unit in its dense form.  Same bits as k_track_units either way.
+// Five waves per SIMD and no more (the hot loop alone would fit seven at 72 registers: config 5 then ran 0.54-0.555 ms a step
+// instead of 0.52-0.53, the next call's build waiting for registers underneath), at most 88 registers like k_track_units --
+// which the dense loop, rarely walked, just fits once the moments' reference point lives in scalar registers here
+// (LYNX_UNIT_PAIRS; instantiated for the two forms that fit: no moments, and moments of mode 3 without the full covariance).
+template <int MOM, bool FULL>
+__global__ __launch_bounds__(kTrackThreads) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_track_unit_pairs(
+    TrackArgs a, int32_t U, int32_t S, const float* p_in, float* p_out, float* __restrict__ energy_out,
+    const float* __restrict__ steps_in, const float* __restrict__ units_in, const float* __restrict__ extras_in,
+    double* __restrict__ partials) {
+  track_units_body<MOM, FULL, 1, true>(a, U, S, p_in, p_out, energy_out, steps_in, units_in, extras_in, partials);
 }
 
 // LDS of k_track_units: the moment slab (TrackArgs.lds_scratch_bytes)

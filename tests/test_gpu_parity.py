@@ -930,6 +930,72 @@ def test_structured_units_equal_the_dense_step_loop_bit_for_bit(lx, monkeypatch,
         assert np.all(np.isnan(outs["1"][0][2, :, :4])) and np.all(np.isfinite(outs["1"][0][[0, 1, 3, 4, 5]]))
 
 
+@pytest.mark.parametrize("case", ["every_sample", "no_voltage", "not_finite", "wide_kick", "no_moments"])
+def test_the_kernel_for_lattices_of_pairs_equals_the_general_one_bit_for_bit(lx, monkeypatch, case):
+    """
+    A float32 lattice all of whose units are merged [run, cavity] pairs of class U -- BASELINE config 5's [Drift, misaligned
+    Quadrupole, Drift, Cavity] cells -- is streamed by a kernel of its own (k_track_unit_pairs, lynx_units.hpp; insisted on
+    with LYNX_UNIT_PAIRS=2): the same functions in the same order without the descriptor's branches.  Same bits as the
+    general kernel (LYNX_UNIT_PAIRS=0) and as the dense step loop (LYNX_TRACK_UNITS=0) -- particles, energy, moment record --
+    when every sample has the form; when one sample's cavities have no voltage (no kick and a NaN map, cavity.py:269:
+    that sample dense, unit by unit); when a tile holds a non-finite particle or one that overflows on the way (the tile
+    again, densely); when kicks leave the short form's range (|k s| > 0.25 rad: the tile again with the complete
+    difference of cosines); and without fused moments.  (A lattice with a tilted quadrupole is not proposed as class U
+    by the host and never reaches this kernel: test_structured_units_equal_the_dense_step_loop_bit_for_bit[coupled].)
+    """
+    B, N = 6, 90_001  # ragged; large enough for two particles per lane, the form large beams get
+    rng = np.random.default_rng(31)
+    f = lambda v: np.full(B, v)  # noqa: E731
+    desc = []
+    for k in range(4):
+        volts = rng.uniform(5e6, 2e7, B)
+        if case == "no_voltage":
+            volts[3] = 0.0
+        desc += [("drift", dict(length=f(0.3))),
+                 ("quadrupole", dict(length=f(0.1), k1=rng.uniform(-5, 5, B), misalignment=rng.normal(0, 1e-4, (B, 2)))),
+                 ("drift", dict(length=f(0.3))),
+                 ("cavity", dict(length=f(1.0377), voltage=volts, phase=rng.uniform(-10, 10, B), frequency=f(1.3e9)))]
+    elements, specs = make_lattice(desc, np.float32, lx)
+    segment = lx.Segment(elements)
+    sigma_s = 5e-3 if case == "wide_kick" else 1e-4  # k = 27.2 rad/m at 1.3 GHz: |k s| > 0.25 beyond 9.2 mm
+    P = o.gaussian_particles((B,), N, seed=7, dtype=np.float32, sigma=[1e-4, 1e-5, 1e-4, 1e-5, sigma_s, 1e-3])
+    if case == "not_finite":
+        P[0, 17, 2] = np.inf
+        P[2, 40_000, 1] = np.nan
+        P[4, 123, 0] = P[4, 123, 1] = 3e38  # finite going in, overflows in the first quadrupole's product
+    if case == "wide_kick":
+        assert (np.abs(P[..., 4]) * 2 * np.pi * 1.3e9 / 299792458.0 > 0.25).any(axis=1).all()
+    beam = lx.ParticleBeam(P, np.full(B, 6e6, np.float32), dtype=np.float32)
+    if case == "no_moments":
+        monkeypatch.setattr(lx.config, "fused_moments", False)
+    outs = {}
+    for name, env in (("pairs", {"LYNX_UNIT_PAIRS": "2", "LYNX_TRACK_UNITS": "2"}), ("general", {"LYNX_UNIT_PAIRS": "0", "LYNX_TRACK_UNITS": "2"}),
+                      ("dense", {"LYNX_TRACK_UNITS": "0"})):
+        for key in ("LYNX_UNIT_PAIRS", "LYNX_TRACK_UNITS"):
+            monkeypatch.delenv(key, raising=False)
+        for key, value in env.items():
+            monkeypatch.setenv(key, value)
+        out = segment.track(beam)
+        outs[name] = [np.asarray(out.particles), np.asarray(out.energy)] + ([] if case == "no_moments" else [np.asarray(out.moment_record())])
+    for other in ("general", "dense"):
+        for k in range(len(outs["pairs"])):
+            assert _same_bits(outs["pairs"][k], outs[other][k]), (case, other, k)
+    got = outs["pairs"][0]
+    ref = o.segment_track(specs, o.particle_beam(P, np.full(B, 6e6, np.float32), np.float32), np.float32)["particles"]
+    # the reference's NaN pattern (a NaN map, a non-finite particle); where a finite particle OVERFLOWS on the way, inf - inf
+    # or not depends on the order of the sums inside numpy's float32 matmul: that one is compared among the kernels only
+    same = np.isnan(got) == np.isnan(ref)
+    if case == "not_finite":
+        same[4, 123] = True
+    assert same.all()
+    if case in ("every_sample", "wide_kick", "no_moments"):
+        assert np.all(np.isfinite(got))
+        # and the oracle's numbers, on the float32 chain or the float64 one (the kick: DESIGN section 2, deviation (v))
+        ref64 = o.segment_track(specs, o.particle_beam(P.astype(np.float64), np.full(B, 6e6), np.float64), np.float64)["particles"]
+        for c in range(6):
+            assert min(rel_err(got[..., c], ref[..., c]), rel_err(got[..., c], ref64[..., c])) < (2e-4 if case == "wide_kick" else 1e-4), (case, c)
+
+
 def test_structured_units_spread_a_non_finite_particle_like_the_dense_chain(lx, monkeypatch):
     """
     0 * inf = NaN: in the reference's `particles @ tm^T` (element.py:85) an infinite y makes every coordinate of that
@@ -1160,7 +1226,7 @@ VARIANTS = [
     {"LYNX_FUSE_MAX_CHUNKS": "64", "LYNX_UNROLL": "1"}, {"LYNX_MIN_TILES_PER_WG": "1"}, {"LYNX_MERGE_STEPS": "0"},
     {"LYNX_SIDE_REDUCE": "1"}, {"LYNX_ASYNC_BUILD": "1", "LYNX_BUILD_HOST_WAIT": "1"}, {"LYNX_BUILD_IN_TAIL": "0", "LYNX_ASYNC_BUILD": "1"},
     {"LYNX_SMALL_INLINE": "0"}, {"LYNX_SMALL_INLINE": "1"},
-    {"LYNX_ALTERNATE_ORDER": "2", "LYNX_UNROLL": "1"}, {"LYNX_ALTERNATE_ORDER": "2", "LYNX_TRACK_UNITS": "0"},
+    {"LYNX_ALTERNATE_ORDER": "2", "LYNX_UNROLL": "1"}, {"LYNX_ALTERNATE_ORDER": "2", "LYNX_TRACK_UNITS": "0"}, {"LYNX_UNIT_PAIRS": "0"},
 ]
 
 
