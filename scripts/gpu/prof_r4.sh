@@ -30,6 +30,7 @@ done; done
 for un in 1 0; do
   LYNX_TRACK_UNITS=$un timeout -k 10 200 python bench.py --workload c5 --steps 40 --warmup 5 --no-cpu-baseline > $OUT/c5_units$un.json 2> $OUT/c5_units$un.err
 done
+LYNX_UNIT_PAIRS=0 timeout -k 10 200 python bench.py --workload c5 --steps 40 --warmup 5 --no-cpu-baseline > $OUT/c5_general.json 2> $OUT/c5_general.err
 timeout -k 10 300 python bench.py --workload c5 --steps 20 --warmup 3 > $OUT/c5_default.json 2> $OUT/c5_default.err
 timeout -k 10 200 python bench.py --workload c5 --grad --steps 20 --warmup 3 --no-cpu-baseline > $OUT/c5grad.json 2> $OUT/c5grad.err
 LYNX_BWD_UNITS=0 timeout -k 10 200 python bench.py --workload c5 --grad --steps 10 --warmup 2 --no-cpu-baseline > $OUT/c5grad_dense.json 2> $OUT/c5grad_dense.err

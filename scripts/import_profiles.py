@@ -44,6 +44,7 @@ for b in (1024, 512, 256, 128):
     put(src / f"shard_b{b}_1.json", f"c4_shard_b{b}_bench.json")
 put(src / "c5_units1.json", "c5_bench_units.json")
 put(src / "c5_units0.json", "c5_bench_dense_step_loop.json")
+put(src / "c5_general.json", "c5_bench_general_kernel.json")
 put(src / "c5_default.json", "c5_bench_default.json")
 put(src / "c5grad.json", "c5grad_bench.json")
 put(src / "steady_c3big.json", "c3big_bench_steady.json")
