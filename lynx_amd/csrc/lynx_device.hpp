@@ -1094,6 +1094,17 @@ __device__ __forceinline__ lynx_f32x2 cos_difference(lynx_f32x2 d, float phi, fl
   return out;
 }
 
+// What the float32 kick leaves in s and delta (cavity.py:151-161, :219-226), given the difference of cosines: the
+// reference's sums as chains of fused multiply-adds like the linear maps' rows (deviation (iv)) --
+// 7 operations where the expression as written takes 12, a ninth of a unit of BASELINE config 5.  ONE function for the
+// scalar and the packed form, the step loop and the unit loops: they agree bit for bit.
+template <typename V>
+__device__ __forceinline__ void kick_outputs(const float* coef, V s_in, V d_in, V dcos, V& s_out, V& d_out) {
+  d_out = vfma(dcos, V(coef[LYNX_C_DKICK]), d_in * coef[LYNX_C_DSCALE]);
+  const V t = vfma(d_in, V(coef[LYNX_C_T566]), s_in * coef[LYNX_C_T556]);  // T566 delta + T556 s
+  s_out = vfma(s_in * s_in, V(coef[LYNX_C_T555]), vfma(t, d_in, s_out));
+}
+
 // Non-linear cavity step on the device.  float64: the expression of cavity_kick<T> (lynx_maps.hpp, the one the host
 // harness checks against the oracle).  float32: the same with the difference of cosines from cos_difference;
 // `coef` points at the step-table row's coefficients, sin(phi) sits behind them (LYNX_SINPHI_OFFSET).
@@ -1102,13 +1113,13 @@ __device__ __forceinline__ void device_cavity_kick(const T* coef, T s_in, T d_in
   if constexpr (sizeof(T) == 4) {
     const float dcos = cos_difference(T(-1) * s_in * coef[LYNX_C_BK], coef[LYNX_C_PHI], coef[LYNX_SINPHI_OFFSET - LYNX_COEF_OFFSET],
                                       coef[LYNX_C_COSPHI]);
-    d_out = d_in * coef[LYNX_C_DSCALE] + coef[LYNX_C_DKICK] * dcos;
+    kick_outputs<float>(coef, s_in, d_in, dcos, s_out, d_out);
   } else {
     d_out = d_in * coef[LYNX_C_DSCALE] +
             coef[LYNX_C_DKICK] * (phase_cos(T(-1) * s_in * coef[LYNX_C_BK] + coef[LYNX_C_PHI]) - coef[LYNX_C_COSPHI]);
+    s_out = s_out + (coef[LYNX_C_T566] * (d_in * d_in) + coef[LYNX_C_T556] * s_in * d_in +
+                     coef[LYNX_C_T555] * (s_in * s_in));
   }
-  s_out = s_out + (coef[LYNX_C_T566] * (d_in * d_in) + coef[LYNX_C_T556] * s_in * d_in +
-                   coef[LYNX_C_T555] * (s_in * s_in));
 }
 
 // Apply one step of the program to one particle held in registers.
@@ -1187,9 +1198,7 @@ __device__ __forceinline__ void apply_step_pair(const float* M /*49 + coef (+ 4)
     }
     const lynx_f32x2 dcos = cos_difference(-1.0f * s_in * coef[LYNX_C_BK], coef[LYNX_C_PHI], coef[LYNX_SINPHI_OFFSET - LYNX_COEF_OFFSET],
                                            coef[LYNX_C_COSPHI]);
-    o[5] = d_in * coef[LYNX_C_DSCALE] + coef[LYNX_C_DKICK] * dcos;
-    o[4] = o[4] + (coef[LYNX_C_T566] * (d_in * d_in) + coef[LYNX_C_T556] * s_in * d_in +
-                   coef[LYNX_C_T555] * (s_in * s_in));
+    kick_outputs<lynx_f32x2>(coef, s_in, d_in, dcos, o[4], o[5]);
   }
 #pragma unroll
   for (int i = 0; i < 7; ++i) z[i] = o[i];

@@ -81,8 +81,7 @@ __device__ __forceinline__ void unit_kick(const float (&coef)[8], float sphi, ly
     dcos = cos_difference_small<lynx_f32x2>(d, sphi, coef[LYNX_C_COSPHI]);
     widest = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(d.x), __builtin_fabsf(d.y)), widest);  // (v_max3_f32)
   }
-  o5 = d_in * coef[LYNX_C_DSCALE] + coef[LYNX_C_DKICK] * dcos;
-  o4 = o4 + (coef[LYNX_C_T566] * (d_in * d_in) + coef[LYNX_C_T556] * s_in * d_in + coef[LYNX_C_T555] * (s_in * s_in));
+  kick_outputs<lynx_f32x2>(coef, s_in, d_in, dcos, o4, o5);
 }
 
 // one 2-row block with up to four columns: (za, zb) <- rows (ra, rb) applied to the given columns, in ascending
