@@ -227,7 +227,7 @@ __device__ __forceinline__ void unit_linear_dense(const float* __restrict__ tab,
 
 // The program on the PAIRS pairs of particles a lane holds.  `s_units` / `s_extras`: the sample's records;
 // `all_dense`: every unit in its dense form.  One record fetch per unit serves all pairs.  DENSE_ONLY: the linear maps in
-// their dense form whatever the records say (what k_track_units' pair form keeps for samples that are not of its form).
+// their dense form whatever the records say (what k_track_unit_pairs keeps for samples that are not of its form).
 template <int PAIRS, bool DENSE_ONLY>
 __device__ __forceinline__ void units_program(int U, const float* __restrict__ s_units, const float* __restrict__ s_extras,
                                               const float* __restrict__ g_steps, bool all_dense, lynx_f32x2 (&z)[PAIRS][7],
