@@ -273,8 +273,9 @@ __device__ __forceinline__ void kick_cotangents(const T* cf, T sphi, T cphi, Z z
   cc[LYNX_C_T566] = o4b * (z5 * z5);
   cc[LYNX_C_T556] = o4b * (z4 * z5);
   cc[LYNX_C_T555] = o4b * (z4 * z4);
-  dir4 = ab * (-cf[LYNX_C_BK]) + o4b * (cf[LYNX_C_T556] * z5 + T(2) * cf[LYNX_C_T555] * z4);
-  dir5 = o5b * cf[LYNX_C_DSCALE] + o4b * (T(2) * cf[LYNX_C_T566] * z5 + cf[LYNX_C_T556] * z4);
+  // (as chains of fused multiply-adds: 4 operations each where the expressions as written take 7)
+  dir4 = zfma(o4b, zfma(z5, Z(cf[LYNX_C_T556]), z4 * (T(2) * cf[LYNX_C_T555])), ab * (-cf[LYNX_C_BK]));
+  dir5 = zfma(o4b, zfma(z5, Z(T(2) * cf[LYNX_C_T566]), z4 * cf[LYNX_C_T556]), o5b * cf[LYNX_C_DSCALE]);
 }
 // sine and cosine of the cavity's phase, once per unit (wave-uniform)
 template <typename T> __device__ __forceinline__ void phase_of(T phi, T& sphi, T& cphi) {
