@@ -45,6 +45,7 @@ struct Knobs {
   int merge_steps = 1;        // LYNX_MERGE_STEPS       [run, cavity] pairs as one unit
   int reduce_wide = 0;        // LYNX_REDUCE_WIDE       1: one 1024-thread workgroup per sample for beams of few samples with a few hundred records each
   int reduce_ticket = 1;      // LYNX_REDUCE_TICKET     samples with more records than one workgroup walks: both levels in one launch (0: two launches)
+  int one_round = -1;         // LYNX_ONE_ROUND         at most this many workgroups per CU in a launch (0: no cap; default: 3 for single-map launches of a few rounds)
   int track_units = 1;        // LYNX_TRACK_UNITS       structured step loop (2: insist)
   int unit_pairs = 1;         // LYNX_UNIT_PAIRS        lattices of merged [run, cavity] pairs of class U: the kernel written for that form (0: the general one, 2: insist)
   int bwd_units = 1;          // LYNX_BWD_UNITS         structured reverse pass
@@ -67,7 +68,7 @@ static void load_knobs(Knobs* k) {
       {"LYNX_GATHER_OVERLAP", &k->gather_overlap}, {"LYNX_LANES_BUILD_MIN_BATCH", &k->lanes_build_min_batch},
       {"LYNX_PIECE", &k->piece}, {"LYNX_PAIR_LEVELS_FUSED", &k->pair_levels_fused},
       {"LYNX_FUSE_MAX_CHUNKS", &k->fuse_max_chunks}, {"LYNX_MERGE_STEPS", &k->merge_steps},
-      {"LYNX_REDUCE_WIDE", &k->reduce_wide}, {"LYNX_REDUCE_TICKET", &k->reduce_ticket}, {"LYNX_TRACK_UNITS", &k->track_units}, {"LYNX_UNIT_PAIRS", &k->unit_pairs}, {"LYNX_BWD_UNITS", &k->bwd_units},
+      {"LYNX_REDUCE_WIDE", &k->reduce_wide}, {"LYNX_REDUCE_TICKET", &k->reduce_ticket}, {"LYNX_TRACK_UNITS", &k->track_units}, {"LYNX_ONE_ROUND", &k->one_round}, {"LYNX_UNIT_PAIRS", &k->unit_pairs}, {"LYNX_BWD_UNITS", &k->bwd_units},
       {"LYNX_BWD_MERGE", &k->bwd_merge}, {"LYNX_BWD_PAIRS", &k->bwd_pairs}, {"LYNX_BUILD_IN_TAIL", &k->build_in_tail},
       {"LYNX_SMALL_INLINE", &k->small_inline}, {"LYNX_INLINE_POOL", &k->inline_pool}, {"LYNX_ALTERNATE_ORDER", &k->alternate_order}, {"LYNX_HOST_VISIBLE_RECORDS", &k->host_visible_records}, {"LYNX_BWD_REUSE_TABLE", &k->bwd_reuse_table}};
   for (const auto& t : table) {
@@ -1387,6 +1388,16 @@ static TrackPlan plan_track(lynx_ctx* ctx, const lynx_lattice* lat, int64_t B, i
   int64_t min_tpw = std::max(1, knob(kn.min_tiles_per_wg, S > 1 ? 16 : 2));
   while (min_tpw > 1 && B * ((ntiles + min_tpw - 1) / min_tpw) < 4 * cus) --min_tpw;
   int64_t chunks = std::max<int64_t>(1, std::min<int64_t>((ntiles + min_tpw - 1) / min_tpw, (target + B - 1) / B));
+  // A launch of a FEW rounds of workgroups is better off as ONE round of longer-lived ones: a workgroup of the single-map
+  // kernels takes ~10 us whatever it does (table load, first tile's latency, moment epilogue), three of them fit a CU
+  // (162-164 registers), and BASELINE config 3 as worded -- one sample, 1 M particles, 1954 tiles -- ran 1954 one-tile
+  // workgroups in 2.5 rounds: 28.9 us; 652 workgroups of three tiles: 23.7 (46 -> 39 us a step).  Launches of many rounds
+  // keep their short-lived workgroups (capped the same way: c3big 155 -> 189 us, config 4 0.96 -> 1.2-1.3 ms).
+  {
+    const int64_t one_round = 3 * cus;
+    const int cap = knob(kn.one_round, (S <= 1 && B * chunks > one_round && B * chunks <= 4 * one_round) ? 3 : 0);
+    if (cap > 0) chunks = std::max<int64_t>(1, std::min<int64_t>(chunks, cap * cus / B));
+  }
   int64_t tpw = (ntiles + chunks - 1) / chunks;
   chunks = (ntiles + tpw - 1) / tpw;
   p.a.chunks = (int32_t)chunks;

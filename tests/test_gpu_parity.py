@@ -1227,6 +1227,7 @@ VARIANTS = [
     {"LYNX_SIDE_REDUCE": "1"}, {"LYNX_ASYNC_BUILD": "1", "LYNX_BUILD_HOST_WAIT": "1"}, {"LYNX_BUILD_IN_TAIL": "0", "LYNX_ASYNC_BUILD": "1"},
     {"LYNX_SMALL_INLINE": "0"}, {"LYNX_SMALL_INLINE": "1"},
     {"LYNX_ALTERNATE_ORDER": "2", "LYNX_UNROLL": "1"}, {"LYNX_ALTERNATE_ORDER": "2", "LYNX_TRACK_UNITS": "0"}, {"LYNX_UNIT_PAIRS": "0"},
+    {"LYNX_ONE_ROUND": "0"}, {"LYNX_ONE_ROUND": "1"},
 ]
 
 
