@@ -682,8 +682,10 @@ def main():
     if pmc and batch == WORKLOADS[args.workload][0] and particles == WORKLOADS[args.workload][1]:
         try:
             rec = json.loads(pmc[-1].read_text())
-            fetch = next(v["mean_KB"] for k, v in rec.items() if "k_track_direct" in k and k.endswith("FETCH_SIZE"))
-            write = next(v["mean_KB"] for k, v in rec.items() if "k_track_direct" in k and k.endswith("WRITE_SIZE"))
+            # (the streaming kernel of the workload: k_track_direct, or k_track_unit_pairs / k_track_units for config 5)
+            stream = "k_track_unit" if args.workload == "c5" else "k_track_direct"
+            fetch = next(v["mean_KB"] for k, v in rec.items() if stream in k and k.endswith("FETCH_SIZE"))
+            write = next(v["mean_KB"] for k, v in rec.items() if stream in k and k.endswith("WRITE_SIZE"))
             # gfx950: FETCH_SIZE counts 64 B per 128-B request -> x2 (MI355X_MICROARCH.md, HBM);
             # calibrated on k_diag_copy in the same profile run.  Units: KiB.
             traffic = (2.0 * fetch + write) * 1024.0

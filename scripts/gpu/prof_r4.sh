@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-4 profile series: rocprofv3 kernel trace + stats for every bench workload, FETCH_SIZE / WRITE_SIZE in separate
-# PMC passes for c4, c4a and c3big, the default bench line (with the CPU baseline), the RCCL path at world size 1, the
+# PMC passes for c4, c4a, c3big and c5, the default bench line (with the CPU baseline), the RCCL path at world size 1, the
 # small configurations pipelined and waited for, the latency table, config 5 forward and forward + reverse, the strong-
 # scaling shards of config 4, SQ counters of config 5's kernels.  SERIES=<letter> names the output
 # (gpurun_out/prof_r4_<letter>); scripts/import_profiles.py <letter> r04 copies the summaries to profiles/.
@@ -10,7 +10,7 @@ for w in c4 c4a c3 c3big c5 c2; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$w -- python3 bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline > $OUT/trace_$w.json 2> $OUT/trace_$w.err
 done
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_c5grad -- python3 bench.py --workload c5 --grad --steps 5 --warmup 1 --no-cpu-baseline > $OUT/trace_c5grad.json 2> $OUT/trace_c5grad.err
-for w in c4 c4a c3big; do
+for w in c4 c4a c3big c5; do
   timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$w -- python3 bench.py --workload $w --steps 5 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch_$w.json 2> $OUT/pmc_fetch_$w.err
   timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$w -- python3 bench.py --workload $w --steps 5 --warmup 1 --no-cpu-baseline > $OUT/pmc_write_$w.json 2> $OUT/pmc_write_$w.err
 done
@@ -56,7 +56,7 @@ for w in ('c4','c4a','c3','c3big','c5','c2','c5grad'):
             n=r['Name']
             if 'diag_copy' in n or 'fill_gaussian' in n or 'rocclr' in n: continue
             print('  %-50s calls %3s avg %10.1f us  min %9.1f  max %9.1f'%(n.replace('void lynx::','').replace('lynx::','')[:50], r['Calls'], float(r['AverageNs'])/1e3, float(r['MinNs'])/1e3, float(r['MaxNs'])/1e3))
-for w in ('c4','c4a','c3big'):
+for w in ('c4','c4a','c3big','c5'):
     rec={}
     for kind in ('fetch','write'):
         for f in glob.glob(out+'/pmc_%s_%s/*/*counter_collection.csv'%(kind,w)):
@@ -66,7 +66,7 @@ for w in ('c4','c4a','c3big'):
             for (k,c),v in agg.items(): rec['%s|%s'%(k,c)]={'n':len(v),'mean_KB':sum(v)/len(v)}
     json.dump(rec, open(out+'/%s_pmc_traffic.json'%w,'w'), indent=1)
     for k,v in rec.items():
-        if 'k_track_direct' in k or 'diag_copy' in k: print(w,k,v)
+        if 'k_track_' in k or 'diag_copy' in k: print(w,k,v)
 t={}
 for f in sorted(glob.glob(out+'/shard_b*_*.json')):
     try:

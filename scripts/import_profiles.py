@@ -30,7 +30,7 @@ for w in ("c4", "c4a", "c3", "c3big", "c5", "c2", "c5grad"):
     if stats:
         put(stats[-1], f"{w}_kernel_stats.csv")
     put(src / f"trace_{w}.json", f"{w}_bench_under_rocprof.json")
-for w in ("c4", "c4a", "c3big"):
+for w in ("c4", "c4a", "c3big", "c5"):
     put(src / f"{w}_pmc_traffic.json", f"{w}_pmc_traffic.json")
 put(src / "default.json", "c4_bench_default.json")
 put(src / "rccl_world1.json", "c4_bench_rccl_world1.json")
