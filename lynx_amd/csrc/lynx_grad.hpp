@@ -73,6 +73,11 @@ struct BwdArgs {
   // of the reading is one more term of every particle's cotangent at that point of the reverse sweep.
   unsigned char unit_observer[kBwdGroup * kBwdMaxGroups];
   int32_t n_observers;
+  // rows per sample of the partial-sum table when that is more than this launch's `chunks` (0: `chunks`): k_track_bwd
+  // launched with ONE workgroup per sample next to k_track_bwd_units (track_backward_t) writes row 0 and clears the rest
+  int32_t out_chunks;
+  int32_t n_work;     // k_track_bwd: pieces of work (sample, chunk) in this launch
+  int32_t leave_odd;  // tests (LYNX_BWD_UNITS=2): every odd sample is left to k_track_bwd whatever class its units have
 };
 
 // ---------------------------------------------------------------------------------------
@@ -323,24 +328,26 @@ template <typename T, int W> struct ExGeom {
   static constexpr int kPieces = kRow / (8 * kVW);         // accesses per lane and row
 };
 
+// what one workgroup of k_track_bwd does: chunk `work % a.chunks` of sample `work / a.chunks`
 template <typename T, typename Z>
-__global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
-    LatticeDev lat, BwdArgs a, const T* __restrict__ p_in, const T* __restrict__ steps,
+__device__ __forceinline__ void track_bwd_workgroup(
+    const LatticeDev& lat, const BwdArgs& a, uint32_t work, const T* __restrict__ p_in, const T* __restrict__ steps,
     const double* __restrict__ moments_fwd, const double* __restrict__ grad_moments,
     T* __restrict__ partials /* [B][chunks][S][64] */, T* __restrict__ grad_p /* [B][N][7] or null */,
-    const float* __restrict__ units_skip = nullptr /* unit records: samples whose units are all of class U belong to
-                                                       k_track_bwd_units (lynx_grad_units.hpp) */,
-    int units_stride = 0, int units_class_shift = 0, int units_class_u = 0,
-    const double* __restrict__ grad_observations = nullptr /* [B][n_observers][2] or null: dL/d(reading) */) {
+    const float* __restrict__ units_skip, int units_stride, int units_class_shift, int units_class_u,
+    const double* __restrict__ grad_observations) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int K = kBwdGroup;
   constexpr int W = LaneOf<Z>::W;
   if (units_skip) {  // uniform
-    const float* rec = units_skip + (blockIdx.x / a.chunks) * (int64_t)a.n_units * units_stride;
-    bool all = true;
-    for (int u = 0; u < a.n_units; ++u)
-      all = all && ((__float_as_int((float)rec[u * units_stride]) >> units_class_shift) & 3) == units_class_u;
-    if (all) return;
+    const float* rec = units_skip + (work / a.chunks) * (int64_t)a.n_units * units_stride;
+    bool other = false;  // (one descriptor per lane, 64 at a time: one round trip where a loop over the units takes n_units)
+    for (int u0 = 0; u0 < a.n_units; u0 += 64) {
+      const int u = u0 + (int)(threadIdx.x & 63);
+      other = other || (u < a.n_units && ((__float_as_int((float)rec[u * units_stride]) >> units_class_shift) & 3) != units_class_u);
+    }
+    const bool all = __builtin_amdgcn_ballot_w64(other) == 0;
+    if (all && !(a.leave_odd && ((work / a.chunks) & 1))) return;
   }
   using Geo = ExGeom<T, W>;
   using V = typename VecOf<T, true>::type;  // 16-byte LDS accesses
@@ -355,8 +362,8 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
   Z stack[kBwdMaxGroups * 7];                                // private: state entering step g*K
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t b = blockIdx.x / a.chunks;
-  const int chunk = blockIdx.x % a.chunks;
+  const int64_t b = work / a.chunks;
+  const int chunk = work % a.chunks;
   const int64_t N = a.n_particles;
   const T* g_steps = steps + b * (int64_t)S * LYNX_STEP_STRIDE;
   T* ex = s_ex + wave * (kExRows * P);
@@ -611,9 +618,32 @@ __global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
   }
 
   __syncthreads();
-  T* out = partials + (((int64_t)b * a.chunks + chunk) * S) * kGradStride;
+  const int rows = a.out_chunks > 0 ? a.out_chunks : a.chunks;
+  T* out = partials + (((int64_t)b * rows + chunk) * S) * kGradStride;
   for (int idx = tid; idx < S * 64; idx += kTrackThreads) {
     out[idx] = ((s_acc[idx] + s_acc[S * 64 + idx]) + s_acc[2 * S * 64 + idx]) + s_acc[3 * S * 64 + idx];
+  }
+  if (a.out_chunks > a.chunks) {  // (one workgroup for the whole sample: the rows of the workgroups that are not there)
+    for (int64_t idx = tid; idx < (int64_t)(rows - a.chunks) * S * kGradStride; idx += kTrackThreads)
+      partials[(((int64_t)b * rows + a.chunks) * S) * kGradStride + idx] = T(0);
+  }
+}
+
+// grid = a.n_work (= B * chunks) workgroups, or fewer that take several pieces of work each (track_backward_t: the launch
+// next to k_track_bwd_units, whose workgroups mostly find nothing to do)
+template <typename T, typename Z>
+__global__ __launch_bounds__(kTrackThreads) void k_track_bwd(
+    LatticeDev lat, BwdArgs a, const T* __restrict__ p_in, const T* __restrict__ steps,
+    const double* __restrict__ moments_fwd, const double* __restrict__ grad_moments,
+    T* __restrict__ partials /* [B][chunks][S][64] */, T* __restrict__ grad_p /* [B][N][7] or null */,
+    const float* __restrict__ units_skip = nullptr /* unit records: samples whose units are all of class U belong to
+                                                       k_track_bwd_units (lynx_grad_units.hpp) */,
+    int units_stride = 0, int units_class_shift = 0, int units_class_u = 0,
+    const double* __restrict__ grad_observations = nullptr /* [B][n_observers][2] or null: dL/d(reading) */) {
+  for (uint32_t work = blockIdx.x; work < (uint32_t)a.n_work; work += gridDim.x) {
+    track_bwd_workgroup<T, Z>(lat, a, work, p_in, steps, moments_fwd, grad_moments, partials, grad_p, units_skip, units_stride,
+                              units_class_shift, units_class_u, grad_observations);
+    __syncthreads();  // (the LDS sums of this piece have been read by everybody before the next one clears them)
   }
 }
 

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(kTrackThreads, (MAXU <= 8 ? LYNX_BWD_UNITS_WAVES : 
   const int64_t N = a.n_particles;
   const float* g_units = units + b * (int64_t)U * kUnitStride;
   const float* g_extras = extras + b * (int64_t)U * kUnitExtraStride;
-  if (!sample_is_class_u(g_units, U)) return;  // this sample belongs to k_track_bwd
+  if (!sample_is_class_u(g_units, U) || (a.leave_odd && (b & 1))) return;  // this sample belongs to k_track_bwd
 
   T* acc = s_acc + wave * (S * 64);
   for (int s = 0; s < S; ++s) acc[s * 64 + lane] = T(0);
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(64) void k_finish_tbar_units(BwdArgs a, int32_t S, 
   const int U = a.n_units;
   const int u = threadIdx.x;
   const float* g_units = units + b * (int64_t)U * kUnitStride;
-  if (!sample_is_class_u(g_units, U)) return;  // uniform
+  if (!sample_is_class_u(g_units, U) || (a.leave_odd && (b & 1))) return;  // uniform
   float* row0 = tbar + (b * S + a.unit_slot[0]) * (int64_t)kGradStride;
   double Sx[6], Sy[6];
 #pragma unroll

@@ -48,7 +48,7 @@ struct Knobs {
   int one_round = -1;         // LYNX_ONE_ROUND         at most this many workgroups per CU in a launch (0: no cap; default: 3 for single-map launches of a few rounds)
   int track_units = 1;        // LYNX_TRACK_UNITS       structured step loop (2: insist)
   int unit_pairs = 1;         // LYNX_UNIT_PAIRS        lattices of merged [run, cavity] pairs of class U: the kernel written for that form (0: the general one, 2: insist)
-  int bwd_units = 1;          // LYNX_BWD_UNITS         structured reverse pass
+  int bwd_units = 1;          // LYNX_BWD_UNITS         structured reverse pass (2, for tests: every odd sample is left to the dense kernel all the same)
   int bwd_merge = 1;          // LYNX_BWD_MERGE         merged pairs in the reverse pass
   int bwd_pairs = 1;          // LYNX_BWD_PAIRS         two particles per lane in the float32 reverse pass
   int build_in_tail = 1;      // LYNX_BUILD_IN_TAIL     start the next build in the tail of the streaming kernel
@@ -1982,6 +1982,9 @@ static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const v
                 !(lat->h_steps[s - 1].flags & LYNX_STEP_FLAG_OBSERVE);
   a.n_units = 0;
   a.n_observers = 0;
+  a.out_chunks = 0;
+  a.n_work = 0;
+  a.leave_odd = ctx->knobs.bwd_units == 2 ? 1 : 0;
   for (int32_t s = 0; s < S; ++s) {
     const bool pair = merged && s + 1 < S && lat->h_steps[s].kind == LYNX_STEP_RUN &&
                       lat->h_steps[s + 1].kind == LYNX_STEP_CAVITY && !(lat->h_steps[s].flags & LYNX_STEP_FLAG_OBSERVE);
@@ -2000,6 +2003,7 @@ static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const v
   // float32 packed pairs: samples whose units all have class U take the structured reverse kernel (lynx_grad_units.hpp)
   float* d_units = nullptr;
   float* d_extras = nullptr;
+  bool all_proposed_u = false;  // the plan proposes class U for every unit: only a sample with a non-finite map is left to k_track_bwd
   if constexpr (W == 2) {
     if (ctx->knobs.bwd_units) {
       if ((rc = ensure_units_plan(ctx, lat, merged != 0))) return rc;
@@ -2014,6 +2018,8 @@ static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const v
           return rc;
         d_units = (float*)ctx->scratch_units_bwd[0];
         d_extras = (float*)ctx->scratch_units_bwd[1];
+        all_proposed_u = true;
+        for (int u = 0; u < up.n_units; ++u) all_proposed_u = all_proposed_u && up.cls[u] == kClassU;
       }
     }
   }
@@ -2084,7 +2090,23 @@ static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const v
       HIP_TRY(ctx, hipGetLastError());
     }
   }
-  hipLaunchKernelGGL((k_track_bwd<T, Z>), dim3((unsigned)(B * chunks)), dim3(kTrackThreads), lds, ctx->stream, lv, a,
+  // Next to k_track_bwd_units this kernel is there for the samples that one left: workgroups of the others return at once --
+  // 40 us for BASELINE config 5's 40 960 of them, which take 60 KB of LDS each to be placed.  When the plan proposes class
+  // U for EVERY unit, only a sample with a non-finite map can be left: ONE workgroup per sample then (it walks all of
+  // the sample's tiles, writes row 0 of the sample's partial sums and clears the rest).
+  BwdArgs a_dense = a;
+  a_dense.n_work = (int32_t)(B * chunks);
+  int64_t dense_grid = B * chunks;
+  if (d_units && all_proposed_u) {
+    if (chunks > 1) {
+      a_dense.out_chunks = (int32_t)chunks;
+      a_dense.chunks = 1;
+      a_dense.tiles_per_wg = (int32_t)ntiles;
+    }
+    a_dense.n_work = (int32_t)B;
+    dense_grid = std::min<int64_t>(B, 2 * cus);  // (and as many workgroups as are resident at once: they look at B / grid samples each)
+  }
+  hipLaunchKernelGGL((k_track_bwd<T, Z>), dim3((unsigned)dense_grid), dim3(kTrackThreads), lds, ctx->stream, lv, a_dense,
                      (const T*)d_p_in, (const T*)d_table, d_moments_fwd, d_grad_moments,
                      (T*)ctx->scratch_grad[0], (T*)d_grad_p_in, (const float*)d_units, kUnitStride, kUnitClassShift, (int)kClassU,
                      d_grad_observations);

@@ -214,6 +214,79 @@ def test_structured_reverse_pass_fp32(lx, monkeypatch, B, N):
             assert any(np.any(structured[key] != dense[key]) for key in g64)
 
 
+def test_samples_the_structured_reverse_kernel_leaves_to_the_dense_one(lx, monkeypatch):
+    """
+    Next to k_track_bwd_units the dense k_track_bwd is launched for the samples that kernel leaves.  When the lattice's
+    plan proposes class U for every unit, such a sample can only be one whose map is not finite, and the dense kernel
+    gets ONE workgroup per sample (all of the sample's tiles, row 0 of its partial sums, the other rows cleared) instead
+    of `chunks` of them that return at once.  (a) LYNX_BWD_UNITS=2 leaves every odd sample to that launch whatever its
+    class: every gradient as from the structured pass alone (default) and from the dense pass alone (LYNX_BWD_UNITS=0),
+    to the sums' re-association, and the float64 pass as in test_structured_reverse_pass_fp32.  (b) a cavity without
+    voltage in ONE sample (NaN map, cavity.py:269): the other samples' gradients are what they are without it.
+    """
+    B, N = 4, 6000  # 12 tiles of 512 per sample: several workgroups per sample in the structured kernel
+    rng = np.random.default_rng(47)
+    f = lambda v: np.full(B, v)  # noqa: E731
+    volts = [rng.uniform(5e6, 2e7, B) for _ in range(3)]
+
+    def lattice(dead=None):
+        r = np.random.default_rng(48)
+        desc = []
+        for cell in range(3):
+            v = volts[cell].copy()
+            if dead is not None and cell == 1:
+                v[dead] = 0.0
+            desc += [("drift", dict(length=f(0.3))),
+                     ("quadrupole", dict(length=f(0.1), k1=r.uniform(-5, 5, B), misalignment=r.normal(0, 1e-3, (B, 2)))),
+                     ("drift", dict(length=f(0.3))),
+                     ("cavity", dict(length=f(1.0377), voltage=v, phase=r.uniform(-10, 10, B), frequency=f(1.3e9)))]
+        return desc
+
+    P = o.gaussian_particles((B,), N, seed=10, dtype=np.float64, sigma=[1e-3, 1e-4, 1e-3, 1e-4, 1e-3, 1e-3],
+                             mu=[1e-3, -1e-4, 5e-4, 2e-4, 1e-4, 1e-3])
+    energy = rng.uniform(6e6, 8e6, B)
+    w_mu = rng.normal(size=(B, 6))
+    w_cov = rng.normal(size=(B, 6, 6)) * 1e3
+
+    def gradients(desc, dtype):
+        elements, _ = make_lattice(desc, dtype, lx)
+        g = lx.grad.track_vjp(lx.Segment(elements), lx.ParticleBeam(P.astype(dtype), energy.astype(dtype), dtype=dtype))(
+            mu_bar=w_mu, cov_bar=w_cov, wrt_particles=True)
+        out = {(e, name): np.asarray(g[elements[e]][name], dtype=np.float64)
+               for e, (kind, _) in enumerate(desc) for name in PARAMS_TO_CHECK.get(kind, [])
+               if getattr(elements[e], name, None) is not None}
+        out["energy"] = np.asarray(g.energy, dtype=np.float64)
+        out["particles"] = np.asarray(g.particles, dtype=np.float64)[..., :6]
+        return out
+
+    def with_units(value, desc):
+        monkeypatch.setenv("LYNX_BWD_UNITS", value)
+        try:
+            return gradients(desc, np.float32)
+        finally:
+            monkeypatch.delenv("LYNX_BWD_UNITS")
+
+    # (a)
+    desc = lattice()
+    g64 = gradients(desc, np.float64)
+    structured, mixed, dense = with_units("1", desc), with_units("2", desc), with_units("0", desc)
+    for key, ref in g64.items():
+        floor = 1e-4 * max(np.max(np.abs(ref)), 1e-9 * np.max(np.abs(w_cov)))
+        assert np.all(np.abs(mixed[key] - ref) <= 3e-3 * np.abs(ref) + floor), key
+        assert np.all(np.abs(mixed[key] - structured[key]) <= 1e-3 * np.abs(ref) + floor), key
+        assert np.all(np.abs(mixed[key] - dense[key]) <= 1e-3 * np.abs(ref) + floor), key
+        # even samples went through the structured kernel as in the default pass: the same bits
+        assert np.array_equal(mixed[key][0::2], structured[key][0::2]), key
+    assert any(np.any(mixed[key][1::2] != structured[key][1::2]) for key in g64)  # (the odd ones through another kernel)
+    # (b)
+    dead = 2
+    with_dead = gradients(lattice(dead), np.float32)
+    alive = [b for b in range(B) if b != dead]
+    for key, ref in structured.items():
+        assert np.array_equal(with_dead[key][alive], ref[alive]), key  # sample by sample: nothing of the dead one leaks
+    assert not np.all(np.isfinite(with_dead["particles"][dead]))
+
+
 @pytest.mark.parametrize("dtype,B,N", [(np.float32, 3, 4000), (np.float32, 300, 512), (np.float64, 2, 3000)],
                          ids=["fp32-workgroup-build", "fp32-lanes-build", "fp64"])
 def test_the_reverse_pass_reads_the_table_of_its_forward_call(lx, monkeypatch, dtype, B, N):
