@@ -369,7 +369,12 @@ __global__ __launch_bounds__(64) void k_finish_tbar_units(BwdArgs a, int32_t S, 
   const int U = a.n_units;
   const int u = threadIdx.x;
   const float* g_units = units + b * (int64_t)U * kUnitStride;
-  if (!sample_is_class_u(g_units, U) || (a.leave_odd && (b & 1))) return;  // uniform
+  // (sample_is_class_u with one descriptor per lane, and the units' transverse entries fetched side by side into LDS: the
+  // loops below walked them one global round trip per unit and plane -- 35 us for a kernel of a few hundred operations)
+  __shared__ float s_m[kBwdUnitsMax * 12];
+  const bool other = u < U && ((__float_as_int(g_units[u * kUnitStride + kUnitDesc]) >> kUnitClassShift) & 3) != kClassU;
+  if (U > kBwdUnitsMax || __builtin_amdgcn_ballot_w64(other) != 0 || (a.leave_odd && (b & 1))) return;  // uniform
+  for (int i = u; i < U * 12; i += 64) s_m[i] = g_units[(i / 12) * kUnitStride + kUnitMap + i % 12];
   float* row0 = tbar + (b * S + a.unit_slot[0]) * (int64_t)kGradStride;
   double Sx[6], Sy[6];
 #pragma unroll
@@ -380,6 +385,7 @@ __global__ __launch_bounds__(64) void k_finish_tbar_units(BwdArgs a, int32_t S, 
   double out[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) out[k] = 0.0;
+  __syncthreads();  // s_m
   if (u < U) {
     for (int plane = 0; plane < 2; ++plane) {
       const double* Sp = plane ? Sy : Sx;
@@ -387,7 +393,7 @@ __global__ __launch_bounds__(64) void k_finish_tbar_units(BwdArgs a, int32_t S, 
       double C[6] = {1, 0, 0, 0, 1, 0}, A[4] = {1, 0, 0, 1};
       for (int v = 0; v < U; ++v) {
         if (v == u) continue;
-        const float* m = g_units + v * kUnitStride + kUnitMap + 6 * plane;
+        const float* m = s_m + v * 12 + 6 * plane;
         const double q0 = m[0], q1 = m[1], q2 = m[2], q3 = m[3], q4 = m[4], q5 = m[5];
         if (v < u) {
           const double c0 = C[0], c1 = C[1], c2 = C[2], c3 = C[3], c4 = C[4], c5 = C[5];
