@@ -830,6 +830,43 @@ __global__ __launch_bounds__(256) void k_reduce_tbar(const T* __restrict__ parti
   tbar[(b * S + s) * (int64_t)kGradStride + lane] = (T)v;
 }
 
+// The same for few workgroups per sample (chunks < 16): a wave adds up R rows (sample, step) of `chunks` partial sums each,
+// all loads of a pass in flight at once -- one wave per row was 65 536 waves of ten dependent-free loads for BASELINE
+// config 5, eight rounds of resident waves at one memory latency each (18 us).
+template <typename T, int R>
+__global__ __launch_bounds__(256) void k_reduce_tbar_rows(const T* __restrict__ partials, int chunks, int S, int64_t rows,
+                                                           T* __restrict__ tbar) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * R;
+  const T* src[R];
+  double v[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int64_t row = row0 + r < rows ? row0 + r : rows - 1;  // (clamped: read twice, written once)
+    src[r] = partials + (((row / S) * chunks) * S + row % S) * (int64_t)kGradStride + lane;
+    v[r] = 0.0;
+  }
+  const int64_t pitch = (int64_t)S * kGradStride;
+  int c = 0;
+  for (; c + 1 < chunks; c += 2) {
+    T x[R][2];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      x[r][0] = src[r][(int64_t)c * pitch];
+      x[r][1] = src[r][(int64_t)(c + 1) * pitch];
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = (v[r] + (double)x[r][0]) + (double)x[r][1];
+  }
+  if (c < chunks) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] += (double)src[r][(int64_t)c * pitch];
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    if (row0 + r < rows) tbar[(row0 + r) * (int64_t)kGradStride + lane] = (T)v[r];
+}
+
 // LDS of k_build_bwd in front of the (optional) maps: energies and their cotangents [S+1] each, the per-element
 // energy terms [E], and for each of the four waves the running cotangent A and a temporary [49] each
 template <typename T> inline size_t build_bwd_lds_fixed(int S, int E) {

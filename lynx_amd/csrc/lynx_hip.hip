@@ -2111,8 +2111,14 @@ static int track_backward_t(lynx_ctx* ctx, lynx_lattice* lat, int64_t N, const v
                      (T*)ctx->scratch_grad[0], (T*)d_grad_p_in, (const float*)d_units, kUnitStride, kUnitClassShift, (int)kClassU,
                      d_grad_observations);
   HIP_TRY(ctx, hipGetLastError());
-  hipLaunchKernelGGL(k_reduce_tbar<T>, dim3((unsigned)(B * S)), dim3(chunks >= 16 ? 256 : 64), 0, ctx->stream,
-                     (const T*)ctx->scratch_grad[0], (int)chunks, (int)S, (T*)ctx->scratch_grad[1]);
+  if (chunks >= 16) {
+    hipLaunchKernelGGL(k_reduce_tbar<T>, dim3((unsigned)(B * S)), dim3(256), 0, ctx->stream, (const T*)ctx->scratch_grad[0],
+                       (int)chunks, (int)S, (T*)ctx->scratch_grad[1]);
+  } else {  // four rows (sample, step) per wave
+    const int64_t rows = B * S;
+    hipLaunchKernelGGL((k_reduce_tbar_rows<T, 4>), dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, ctx->stream,
+                       (const T*)ctx->scratch_grad[0], (int)chunks, (int)S, rows, (T*)ctx->scratch_grad[1]);
+  }
   HIP_TRY(ctx, hipGetLastError());
   if constexpr (W == 2) {
     if (d_units) {  // class-U samples: the units' transverse blocks from the sample's S_x, S_y (lynx_grad_units.hpp)
