@@ -1128,11 +1128,12 @@ __device__ __forceinline__ void build_bwd_sample(const LatticeDev& lat, const T*
   }
 }
 
-// (float32: compiled for five waves per SIMD -- 96 registers and one accumulation register, which makes FOUR: at the 132
+// (float32: compiled for seven waves per SIMD -- 72 registers and one accumulation register, which makes SIX: at the 132
 // the compiler takes by itself three workgroups fit a CU, 768 on the GPU, and BASELINE config 5's 4096 samples are 5.3
-// rounds of them; with four they are exactly four rounds: 210 -> 173 us.  The workgroup is a latency chain, not arithmetic.)
+// rounds of them: 210 us.  Four per CU (96 registers): 173; six: 153; seven (67 registers): 150.  The workgroup is a
+// latency chain, not arithmetic: 720 bytes of scratch per lane instead of 608 cost it nothing that shows.)
 template <typename T>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? 5 : 1))) void k_build_bwd(LatticeDev lat, const T* __restrict__ energy_in,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? 7 : 1))) void k_build_bwd(LatticeDev lat, const T* __restrict__ energy_in,
                                                     T* tbar, T* __restrict__ scratch, T* __restrict__ grad_params,
                                                     T* __restrict__ grad_energy, int merged_pairs, int maps_in_lds,
                                                     const unsigned short* __restrict__ tasks, int n_tasks) {
@@ -1142,7 +1143,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 // ... of a small lattice, whose parameters come with the arguments (InlinePool, lynx_device.hpp): a reverse pass right behind
 // a parameter write does not have to bring the pool in HBM up to date first
 template <typename T, int BYTES>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? 5 : 1))) void k_build_bwd_inline(InlinePool<BYTES> /* read in place: inline_pool_view */, LatticeDev lat,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? 7 : 1))) void k_build_bwd_inline(InlinePool<BYTES> /* read in place: inline_pool_view */, LatticeDev lat,
                                                            const T* __restrict__ energy_in, T* tbar, T* __restrict__ scratch,
                                                            T* __restrict__ grad_params, T* __restrict__ grad_energy,
                                                            int merged_pairs, int maps_in_lds,
