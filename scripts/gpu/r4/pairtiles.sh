@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 4: tiles per workgroup (LYNX_MIN_TILES_PER_WG) for BASELINE config 5 with k_track_unit_pairs.
 TAG=${1:-r4pairtiles}; OUT=gpurun_out/$TAG; mkdir -p $OUT
-for v in 16 4 7 20 16 10; do
+for v in 16 7 5 4 2 16 7 5 4 2; do
   LYNX_MIN_TILES_PER_WG=$v timeout -k 10 200 python bench.py --workload c5 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/c5_tiles$v.json 2>> $OUT/err.log || exit 1
   python3 - $OUT/c5_tiles$v.json $v <<'PY'
 import json, sys
